@@ -1,0 +1,163 @@
+/* mfa_hip.h — C ABI of libmfa_hip.so: the MI355X (gfx950) alignment hot path.
+ *
+ * Drop-in boundary: the reference (Cathoven-AI/Montreal-Forced-Aligner) reaches all arithmetic on
+ * this path through the kalpy Python objects; each entry point below names the kalpy call it stands behind.  The
+ * Python host module (montreal_forced_aligner_amd/) mirrors those objects and binds these symbols with ctypes —
+ * INTEGRATION.md shows the binding a maintainer would add.
+ *
+ * Conventions
+ *  - Every function returns 0 on success, <0 on error; mfa_last_error(ctx) gives the message.  No exceptions cross
+ *    the ABI.  A per-utterance alignment failure is NOT an error: it is reported in status[] (the reference counts
+ *    failures and raises only if none succeed — MFA/alignment/mixins.py:305-324).
+ *  - Pointers named d_* are DEVICE pointers owned by the caller (torch tensors or mfa_device_alloc); h_* are host
+ *    pointers.  The library never frees caller memory.  All work is enqueued on the ctx stream (mfa_set_stream);
+ *    nothing synchronises unless the name says so.
+ *  - Ragged batches use CSR offsets: frame_off[u]..frame_off[u+1] are the rows of utterance u.
+ *  - One ctx per (process, GPU); calls on a ctx are serialised by the caller.
+ */
+#ifndef MFA_HIP_H_
+#define MFA_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MFA_API __attribute__((visibility("default")))
+
+typedef struct mfa_ctx mfa_ctx;
+
+/* ---- context ------------------------------------------------------------------------------------------------ */
+MFA_API mfa_ctx *mfa_create(int device_id);
+MFA_API void mfa_destroy(mfa_ctx *ctx);
+MFA_API const char *mfa_last_error(mfa_ctx *ctx);
+MFA_API int mfa_version(void);
+/* Enqueue on the caller's hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = the ctx's own stream. */
+MFA_API int mfa_set_stream(mfa_ctx *ctx, void *hip_stream);
+MFA_API int mfa_synchronize(mfa_ctx *ctx);
+/* Device-memory helpers for callers without torch. */
+MFA_API void *mfa_device_alloc(mfa_ctx *ctx, size_t bytes);
+MFA_API int mfa_device_free(mfa_ctx *ctx, void *d_ptr);
+MFA_API int mfa_memcpy_h2d(mfa_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+MFA_API int mfa_memcpy_d2h(mfa_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+/* HIP-event timing of everything enqueued between begin and end on the ctx stream (bench.py's roofline leg). */
+MFA_API int mfa_timer_begin(mfa_ctx *ctx);
+MFA_API int mfa_timer_end_ms(mfa_ctx *ctx, float *h_ms);
+/* Per-kernel accumulated HIP-event times since the last reset.  which: 0 mfcc, 1 cmvn, 2 feats, 3 gmm, 4 viterbi.
+ * Enabled with mfa_kernel_timing(ctx, 1) (adds an event pair around each launch). */
+MFA_API int mfa_kernel_timing(mfa_ctx *ctx, int enable);
+MFA_API int mfa_kernel_time_ms(mfa_ctx *ctx, int which, float *h_ms, int *h_launches);
+MFA_API int mfa_kernel_time_reset(mfa_ctx *ctx);
+
+/* ---- MFCC: replaces kalpy.feat.mfcc.MfccComputer(**mfcc_options).compute_mfccs[_for_export]
+ *      (MFA/corpus/features.py:193-251, :235; MFA/online/alignment.py:83; options MFA/corpus/features.py:780-820). */
+typedef struct {
+  float sample_frequency;   /* 16000 */
+  float frame_length_ms;    /* 25 */
+  float frame_shift_ms;     /* 10 */
+  float preemphasis;        /* 0.97 */
+  float low_frequency;      /* 20 */
+  float high_frequency;     /* 7800 (<=0: relative to Nyquist) */
+  float cepstral_lifter;    /* 22 */
+  float energy_floor;       /* 0 */
+  int32_t num_mel_bins;     /* 23 */
+  int32_t num_coefficients; /* 13 */
+  int32_t snip_edges;       /* MFA default 0 */
+  int32_t remove_dc_offset; /* 1 */
+  int32_t use_energy;       /* 0 */
+  int32_t raw_energy;       /* 1 */
+} mfa_mfcc_opts;
+
+MFA_API int mfa_mfcc_configure(mfa_ctx *ctx, const mfa_mfcc_opts *opts);
+/* Frames Kaldi extracts from num_samples samples under the configured options (host arithmetic). */
+MFA_API int32_t mfa_mfcc_num_frames(mfa_ctx *ctx, int64_t num_samples);
+/* d_pcm: int16 samples of all utterances back to back; d_sample_off[n_utt+1]; d_frame_off[n_utt+1] (host computes
+ * them with mfa_mfcc_num_frames); d_mfcc: float32 [total_frames][num_coefficients].  max_frames = longest utterance. */
+MFA_API int mfa_mfcc_batch(mfa_ctx *ctx, const int16_t *d_pcm, const int64_t *d_sample_off, const int64_t *d_frame_off,
+                           int32_t n_utt, int32_t max_frames, float *d_mfcc);
+
+/* ---- CMVN statistics: replaces CmvnComputer().compute_cmvn_from_features / export_cmvn
+ *      (MFA/corpus/acoustic_corpus.py:1315-1367; MFA/online/alignment.py:86-88).
+ * d_spk_utt_off[n_spk+1] / d_spk_utt[…]: utterances of each speaker; d_stats: float64 [n_spk][2][dim+1]
+ * (row 0: sums + count, row 1: sums of squares — Kaldi's layout).  Deterministic summation order. */
+MFA_API int mfa_cmvn_stats(mfa_ctx *ctx, const float *d_feats, const int64_t *d_frame_off, int32_t n_utt, int32_t dim,
+                           const int32_t *d_spk_utt_off, const int32_t *d_spk_utt, int32_t n_spk, double *d_stats);
+
+/* ---- Final features: replaces FeatureArchive(..., cmvn, deltas | lda_mat, transform) iteration / the explicit chain at
+ *      MFA/alignment/multiprocessing.py:1287-1304: ApplyCmvn → compute_deltas | splice_frames+LDA → fMLLR.
+ * mode 0: CMVN + Δ+ΔΔ (order 2, window 2): out dim = 3*dim.
+ * mode 1: CMVN + splice(±ctx) + LDA d_lda[lda_rows][lda_cols] (+ fMLLR d_fmllr[n_spk][lda_rows][lda_rows+1] if non-NULL).
+ * d_utt2spk[n_utt]; d_cmvn may be NULL (no CMVN). */
+MFA_API int mfa_feats_batch(mfa_ctx *ctx, const float *d_mfcc, const int64_t *d_frame_off, int32_t n_utt, int32_t max_frames,
+                            int32_t dim, const int32_t *d_utt2spk, const double *d_cmvn, int32_t mode, int32_t splice_ctx,
+                            const float *d_lda, int32_t lda_rows, int32_t lda_cols, const float *d_fmllr, float *d_out);
+
+/* ---- Acoustic model: replaces GmmAligner.__init__'s model load (+ .boost_silence, applied by the host to gconsts)
+ *      (MFA/alignment/multiprocessing.py:814-815).  Host arrays, SoA over all Gaussians:
+ * gconsts[G], means_invvars[G][dim], inv_vars[G][dim], pdf_offsets[num_pdfs+1].  Packs them for the MFMA kernel. */
+MFA_API int mfa_load_gmm(mfa_ctx *ctx, int32_t dim, int32_t num_pdfs, const int32_t *h_pdf_offsets, const float *h_gconsts,
+                         const float *h_means_invvars, const float *h_inv_vars);
+/* Slot class of a pdf in the packed model (rows it occupies in an MFMA block: 1, 4, 8, 16 or 32); the host must order
+ * each utterance's pdf list by descending slot class (mfa_gmm_sort_pdf_list does it). */
+MFA_API int32_t mfa_gmm_slot(mfa_ctx *ctx, int32_t pdf);
+/* Sort h_pdfs[n] in place into the order the scoring kernel requires; h_class_counts[5] receives how many pdfs fall in
+ * slot classes 32,16,8,4,1. */
+MFA_API int mfa_gmm_sort_pdf_list(mfa_ctx *ctx, int32_t *h_pdfs, int32_t n, int32_t *h_class_counts);
+
+/* ---- Acoustic scoring: replaces DecodableAmDiagGmmScaled::LogLikelihood inside GmmAligner.align_utterance and
+ *      gmm_compute_likes (MFA/alignment/multiprocessing.py:846-853, :1415).
+ * Per utterance u: pdf list d_pdf_list[pdf_off[u]..pdf_off[u+1]) (sorted as above) with d_class_counts[u][5];
+ * output d_loglikes + ll_off[u]: float32 [T_u][P_u] row-major (UNSCALED log-likelihoods). */
+MFA_API int mfa_gmm_score_batch(mfa_ctx *ctx, const float *d_feats, const int64_t *d_frame_off, int32_t n_utt,
+                                int32_t max_frames, const int32_t *d_pdf_list, const int64_t *d_pdf_off,
+                                const int32_t *d_class_counts, const int64_t *d_ll_off, float *d_loglikes);
+
+/* ---- Alignment: replaces GmmAligner.align_utterance(fst, feats) / .export_alignments
+ *      (MFA/alignment/multiprocessing.py:846-853, :1311-1315; MFA/online/alignment.py:107) = Kaldi AddTransitionProbs
+ *      (done by the host on the arc weights) + AlignUtteranceWrapper + FasterDecoder (beam, min_active 20,
+ *      beam_delta 0.5, hash_ratio 2.0) with exactly Kaldi's pruning and tie-breaking order.
+ * Graph u (epsilon-free): states state_off[u]..state_off[u+1]; d_arc_off[global_state] .. [global_state+1] index the
+ * arc arrays RELATIVE to arc_base[u]; start state d_start[u]; d_final[global_state] (+inf = non-final).
+ * Arcs (SoA): d_arc_next (local state), d_arc_weight (graph cost incl. transition probs), d_arc_col (column of the
+ * utterance's log-likelihood matrix = position of pdf(tid) in its pdf list), d_arc_ilabel (transition-id),
+ * d_arc_olabel (word id). */
+typedef struct {
+  int32_t n_utt;
+  const int64_t *d_state_off; /* [n_utt+1] */
+  const int64_t *d_arc_base;  /* [n_utt+1] */
+  const int32_t *d_start;     /* [n_utt] */
+  const int32_t *d_arc_off;   /* [total_states + n_utt] : per utterance S_u+1 entries, at state_off[u]+u */
+  const float *d_final;       /* [total_states] */
+  const int32_t *d_arc_next;
+  const float *d_arc_weight;
+  const int32_t *d_arc_col;
+  const int32_t *d_arc_ilabel;
+  const int32_t *d_arc_olabel;
+} mfa_graph_batch;
+
+typedef struct {
+  float beam;            /* 10 */
+  float retry_beam;      /* 40; 0 = no retry */
+  float acoustic_scale;  /* 0.1 */
+  int32_t max_tokens;    /* live-token capacity per utterance (LDS-resident tables), e.g. 1024 */
+  int32_t bp_tokens_per_frame; /* back-pointer capacity per utterance = T_u * this, e.g. 512 */
+} mfa_align_opts;
+
+/* d_utt_list: which utterances to decode (NULL = all n_utt); outputs (device):
+ *   d_ali [total_frames] transition-ids (at frame_off), d_words [total_frames] word ids packed at frame_off[u] with
+ *   d_n_words[u] valid entries, d_like[u] = -(graph+acoustic cost)/acoustic_scale, d_frame_like [total_frames] or NULL,
+ *   d_status[u]: 0 ok, 1 ok after retry, 2 no final token (failed), 3 token-capacity overflow, 4 back-pointer overflow.
+ * max_states = largest S_u in the batch. */
+MFA_API int mfa_align_batch(mfa_ctx *ctx, const mfa_graph_batch *graphs, const float *d_loglikes, const int64_t *d_ll_off,
+                            const int32_t *d_ll_cols, const int64_t *d_frame_off, int32_t max_states,
+                            const mfa_align_opts *opts, int32_t *d_ali, int32_t *d_words, int32_t *d_n_words,
+                            float *d_like, float *d_frame_like, int32_t *d_status);
+/* Bytes of device workspace mfa_align_batch will hold for a batch shape (so callers can budget HBM). */
+MFA_API size_t mfa_align_workspace_bytes(mfa_ctx *ctx, int32_t n_utt, int64_t total_frames, const mfa_align_opts *opts);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MFA_HIP_H_ */

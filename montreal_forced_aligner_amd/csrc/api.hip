@@ -1,0 +1,118 @@
+// Context management, memory helpers and timing for libmfa_hip.so.
+#include "ctx.hpp"
+
+extern "C" {
+
+MFA_API int mfa_version(void) { return 1; }
+
+MFA_API mfa_ctx *mfa_create(int device_id) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || device_id < 0 || device_id >= n) return nullptr;
+  if (hipSetDevice(device_id) != hipSuccess) return nullptr;
+  mfa_ctx *c = new mfa_ctx();
+  c->device = device_id;
+  if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; }
+  c->stream = c->own_stream;
+  hipEventCreate(&c->t0);
+  hipEventCreate(&c->t1);
+  return c;
+}
+
+MFA_API void mfa_destroy(mfa_ctx *c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  hipStreamSynchronize(c->stream);
+  void *ptrs[] = {c->d_window, c->d_twiddle, c->d_melw, c->d_melidx, c->d_dct, c->d_lifter, c->d_w, c->d_gc,
+                  c->d_row0, c->d_nblk, c->d_slot, c->d_ws};
+  for (void *p : ptrs) if (p) hipFree(p);
+  for (auto &p : c->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+  for (auto e : c->event_pool) hipEventDestroy(e);
+  hipEventDestroy(c->t0);
+  hipEventDestroy(c->t1);
+  hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+MFA_API const char *mfa_last_error(mfa_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+MFA_API int mfa_set_stream(mfa_ctx *c, void *s) {
+  if (!c) return -1;
+  c->stream = s ? (hipStream_t)s : c->own_stream;
+  return 0;
+}
+
+MFA_API int mfa_synchronize(mfa_ctx *c) {
+  MFA_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+MFA_API void *mfa_device_alloc(mfa_ctx *c, size_t bytes) {
+  void *p = nullptr;
+  hipSetDevice(c->device);
+  if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) { c->fail("hipMalloc(%zu) failed", bytes); return nullptr; }
+  return p;
+}
+
+MFA_API int mfa_device_free(mfa_ctx *c, void *p) {
+  MFA_HIP_CHECK(c, hipFree(p));
+  return 0;
+}
+
+MFA_API int mfa_memcpy_h2d(mfa_ctx *c, void *d, const void *h, size_t bytes) {
+  MFA_HIP_CHECK(c, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream));
+  MFA_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+MFA_API int mfa_memcpy_d2h(mfa_ctx *c, void *h, const void *d, size_t bytes) {
+  MFA_HIP_CHECK(c, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, c->stream));
+  MFA_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+MFA_API int mfa_timer_begin(mfa_ctx *c) {
+  MFA_HIP_CHECK(c, hipEventRecord(c->t0, c->stream));
+  return 0;
+}
+
+MFA_API int mfa_timer_end_ms(mfa_ctx *c, float *ms) {
+  MFA_HIP_CHECK(c, hipEventRecord(c->t1, c->stream));
+  MFA_HIP_CHECK(c, hipEventSynchronize(c->t1));
+  MFA_HIP_CHECK(c, hipEventElapsedTime(ms, c->t0, c->t1));
+  return 0;
+}
+
+MFA_API int mfa_kernel_timing(mfa_ctx *c, int enable) {
+  c->kernel_timing = enable != 0;
+  return 0;
+}
+
+MFA_API int mfa_kernel_time_ms(mfa_ctx *c, int which, float *ms, int *launches) {
+  if (which < 0 || which >= MFA_K_COUNT) return c->fail("bad kernel id %d", which);
+  if (mfa_resolve_timers(c) != 0) return -1;
+  *ms = (float)c->k_ms[which];
+  if (launches) *launches = c->k_n[which];
+  return 0;
+}
+
+MFA_API int mfa_kernel_time_reset(mfa_ctx *c) {
+  if (mfa_resolve_timers(c) != 0) return -1;
+  for (int i = 0; i < MFA_K_COUNT; i++) { c->k_ms[i] = 0; c->k_n[i] = 0; }
+  return 0;
+}
+
+}  // extern "C"
+
+int mfa_resolve_timers(mfa_ctx *c) {
+  for (auto &p : c->pending) {
+    MFA_HIP_CHECK(c, hipEventSynchronize(p.b));
+    float ms = 0;
+    MFA_HIP_CHECK(c, hipEventElapsedTime(&ms, p.a, p.b));
+    c->k_ms[p.which] += ms;
+    c->k_n[p.which] += 1;
+    c->event_pool.push_back(p.a);
+    c->event_pool.push_back(p.b);
+  }
+  c->pending.clear();
+  return 0;
+}

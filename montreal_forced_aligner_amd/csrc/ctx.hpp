@@ -1,0 +1,91 @@
+// Internal context of libmfa_hip.so (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/mfa_hip.h"
+
+enum { MFA_K_MFCC = 0, MFA_K_CMVN = 1, MFA_K_FEATS = 2, MFA_K_GMM = 3, MFA_K_VITERBI = 4, MFA_K_COUNT = 5 };
+
+struct mfa_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  // timing
+  hipEvent_t t0 = nullptr, t1 = nullptr;
+  bool kernel_timing = false;
+  struct Pending { int which; hipEvent_t a, b; };
+  std::vector<Pending> pending;
+  double k_ms[MFA_K_COUNT] = {0, 0, 0, 0, 0};
+  int k_n[MFA_K_COUNT] = {0, 0, 0, 0, 0};
+  std::vector<hipEvent_t> event_pool;
+
+  // MFCC tables (device)
+  mfa_mfcc_opts mfcc{};
+  bool mfcc_ready = false;
+  int win = 0, shift = 0, nfft = 0;
+  float *d_window = nullptr;   // [win]
+  float *d_twiddle = nullptr;  // [nfft/2][2] cos,sin of -2*pi*k/nfft ... see mfcc.hip
+  float *d_melw = nullptr;     // [nbins][2] packed sparse: see mfcc.hip
+  int32_t *d_melidx = nullptr;
+  float *d_dct = nullptr;      // [nceps][nbins] with lifter folded separately
+  float *d_lifter = nullptr;   // [nceps]
+
+  // GMM model (device)
+  bool gmm_ready = false;
+  int dim = 0, kpad = 0, num_pdfs = 0, num_rows = 0;
+  float *d_w = nullptr;        // [num_rows][kpad] permuted weights
+  float *d_gc = nullptr;       // [num_rows]
+  int32_t *d_row0 = nullptr;   // [num_pdfs] first packed row
+  int32_t *d_nblk = nullptr;   // [num_pdfs] number of 32-row blocks (slot 32) else 1
+  int32_t *d_slot = nullptr;   // [num_pdfs] slot class rows (1,4,8,16,32)
+  std::vector<int32_t> h_slot;
+
+  // Viterbi workspace
+  void *d_ws = nullptr;
+  size_t ws_bytes = 0;
+
+  int fail(const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    err = buf;
+    return -1;
+  }
+};
+
+#define MFA_HIP_CHECK(ctx, expr)                                                                 \
+  do {                                                                                           \
+    hipError_t _e = (expr);                                                                      \
+    if (_e != hipSuccess) return (ctx)->fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+
+// Scoped per-kernel timing (HIP events on the ctx stream, resolved lazily).
+struct KernelTimer {
+  mfa_ctx *c; int which; hipEvent_t a = nullptr, b = nullptr;
+  KernelTimer(mfa_ctx *ctx, int w) : c(ctx), which(w) {
+    if (!c->kernel_timing) return;
+    a = get(); b = get();
+    hipEventRecord(a, c->stream);
+  }
+  ~KernelTimer() {
+    if (!c->kernel_timing) return;
+    hipEventRecord(b, c->stream);
+    c->pending.push_back({which, a, b});
+  }
+  hipEvent_t get() {
+    if (!c->event_pool.empty()) { hipEvent_t e = c->event_pool.back(); c->event_pool.pop_back(); return e; }
+    hipEvent_t e; hipEventCreate(&e); return e;
+  }
+};
+
+int mfa_resolve_timers(mfa_ctx *ctx);

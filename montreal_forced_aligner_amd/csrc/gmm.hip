@@ -1,0 +1,415 @@
+// Diagonal-GMM acoustic scoring on gfx950 with exact-f32 MFMA (v_mfma_f32_32x32x2_f32).
+// Replaces DecodableAmDiagGmmScaled::LogLikelihood / gmm_compute_likes (MFA/alignment/multiprocessing.py:846-853, :1415;
+// Kaldi gmm/decodable-am-diag-gmm.cc, VectorBase<float>::LogSumExp).
+//
+// Per Gaussian:  ll = gconst + Σ_d means_invvars[d]·x[d] + Σ_d (−½ inv_vars[d])·x[d]²   — a [rows × 2D]·[2D × frames]
+// contraction.  The MFMA accumulates a k-ordered fmaf chain starting from C = gconst, i.e. bit for bit the oracle's chain.
+// Per pdf:       LL = max + log Σ_{ll ≥ max+ln ε} exp(ll − max)  (exp in f32, sum and log in f64, as Kaldi).
+//
+// Packed model (built once in mfa_load_gmm): every pdf owns `slot` consecutive rows of W[rows][kpad]
+// (slot ∈ {1,4,8,16,32·n}; pad rows have zero weights and gconst −1e30 so they fall under the cutoff).  Within each group
+// of 8 k-values a row is stored permuted, stored[8m+4h+c] = logical[8m+2c+h], so that one 16-byte load per lane yields the
+// A operands of four consecutive MFMA steps (lane l feeds A[row l&31][k = 2s + (l>>5)]).
+// One 32-row MFMA block then serves 32/slot pdfs of the utterance's (slot-sorted) pdf list; rows ↔ accumulator registers:
+// row = (r&3) + 8(r>>2) + 4(l>>5), so 4-row slots reduce inside a lane and 8/16/32-row slots add one cross-half shuffle.
+//
+// Work decomposition: grid (frame tiles of 256, utterances); a wavefront owns NT×32 frames, keeps their x̃ = [x, x²]
+// operands in registers (the B side) and streams the utterance's model rows (the A side, L2/MALL-resident).
+// Output: [T][P_u] row-major, the layout the Viterbi kernel gathers from.
+#include <cmath>
+#include <cstdlib>
+#include <vector>
+
+#include "ctx.hpp"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kNT = 2;                 // 32-frame tiles per wavefront
+constexpr int kFramesPerWave = 32 * kNT;
+constexpr int kWaves = 4;
+constexpr float kPadGconst = -1.0e30f;
+
+struct GmmParams {
+  int dim, kpad, num_rows;  // num_rows = index of the dummy row
+  const float *w; const float *gc; const int32_t *row0; const int32_t *nblk;
+  const float *feats; const int64_t *frame_off;
+  const int32_t *pdf_list; const int64_t *pdf_off; const int32_t *class_counts; const int64_t *ll_off;
+  float *out;
+  float min_log_diff;  // logf(FLT_EPSILON), computed on the host so device and oracle use the same constant
+};
+
+__device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __shfl_xor(lo, mask); hi = __shfl_xor(hi, mask);
+  return __hiloint2double(hi, lo);
+}
+
+// row index (within a 32-row MFMA block) held by accumulator register r of a lane in half h
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+template <int M8>
+struct Tile {
+  // One wavefront: B operands for kNT frame tiles, generic block evaluation.
+  float b[kNT][4 * M8];
+
+  __device__ __forceinline__ void load_b(const GmmParams &p, int64_t f0, int T, int t_base, int lane) {
+    const int col = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int n = 0; n < kNT; n++) {
+      int t = t_base + 32 * n + col;
+      t = t < T ? t : T - 1;
+      const float *x = p.feats + (f0 + t) * p.dim;
+#pragma unroll
+      for (int s = 0; s < 4 * M8; s++) {
+        int k = 2 * s + h;
+        float v = 0.0f;
+        if (k < p.dim) v = x[k];
+        else if (k < 2 * p.dim) { float xv = x[k - p.dim]; v = xv * xv; }
+        b[n][s] = v;
+      }
+    }
+  }
+
+  // acc[n] = gconst(rows) + W(block rows) · x̃(tile n).  arow: this lane's A row (already offset by 4h floats);
+  // gcv: gconst of the row this lane (lane&31) addresses.
+  __device__ __forceinline__ void block(const float *arow, float gcv, int lane, f32x16 (&acc)[kNT]) const {
+    const int h = lane >> 5;
+    f32x4 a[M8];
+#pragma unroll
+    for (int m = 0; m < M8; m++) a[m] = *reinterpret_cast<const f32x4 *>(arow + 8 * m);
+    f32x16 init;
+#pragma unroll
+    for (int r = 0; r < 16; r++) init[r] = __shfl(gcv, acc_row(r, h));
+#pragma unroll
+    for (int n = 0; n < kNT; n++) acc[n] = init;
+#pragma unroll
+    for (int m = 0; m < M8; m++) {
+#pragma unroll
+      for (int cc = 0; cc < 4; cc++) {
+#pragma unroll
+        for (int n = 0; n < kNT; n++)
+          acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][cc], b[n][4 * m + cc], acc[n], 0, 0, 0);
+      }
+    }
+  }
+};
+
+// log-sum-exp pieces (Kaldi LogSumExp semantics)
+template <int R0, int R1>
+__device__ __forceinline__ float reg_max(const f32x16 &v) {
+  float m = v[R0];
+#pragma unroll
+  for (int r = R0 + 1; r < R1; r++) m = fmaxf(m, v[r]);
+  return m;
+}
+template <int R0, int R1>
+__device__ __forceinline__ double reg_expsum(const f32x16 &v, float mx, float cutoff) {
+  double s = 0.0;
+#pragma unroll
+  for (int r = R0; r < R1; r++)
+    if (v[r] >= cutoff) s += (double)expf(v[r] - mx);
+  return s;
+}
+__device__ __forceinline__ float finish(float mx, double sum) { return (float)((double)mx + log(sum)); }
+
+template <int M8>
+__global__ __launch_bounds__(256, 2) void gmm_kernel(GmmParams p) {
+  const int utt = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t f0 = p.frame_off[utt];
+  const int T = (int)(p.frame_off[utt + 1] - f0);
+  const int t_base = (blockIdx.x * kWaves + wave) * kFramesPerWave;
+  if (t_base >= T) return;  // wavefronts are independent (no barriers in this kernel)
+  const int col = lane & 31, h = lane >> 5;
+  const int64_t l0 = p.pdf_off[utt];
+  const int P = (int)(p.pdf_off[utt + 1] - l0);
+  const int32_t *list = p.pdf_list + l0;
+  const int32_t *cc = p.class_counts + (size_t)utt * 5;
+  float *out = p.out + p.ll_off[utt];
+
+  Tile<M8> tile;
+  tile.load_b(p, f0, T, t_base, lane);
+  f32x16 acc[kNT];
+
+  // ---- slot 32 (one pdf per block; pdfs with more than 32 Gaussians take several blocks, two passes)
+  const int n32 = cc[0];
+  for (int j = 0; j < n32; j++) {
+    const int pdf = list[j];
+    const int r0 = p.row0[pdf], nb = p.nblk[pdf];
+    float mx[kNT]; double sum[kNT];
+    if (nb == 1) {
+      const float *arow = p.w + (size_t)(r0 + col) * p.kpad + 4 * h;
+      tile.block(arow, p.gc[r0 + col], lane, acc);
+#pragma unroll
+      for (int n = 0; n < kNT; n++) {
+        float m = reg_max<0, 16>(acc[n]);
+        m = fmaxf(m, __shfl_xor(m, 32));
+        double s = reg_expsum<0, 16>(acc[n], m, m + p.min_log_diff);
+        s += shfl_xor_f64(s, 32);
+        mx[n] = m; sum[n] = s;
+      }
+    } else {
+#pragma unroll
+      for (int n = 0; n < kNT; n++) { mx[n] = -INFINITY; sum[n] = 0.0; }
+      for (int blk = 0; blk < nb; blk++) {
+        const int rr = r0 + 32 * blk + col;
+        tile.block(p.w + (size_t)rr * p.kpad + 4 * h, p.gc[rr], lane, acc);
+#pragma unroll
+        for (int n = 0; n < kNT; n++) {
+          float m = reg_max<0, 16>(acc[n]);
+          m = fmaxf(m, __shfl_xor(m, 32));
+          mx[n] = fmaxf(mx[n], m);
+        }
+      }
+      for (int blk = 0; blk < nb; blk++) {
+        const int rr = r0 + 32 * blk + col;
+        tile.block(p.w + (size_t)rr * p.kpad + 4 * h, p.gc[rr], lane, acc);
+#pragma unroll
+        for (int n = 0; n < kNT; n++) {
+          double s = reg_expsum<0, 16>(acc[n], mx[n], mx[n] + p.min_log_diff);
+          s += shfl_xor_f64(s, 32);
+          sum[n] += s;
+        }
+      }
+    }
+#pragma unroll
+    for (int n = 0; n < kNT; n++) {
+      int t = t_base + 32 * n + col;
+      if (h == 0 && t < T) out[(size_t)t * P + j] = finish(mx[n], sum[n]);
+    }
+  }
+
+  // ---- smaller slots: 32/slot pdfs share one MFMA block
+  int base = n32;
+  // slot 16
+  for (int j = 0; j < cc[1]; j += 2) {
+    const int which = col >> 4, within = col & 15;
+    const int idx = j + which;
+    const int row = idx < cc[1] ? p.row0[list[base + idx]] + within : p.num_rows;
+    tile.block(p.w + (size_t)row * p.kpad + 4 * h, p.gc[row], lane, acc);
+#pragma unroll
+    for (int n = 0; n < kNT; n++) {
+      int t = t_base + 32 * n + col;
+      float m0 = reg_max<0, 8>(acc[n]), m1 = reg_max<8, 16>(acc[n]);
+      m0 = fmaxf(m0, __shfl_xor(m0, 32)); m1 = fmaxf(m1, __shfl_xor(m1, 32));
+      double s0 = reg_expsum<0, 8>(acc[n], m0, m0 + p.min_log_diff), s1 = reg_expsum<8, 16>(acc[n], m1, m1 + p.min_log_diff);
+      s0 += shfl_xor_f64(s0, 32); s1 += shfl_xor_f64(s1, 32);
+      if (h == 0 && t < T) {
+        out[(size_t)t * P + base + j] = finish(m0, s0);
+        if (j + 1 < cc[1]) out[(size_t)t * P + base + j + 1] = finish(m1, s1);
+      }
+    }
+  }
+  base += cc[1];
+  // slot 8
+  for (int j = 0; j < cc[2]; j += 4) {
+    const int which = col >> 3, within = col & 7;
+    const int idx = j + which;
+    const int row = idx < cc[2] ? p.row0[list[base + idx]] + within : p.num_rows;
+    tile.block(p.w + (size_t)row * p.kpad + 4 * h, p.gc[row], lane, acc);
+#pragma unroll
+    for (int n = 0; n < kNT; n++) {
+      int t = t_base + 32 * n + col;
+      float m[4]; double s[4];
+      m[0] = reg_max<0, 4>(acc[n]); m[1] = reg_max<4, 8>(acc[n]); m[2] = reg_max<8, 12>(acc[n]); m[3] = reg_max<12, 16>(acc[n]);
+#pragma unroll
+      for (int q = 0; q < 4; q++) m[q] = fmaxf(m[q], __shfl_xor(m[q], 32));
+      s[0] = reg_expsum<0, 4>(acc[n], m[0], m[0] + p.min_log_diff); s[1] = reg_expsum<4, 8>(acc[n], m[1], m[1] + p.min_log_diff);
+      s[2] = reg_expsum<8, 12>(acc[n], m[2], m[2] + p.min_log_diff); s[3] = reg_expsum<12, 16>(acc[n], m[3], m[3] + p.min_log_diff);
+#pragma unroll
+      for (int q = 0; q < 4; q++) s[q] += shfl_xor_f64(s[q], 32);
+      if (h == 0 && t < T) {
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+          if (j + q < cc[2]) out[(size_t)t * P + base + j + q] = finish(m[q], s[q]);
+      }
+    }
+  }
+  base += cc[2];
+  // slot 4: rows 8q+4h..8q+4h+3 live in registers 4q..4q+3 of one lane → pdf index 2q+h, no shuffle
+  for (int j = 0; j < cc[3]; j += 8) {
+    const int which = col >> 2, within = col & 3;
+    const int idx = j + which;
+    const int row = idx < cc[3] ? p.row0[list[base + idx]] + within : p.num_rows;
+    tile.block(p.w + (size_t)row * p.kpad + 4 * h, p.gc[row], lane, acc);
+#pragma unroll
+    for (int n = 0; n < kNT; n++) {
+      int t = t_base + 32 * n + col;
+      float m[4]; double s[4];
+      m[0] = reg_max<0, 4>(acc[n]); m[1] = reg_max<4, 8>(acc[n]); m[2] = reg_max<8, 12>(acc[n]); m[3] = reg_max<12, 16>(acc[n]);
+      s[0] = reg_expsum<0, 4>(acc[n], m[0], m[0] + p.min_log_diff); s[1] = reg_expsum<4, 8>(acc[n], m[1], m[1] + p.min_log_diff);
+      s[2] = reg_expsum<8, 12>(acc[n], m[2], m[2] + p.min_log_diff); s[3] = reg_expsum<12, 16>(acc[n], m[3], m[3] + p.min_log_diff);
+      if (t < T) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          int pi = j + 2 * q + h;
+          if (pi < cc[3]) out[(size_t)t * P + base + pi] = finish(m[q], s[q]);
+        }
+      }
+    }
+  }
+  base += cc[3];
+  // slot 1: every row is its own single-Gaussian pdf: LL = ll (max + log(1) exactly)
+  for (int j = 0; j < cc[4]; j += 32) {
+    const int idx = j + col;
+    const int row = idx < cc[4] ? p.row0[list[base + idx]] : p.num_rows;
+    tile.block(p.w + (size_t)row * p.kpad + 4 * h, p.gc[row], lane, acc);
+#pragma unroll
+    for (int n = 0; n < kNT; n++) {
+      int t = t_base + 32 * n + col;
+      if (t < T) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          int pi = j + acc_row(r, h);
+          if (pi < cc[4]) out[(size_t)t * P + base + pi] = acc[n][r];
+        }
+      }
+    }
+  }
+}
+
+// Straightforward one-thread-per-(frame,pdf) kernel: used for feature dims the MFMA kernel is not instantiated for and,
+// with MFA_GMM_NAIVE=1, as an on-device cross-check of the MFMA path.  Same fmaf chain, same log-sum-exp.
+__global__ void gmm_naive_kernel(GmmParams p) {
+  const int utt = blockIdx.y;
+  const int64_t f0 = p.frame_off[utt];
+  const int T = (int)(p.frame_off[utt + 1] - f0);
+  const int64_t l0 = p.pdf_off[utt];
+  const int P = (int)(p.pdf_off[utt + 1] - l0);
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)T * P) return;
+  const int t = (int)(idx / P), j = (int)(idx % P);
+  const int pdf = p.pdf_list[l0 + j];
+  const int r0 = p.row0[pdf];
+  const int rows = p.row0[pdf + 1] - r0;  // row0 has num_pdfs+1 entries; pad rows carry gconst -1e30
+  const float *x = p.feats + (f0 + t) * p.dim;
+  float mx = -INFINITY;
+  double sum = 0.0;
+  for (int pass = 0; pass < 2; pass++) {
+    for (int r = 0; r < rows; r++) {
+      const float *w = p.w + (size_t)(r0 + r) * p.kpad;
+      float acc = p.gc[r0 + r];
+      for (int k = 0; k < 2 * p.dim; k++) {
+        int m = k >> 3, o = k & 7;  // logical k = 8m + 2c + h is stored at 8m + 4h + c
+        float xv = k < p.dim ? x[k] : x[k - p.dim] * x[k - p.dim];
+        acc = fmaf(w[8 * m + 4 * (o & 1) + (o >> 1)], xv, acc);
+      }
+      if (pass == 0) mx = fmaxf(mx, acc);
+      else if (acc >= mx + p.min_log_diff) sum += (double)expf(acc - mx);
+    }
+  }
+  p.out[p.ll_off[utt] + (size_t)t * P + j] = (float)((double)mx + log(sum));
+}
+
+int slot_of(int g) { return g <= 1 ? 1 : g <= 4 ? 4 : g <= 8 ? 8 : g <= 16 ? 16 : 32; }
+int class_index(int slot) { return slot == 32 ? 0 : slot == 16 ? 1 : slot == 8 ? 2 : slot == 4 ? 3 : 4; }
+
+}  // namespace
+
+extern "C" {
+
+MFA_API int mfa_load_gmm(mfa_ctx *c, int32_t dim, int32_t num_pdfs, const int32_t *h_pdf_offsets, const float *h_gconsts,
+                         const float *h_means_invvars, const float *h_inv_vars) {
+  hipSetDevice(c->device);
+  if (dim <= 0 || num_pdfs <= 0) return c->fail("mfa_load_gmm: bad dim/num_pdfs %d/%d", dim, num_pdfs);
+  // the MFMA kernel is instantiated for rows of exactly 80 or 96 floats; wider models use the naive kernel
+  const int kpad = 2 * dim <= 80 ? 80 : (2 * dim <= 96 ? 96 : ((2 * dim + 7) / 8) * 8);
+  std::vector<int32_t> row0(num_pdfs + 1), nblk(num_pdfs), slot(num_pdfs);
+  int rows = 0;
+  for (int p = 0; p < num_pdfs; p++) {
+    int g = h_pdf_offsets[p + 1] - h_pdf_offsets[p];
+    if (g <= 0) return c->fail("mfa_load_gmm: pdf %d has no Gaussians", p);
+    int s = slot_of(g);
+    slot[p] = s;
+    nblk[p] = s == 32 ? (g + 31) / 32 : 1;
+    row0[p] = rows;
+    rows += s == 32 ? 32 * nblk[p] : s;
+  }
+  row0[num_pdfs] = rows;
+  std::vector<float> w((size_t)(rows + 1) * kpad, 0.0f), gc(rows + 1, kPadGconst);
+  for (int p = 0; p < num_pdfs; p++) {
+    int g0 = h_pdf_offsets[p], g = h_pdf_offsets[p + 1] - g0;
+    for (int i = 0; i < g; i++) {
+      float *dst = w.data() + (size_t)(row0[p] + i) * kpad;
+      const float *mi = h_means_invvars + (size_t)(g0 + i) * dim, *iv = h_inv_vars + (size_t)(g0 + i) * dim;
+      for (int k = 0; k < 2 * dim; k++) {
+        float v = k < dim ? mi[k] : -0.5f * iv[k - dim];
+        int m = k >> 3, o = k & 7;
+        dst[8 * m + 4 * (o & 1) + (o >> 1)] = v;  // stored[8m+4h+c] = logical[8m+2c+h]
+      }
+      gc[row0[p] + i] = h_gconsts[g0 + i];
+    }
+  }
+  void *old[] = {c->d_w, c->d_gc, c->d_row0, c->d_nblk, c->d_slot};
+  for (void *q : old) if (q) hipFree(q);
+  c->d_w = nullptr; c->d_gc = nullptr; c->d_row0 = nullptr; c->d_nblk = nullptr; c->d_slot = nullptr;
+  MFA_HIP_CHECK(c, hipMalloc((void **)&c->d_w, w.size() * 4));
+  MFA_HIP_CHECK(c, hipMalloc((void **)&c->d_gc, gc.size() * 4));
+  MFA_HIP_CHECK(c, hipMalloc((void **)&c->d_row0, row0.size() * 4));
+  MFA_HIP_CHECK(c, hipMalloc((void **)&c->d_nblk, nblk.size() * 4));
+  MFA_HIP_CHECK(c, hipMalloc((void **)&c->d_slot, slot.size() * 4));
+  MFA_HIP_CHECK(c, hipMemcpy(c->d_w, w.data(), w.size() * 4, hipMemcpyHostToDevice));
+  MFA_HIP_CHECK(c, hipMemcpy(c->d_gc, gc.data(), gc.size() * 4, hipMemcpyHostToDevice));
+  MFA_HIP_CHECK(c, hipMemcpy(c->d_row0, row0.data(), row0.size() * 4, hipMemcpyHostToDevice));
+  MFA_HIP_CHECK(c, hipMemcpy(c->d_nblk, nblk.data(), nblk.size() * 4, hipMemcpyHostToDevice));
+  MFA_HIP_CHECK(c, hipMemcpy(c->d_slot, slot.data(), slot.size() * 4, hipMemcpyHostToDevice));
+  c->dim = dim; c->kpad = kpad; c->num_pdfs = num_pdfs; c->num_rows = rows;
+  c->h_slot = slot;
+  c->gmm_ready = true;
+  return 0;
+}
+
+MFA_API int32_t mfa_gmm_slot(mfa_ctx *c, int32_t pdf) {
+  if (!c->gmm_ready || pdf < 0 || pdf >= c->num_pdfs) return -1;
+  return c->h_slot[pdf];
+}
+
+MFA_API int mfa_gmm_sort_pdf_list(mfa_ctx *c, int32_t *h_pdfs, int32_t n, int32_t *h_class_counts) {
+  if (!c->gmm_ready) return c->fail("mfa_load_gmm has not been called");
+  std::vector<int32_t> bucket[5];
+  for (int i = 0; i < n; i++) {
+    int p = h_pdfs[i];
+    if (p < 0 || p >= c->num_pdfs) return c->fail("pdf id %d out of range [0,%d)", p, c->num_pdfs);
+    bucket[class_index(c->h_slot[p])].push_back(p);
+  }
+  int k = 0;
+  for (int b = 0; b < 5; b++) {
+    h_class_counts[b] = (int32_t)bucket[b].size();
+    for (int p : bucket[b]) h_pdfs[k++] = p;
+  }
+  return 0;
+}
+
+MFA_API int mfa_gmm_score_batch(mfa_ctx *c, const float *d_feats, const int64_t *d_frame_off, int32_t n_utt,
+                                int32_t max_frames, const int32_t *d_pdf_list, const int64_t *d_pdf_off,
+                                const int32_t *d_class_counts, const int64_t *d_ll_off, float *d_loglikes) {
+  if (!c->gmm_ready) return c->fail("mfa_load_gmm has not been called");
+  if (n_utt <= 0 || max_frames <= 0) return 0;
+  if (n_utt > 65535) return c->fail("at most 65535 utterances per scoring launch (got %d)", n_utt);
+  GmmParams p;
+  p.dim = c->dim; p.kpad = c->kpad; p.num_rows = c->num_rows;
+  p.w = c->d_w; p.gc = c->d_gc; p.row0 = c->d_row0; p.nblk = c->d_nblk;
+  p.feats = d_feats; p.frame_off = d_frame_off; p.pdf_list = d_pdf_list; p.pdf_off = d_pdf_off;
+  p.class_counts = d_class_counts; p.ll_off = d_ll_off; p.out = d_loglikes;
+  p.min_log_diff = logf(1.1920928955078125e-07f);
+  const char *naive = getenv("MFA_GMM_NAIVE");
+  const int m8 = c->kpad / 8;
+  KernelTimer kt(c, MFA_K_GMM);
+  if ((naive && naive[0] == '1') || m8 > 12) {
+    // worst-case P is not known on the host side of this call: cover max_frames * num_pdfs threads per utterance
+    int64_t per_utt = (int64_t)max_frames * c->num_pdfs;
+    dim3 grid((unsigned)((per_utt + 255) / 256), n_utt);
+    hipLaunchKernelGGL(gmm_naive_kernel, grid, dim3(256), 0, c->stream, p);
+  } else {
+    dim3 grid((max_frames + kWaves * kFramesPerWave - 1) / (kWaves * kFramesPerWave), n_utt);
+    if (m8 <= 10) hipLaunchKernelGGL(gmm_kernel<10>, grid, dim3(256), 0, c->stream, p);
+    else hipLaunchKernelGGL(gmm_kernel<12>, grid, dim3(256), 0, c->stream, p);
+  }
+  MFA_HIP_CHECK(c, hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"

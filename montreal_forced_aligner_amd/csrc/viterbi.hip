@@ -1,0 +1,582 @@
+// Batched beam-pruned token-passing Viterbi for gfx950: one wavefront per utterance, frame loop inside the kernel.
+// Replaces GmmAligner.align_utterance / export_alignments (MFA/alignment/multiprocessing.py:846-853;
+// MFA/online/alignment.py:107) = Kaldi AlignUtteranceWrapper + FasterDecoder.
+//
+// The result is REQUIRED to equal the sequential decoder's, so the kernel reproduces its order-dependent rules in
+// parallel form rather than approximating them:
+//   * tokens live in an ORDERED list (Kaldi HashList order: buckets by first occupancy, insertion order inside);
+//   * a candidate (token i, arc k) is created iff its cost is below the running cutoff
+//       min(seed from the best token, min over all EARLIER candidates) + adaptive_beam
+//     — an exclusive prefix-min over candidates in list×arc order (wave scan, no serial loop);
+//   * per destination state the cheapest candidate wins, ties to the earliest candidate (two-phase LDS atomics);
+//   * the next list is produced by a prefix-sum compaction keyed by each state's first creating candidate
+//     (and its hash bucket's, when the graph has more states than hash buckets);
+//   * GetCutoff's min_active=20 rule is evaluated exactly (counting selection of the 21st smallest cost).
+// Costs are float64 exactly as Kaldi's tokens; arc weights / acoustic costs float32.
+//
+// Memory: per-wavefront LDS holds only the atomically updated tables (state→slot map, per-slot cost/first/winner, the
+// candidate-ordinal counter array); token lists, the candidate stash and the back-pointer records stream through a
+// per-utterance HBM workspace (288 GB lets every in-flight utterance keep its own).  No MFMA: this is min-plus DP.
+#include <cmath>
+#include <cstdint>
+
+#include "ctx.hpp"
+
+namespace {
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+constexpr u32 kEmpty = 0xFFFFFFFFu;
+constexpr u32 kClaim = 0xFFFFFFFEu;
+constexpr u64 kKeyInf = 0xFFFFFFFFFFFFFFFFull;
+constexpr int kMinActive = 20;
+constexpr float kBeamDelta = 0.5f;
+constexpr float kHashRatio = 2.0f;
+constexpr int kArcBits = 6;               // at most 64 arcs per state
+constexpr int kMaxArcsPerState = 1 << kArcBits;
+
+enum { ST_OK = 0, ST_RETRIED = 1, ST_FAILED = 2, ST_TOKEN_OVERFLOW = 3, ST_BP_OVERFLOW = 4, ST_UNSUPPORTED = 5, ST_PENDING = -1 };
+
+struct VitParams {
+  mfa_graph_batch g;
+  const float *ll; const int64_t *ll_off; const int32_t *ll_cols; const int64_t *frame_off;
+  float beam, scale;
+  int nmax, cmax, bpf;        // live-token capacity, candidate capacity, back-pointer tokens per frame
+  const int32_t *utt_list;    // utterances to decode (NULL: identity)
+  const int32_t *n_list;      // number of entries in utt_list (device scalar) or NULL
+  int pass;                   // 0 first beam, 1 retry
+  // workspace
+  u32 *w_state; double *w_cost;        // [n_utt][2][nmax]
+  u32 *w_stash_a; u64 *w_stash_key;    // [n_utt][cmax]: (slot<<32|cidx) packed in stash_a pair → two arrays
+  u32 *w_stash_b;
+  u64 *w_bp;                           // [total_frames*bpf] (arc index <<32 | prev pos)
+  u32 *w_tokoff;                       // [total_frames + n_utt]
+  u32 *w_hash;                         // [n_utt] hash size carried from pass 0 to the retry pass
+  // outputs
+  int32_t *ali; int32_t *words; int32_t *n_words; float *like; float *frame_like; int32_t *status;
+};
+
+__device__ __forceinline__ u64 dkey(double d) {
+  u64 b = (u64)__double_as_longlong(d);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double dunkey(u64 k) {
+  u64 b = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+  return __longlong_as_double((long long)b);
+}
+
+__device__ __forceinline__ double shfl_f64(double v, int src) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __shfl(lo, src); hi = __shfl(hi, src);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double shfl_up_f64(double v, int d) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __shfl_up(lo, d); hi = __shfl_up(hi, d);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double shfl_xor_f64(double v, int m) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __shfl_xor(lo, m); hi = __shfl_xor(hi, m);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_min_f64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmin(v, shfl_xor_f64(v, o));
+  return v;
+}
+__device__ __forceinline__ u32 wave_min_u32(u32 v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = min(v, (u32)__shfl_xor((int)v, o));
+  return v;
+}
+__device__ __forceinline__ u32 wave_sum_u32(u32 v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += (u32)__shfl_xor((int)v, o);
+  return v;
+}
+__device__ __forceinline__ u32 wave_max_u32(u32 v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, (u32)__shfl_xor((int)v, o));
+  return v;
+}
+// exclusive prefix-min over lanes (lane 0 gets +inf)
+__device__ __forceinline__ double excl_prefix_min(double v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    double t = shfl_up_f64(v, o);
+    if (lane >= o) v = fmin(v, t);
+  }
+  double e = shfl_up_f64(v, 1);
+  return lane == 0 ? INFINITY : e;
+}
+// exclusive prefix-sum over lanes
+__device__ __forceinline__ u32 excl_prefix_sum(u32 v, int lane) {
+  u32 inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    u32 t = (u32)__shfl_up((int)inc, o);
+    if (lane >= o) inc += t;
+  }
+  return inc - v;
+}
+
+// Kaldi: ac_cost = -(scale * loglike) in float; new_weight = (double)arc.weight + tok.cost + ac_cost
+__device__ __forceinline__ double cand_cost(float w, double cost, float ll, float scale) {
+  float ac = -(scale * ll);
+  return ((double)w + cost) + (double)ac;
+}
+
+__global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x;
+  int utt = blockIdx.x;
+  if (p.utt_list) {
+    if (p.n_list && (int)blockIdx.x >= *p.n_list) return;
+    utt = p.utt_list[blockIdx.x];
+  }
+  const int64_t so = p.g.d_state_off[utt];
+  const int S = (int)(p.g.d_state_off[utt + 1] - so);
+  const int64_t ab_ = p.g.d_arc_base[utt];
+  const int32_t *arc_off = p.g.d_arc_off + so + utt;
+  const float *final_w = p.g.d_final + so;
+  const int32_t *a_next = p.g.d_arc_next + ab_;
+  const float *a_w = p.g.d_arc_weight + ab_;
+  const int32_t *a_col = p.g.d_arc_col + ab_;
+  const int64_t f0 = p.frame_off[utt];
+  const int T = (int)(p.frame_off[utt + 1] - f0);
+  const float *ll = p.ll + p.ll_off[utt];
+  const int P = p.ll_cols[utt];
+  const int N = p.nmax, C = p.cmax;
+
+  // ---- LDS carve (all offsets multiples of 8 bytes)
+  // volatile: these tables carry values between lanes of the wavefront; every access must reach LDS in program order
+  volatile u64 *s_cost = (volatile u64 *)smem;                 // [N] best cost key per slot
+  volatile u32 *slot_of = (volatile u32 *)(smem + (size_t)N * 8);  // [S] state → slot
+  const int S2 = (S + 1) & ~1;
+  volatile u32 *s_state = slot_of + S2;      // [N]
+  volatile u32 *s_F = s_state + N;           // [N] first creating candidate (pos<<6|k)
+  volatile u32 *s_W = s_F + N;               // [N] winning candidate
+  volatile u32 *s_aux = s_W + N;             // [N] (rank<<24)|ordinal of the bucket leader's first candidate
+  volatile u32 *t_cbase = s_aux + N;         // [N] candidate ordinal base per source token
+  volatile u32 *cntord = t_cbase + N;        // [C] bucket sizes at leader ordinals → exclusive sums
+  volatile u32 *ctr = cntord + C;            // [2]: nslots, nstash
+
+  volatile u32 *l_state[2] = {p.w_state + (size_t)utt * 2 * N, p.w_state + (size_t)utt * 2 * N + N};
+  volatile double *l_cost[2] = {p.w_cost + (size_t)utt * 2 * N, p.w_cost + (size_t)utt * 2 * N + N};
+  volatile u32 *st_a = p.w_stash_a + (size_t)utt * C;
+  volatile u32 *st_b = p.w_stash_b + (size_t)utt * C;
+  volatile u64 *st_key = p.w_stash_key + (size_t)utt * C;
+  volatile u64 *bp = p.w_bp + (size_t)f0 * p.bpf;
+  const u64 bp_cap = (u64)T * (u64)p.bpf;
+  volatile u32 *tokoff = p.w_tokoff + f0 + utt;
+
+  for (int i = lane; i < S; i += 64) slot_of[i] = kEmpty;
+  for (int i = lane; i < C; i += 64) cntord[i] = 0;
+  if (lane == 0) { ctr[0] = 0; ctr[1] = 0; }
+
+  int status = ST_OK;
+  const int start = p.g.d_start[utt];
+  if (S <= 0 || start < 0 || start >= S || T <= 0) status = ST_FAILED;
+  // InitDecoding: one token at the start state with cost 0 (graphs are epsilon-free: ProcessNonemitting is a no-op)
+  int cur = 0, n = 1;
+  if (lane == 0) { l_state[0][0] = (u32)(start < 0 ? 0 : start); l_cost[0][0] = 0.0; }
+  u32 H = p.pass == 0 ? 1000u : p.w_hash[utt];
+  u64 bp_used = 0;
+  __threadfence_block();
+
+  int t = 0;
+  for (; t < T && status == ST_OK; t++) {
+    const float *llt = ll + (size_t)t * P;
+    // ---------------- GetCutoff: best cost (first index on ties), count
+    double best = INFINITY; u32 best_i = kEmpty;
+    for (int c0 = 0; c0 < n; c0 += 64) {
+      int i = c0 + lane;
+      double cst = i < n ? l_cost[cur][i] : INFINITY;
+      double m = wave_min_f64(cst);
+      if (m < best) {  // uniform
+        u32 cand = (i < n && cst == m) ? (u32)i : kEmpty;
+        best_i = wave_min_u32(cand);
+        best = m;
+      }
+    }
+    double wcut; float abeam;
+    if (n <= kMinActive) { wcut = INFINITY; abeam = INFINITY; }
+    else {
+      const double beam_cut = best + p.beam;
+      u32 kle = 0;
+      for (int c0 = 0; c0 < n; c0 += 64) {
+        int i = c0 + lane;
+        kle += (i < n && l_cost[cur][i] <= beam_cut) ? 1u : 0u;
+      }
+      kle = wave_sum_u32(kle);
+      if (kle > (u32)kMinActive) { wcut = beam_cut; abeam = p.beam; }
+      else {
+        // sorted[min_active] > beam_cut: walk up the distinct costs above beam_cut until 21 tokens are covered
+        double v = beam_cut; u32 cnt = kle;
+        for (int it = 0; it <= kMinActive && cnt <= (u32)kMinActive; it++) {
+          double nxt = INFINITY;
+          for (int c0 = 0; c0 < n; c0 += 64) {
+            int i = c0 + lane;
+            double cst = i < n ? l_cost[cur][i] : INFINITY;
+            if (cst > v) nxt = fmin(nxt, cst);
+          }
+          nxt = wave_min_f64(nxt);
+          if (!(nxt < INFINITY)) { v = nxt; break; }
+          u32 eq = 0;
+          for (int c0 = 0; c0 < n; c0 += 64) {
+            int i = c0 + lane;
+            eq += (i < n && l_cost[cur][i] == nxt) ? 1u : 0u;
+          }
+          cnt += wave_sum_u32(eq);
+          v = nxt;
+        }
+        wcut = v;
+        abeam = (float)(v - best + (double)kBeamDelta);
+      }
+    }
+    // PossiblyResizeHash
+    { u32 want = (u32)((float)n * kHashRatio); if (want > H) H = want; }
+
+    // ---------------- seed the next cutoff from the best token's arcs
+    double run = INFINITY;  // min over candidate costs seen so far (seed + earlier candidates)
+    if (best_i != kEmpty) {
+      const u32 bs = l_state[cur][best_i];
+      const int a0 = arc_off[bs], a1 = arc_off[bs + 1];
+      double m = INFINITY;
+      for (int a = a0 + lane; a < a1; a += 64) m = fmin(m, cand_cost(a_w[a], best, llt[a_col[a]], p.scale));
+      run = wave_min_f64(m);
+    }
+
+    // ---------------- expand tokens in list order
+    u32 cand_base = 0;
+    bool bad_degree = false;
+    for (int c0 = 0; c0 < n; c0 += 64) {
+      const int i = c0 + lane;
+      const u32 st = i < n ? l_state[cur][i] : 0u;
+      const double cst = i < n ? l_cost[cur][i] : INFINITY;
+      const bool act = i < n && cst < wcut;
+      const int a0 = act ? arc_off[st] : 0;
+      const int narc = act ? arc_off[st + 1] - a0 : 0;
+      if (narc > kMaxArcsPerState) bad_degree = true;
+      const int maxarc = (int)wave_max_u32((u32)narc);
+      // candidate ordinals
+      const u32 cb = cand_base + excl_prefix_sum((u32)narc, lane);
+      if (i < n) t_cbase[i] = cb;
+      cand_base += wave_sum_u32((u32)narc);
+      // traversal 1: per-token minimum
+      double m = INFINITY;
+      for (int k = 0; k < maxarc; k++)
+        if (k < narc) m = fmin(m, cand_cost(a_w[a0 + k], cst, llt[a_col[a0 + k]], p.scale));
+      double local = fmin(run, excl_prefix_min(m, lane));
+      run = fmin(run, wave_min_f64(m));
+      // traversal 2: create
+      for (int k = 0; k < maxarc; k++) {
+        bool created = false; double nw = 0.0; u32 d = 0;
+        if (k < narc) {
+          nw = cand_cost(a_w[a0 + k], cst, llt[a_col[a0 + k]], p.scale);
+          created = nw < local + (double)abeam;
+          local = fmin(local, nw);
+          d = (u32)a_next[a0 + k];
+        }
+        if (created) {
+          u32 s = slot_of[d];
+          if (s == kEmpty) {
+            u32 old = atomicCAS((u32 *)&slot_of[d], kEmpty, kClaim);
+            if (old == kEmpty) {
+              u32 my = atomicAdd((u32 *)&ctr[0], 1u);
+              if (my < (u32)N) { s_state[my] = d; s_cost[my] = kKeyInf; s_F[my] = kEmpty; s_W[my] = kEmpty; }
+              slot_of[d] = my;
+            }
+          }
+        }
+        // all lanes reconverge here; claims made above are published (LDS is in-order within a wavefront)
+        if (created) {
+          u32 s = slot_of[d];
+          if (s < (u32)N) {
+            const u32 cidx = ((u32)i << kArcBits) | (u32)k;
+            const u64 key = dkey(nw);
+            atomicMin((u64 *)&s_cost[s], key);
+            atomicMin((u32 *)&s_F[s], cidx);
+            u32 q = atomicAdd((u32 *)&ctr[1], 1u);
+            if (q < (u32)C) { st_a[q] = s; st_b[q] = cidx; st_key[q] = key; }
+          }
+        }
+      }
+    }
+    __threadfence_block();
+    const u32 nslots = ctr[0], nstash = ctr[1];
+    if (__any(bad_degree)) { status = ST_UNSUPPORTED; break; }
+    if (nslots > (u32)N || nstash > (u32)C || cand_base > (u32)C) { status = ST_TOKEN_OVERFLOW; break; }
+    if (nslots == 0) { n = 0; t++; break; }  // everything pruned: no surviving token
+
+    // ---------------- winners: earliest candidate among those that reached the best cost
+    for (u32 q0 = 0; q0 < nstash; q0 += 64) {
+      u32 q = q0 + lane;
+      if (q < nstash) {
+        u32 s = st_a[q];
+        if (st_key[q] == s_cost[s]) atomicMin((u32 *)&s_W[s], st_b[q]);
+      }
+    }
+    // ---------------- Kaldi list order of the new tokens
+    for (u32 j0 = 0; j0 < nslots; j0 += 64) {
+      u32 j = j0 + lane;
+      if (j < nslots) {
+        const u32 d = s_state[j], Fj = s_F[j];
+        u32 Fb = Fj, nb = 1, rank = 0;
+        if ((u32)S > H) {
+          nb = 0;
+          for (u32 m = d % H; m < (u32)S; m += H) {
+            u32 sm = slot_of[m];
+            if (sm < (u32)N) {
+              u32 Fm = s_F[sm];
+              nb++;
+              if (Fm < Fj) rank++;
+              if (Fm < Fb) Fb = Fm;
+            }
+          }
+        }
+        const u32 ord_b = t_cbase[Fb >> kArcBits] + (Fb & (kMaxArcsPerState - 1));
+        s_aux[j] = (rank << 24) | ord_b;
+        if (Fb == Fj) cntord[ord_b] = nb;
+      }
+    }
+    {
+      u32 carry = 0;
+      for (u32 o0 = 0; o0 < cand_base; o0 += 64) {
+        u32 o = o0 + lane;
+        u32 v = o < cand_base ? cntord[o] : 0u;
+        u32 ex = excl_prefix_sum(v, lane);
+        if (o < cand_base) cntord[o] = carry + ex;
+        carry += wave_sum_u32(v);
+      }
+    }
+    // ---------------- write the new list + back-pointers, reset the tables
+    if (bp_used + nslots > bp_cap) { status = ST_BP_OVERFLOW; break; }
+    const int nxt = cur ^ 1;
+    for (u32 j0 = 0; j0 < nslots; j0 += 64) {
+      u32 j = j0 + lane;
+      if (j < nslots) {
+        const u32 aux = s_aux[j];
+        const u32 pos = cntord[aux & 0xFFFFFFu] + (aux >> 24);
+        const u32 d = s_state[j], W = s_W[j];
+        const u32 ppos = W >> kArcBits, k = W & (kMaxArcsPerState - 1);
+        const u32 arc = (u32)arc_off[l_state[cur][ppos]] + k;
+        l_state[nxt][pos] = d;
+        l_cost[nxt][pos] = dunkey(s_cost[j]);
+        bp[bp_used + pos] = ((u64)arc << 32) | (u64)ppos;
+      }
+    }
+    for (u32 j0 = 0; j0 < nslots; j0 += 64) {
+      u32 j = j0 + lane;
+      if (j < nslots) { slot_of[s_state[j]] = kEmpty; cntord[s_aux[j] & 0xFFFFFFu] = 0; }
+    }
+    if (lane == 0) { tokoff[t] = (u32)bp_used; ctr[0] = 0; ctr[1] = 0; }
+    bp_used += nslots;
+    n = (int)nslots;
+    cur = nxt;
+    __threadfence_block();
+  }
+  if (p.pass == 0 && lane == 0) p.w_hash[utt] = H;
+
+  // ---------------- ReachedFinal / best final token (first in list order on ties)
+  int32_t out_status = status;
+  double bestc = INFINITY; u32 bpos = kEmpty;
+  if (status == ST_OK) {
+    if (t < T || n == 0) out_status = ST_FAILED;
+    else {
+      for (int c0 = 0; c0 < n; c0 += 64) {
+        int i = c0 + lane;
+        double tc = INFINITY;
+        if (i < n) {
+          float fw = final_w[l_state[cur][i]];
+          if (fw != INFINITY) tc = l_cost[cur][i] + (double)fw;
+        }
+        double m = wave_min_f64(tc);
+        if (m < bestc) {
+          u32 cand = (i < n && tc == m) ? (u32)i : kEmpty;
+          bpos = wave_min_u32(cand);
+          bestc = m;
+        }
+      }
+      if (bpos == kEmpty) out_status = ST_FAILED;
+    }
+  }
+  if (out_status != ST_OK) {
+    if (lane == 0) {
+      // a first-pass failure stays pending for the retry pass; other codes are final
+      p.status[utt] = (p.pass == 0 && out_status == ST_FAILED) ? ST_PENDING : out_status;
+      p.n_words[utt] = 0; p.like[utt] = 0.0f;
+    }
+    return;
+  }
+
+  // ---------------- traceback (one lane chases the pointers), arc index per frame parked in ali[]
+  int32_t *ali = p.ali + f0;
+  const u32 fstate = l_state[cur][bpos];
+  if (lane == 0) {
+    u32 pos = bpos;
+    for (int tt = T - 1; tt >= 0; tt--) {
+      u64 rec = bp[(u64)tokoff[tt] + pos];
+      ali[tt] = (int32_t)(rec >> 32);
+      pos = (u32)(rec & 0xFFFFFFFFu);
+    }
+  }
+  __threadfence_block();
+  // ---------------- outputs: transition-ids, words (ordered compaction), likelihood (Kaldi's float accumulation)
+  const int32_t *a_il = p.g.d_arc_ilabel + ab_, *a_ol = p.g.d_arc_olabel + ab_;
+  int32_t *words = p.words + f0;
+  float *flike = p.frame_like ? p.frame_like + f0 : nullptr;
+  u32 nw_out = 0;
+  double cost = 0.0; float w1 = 0.0f, w2 = 0.0f;
+  const float inv_scale = -1.0f / p.scale;
+  for (int c0 = 0; c0 < T; c0 += 64) {
+    const int tt = c0 + lane;
+    int arc = tt < T ? ali[tt] : 0;
+    int il = 0, ol = 0; float w = 0.0f, ac = 0.0f;
+    if (tt < T) {
+      il = a_il[arc]; ol = a_ol[arc]; w = a_w[arc];
+      ac = -(p.scale * ll[(size_t)tt * P + a_col[arc]]);
+    }
+    // words in path order
+    const u64 mask = __ballot(ol != 0);
+    if (ol != 0) words[nw_out + __popcll(mask & ((1ull << lane) - 1ull))] = ol;
+    nw_out += (u32)__popcll(mask);
+    // cost chain, sequential in frame order (every lane runs the same chain on broadcast operands)
+    float my_fl = 0.0f;
+    const int lim = min(64, T - c0);
+    for (int j = 0; j < lim; j++) {
+      float wj = __shfl(w, j), acj = __shfl(ac, j);
+      double nc = ((double)wj + cost) + (double)acj;
+      float tot = (float)(nc - cost);
+      float acost = tot - wj;
+      w1 += wj; w2 += acost;
+      cost = nc;
+      if (lane == j) my_fl = acost * inv_scale;
+    }
+    if (tt < T) { ali[tt] = il; if (flike) flike[tt] = my_fl; }
+  }
+  if (lane == 0) {
+    w1 += final_w[fstate];
+    p.like[utt] = -(w1 + w2) / p.scale;
+    p.n_words[utt] = (int32_t)nw_out;
+    p.status[utt] = p.pass == 0 ? ST_OK : ST_RETRIED;
+  }
+}
+
+// Build the retry list: utterances left pending by the first pass.
+__global__ void collect_pending_kernel(const int32_t *status, int n_utt, int32_t *list, int32_t *count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_utt && status[i] == ST_PENDING) list[atomicAdd(count, 1)] = i;
+}
+__global__ void finalize_pending_kernel(int32_t *status, int n_utt) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_utt && status[i] == ST_PENDING) status[i] = ST_FAILED;
+}
+
+size_t lds_bytes(int S, int N, int C) {
+  int S2 = (S + 1) & ~1;
+  return (size_t)N * 8 + (size_t)S2 * 4 + (size_t)N * 5 * 4 + (size_t)C * 4 + 16;
+}
+
+struct WsLayout {
+  size_t state, cost, sta, stb, stkey, bp, tokoff, hash, list, count, total;
+};
+WsLayout ws_layout(int n_utt, int64_t total_frames, int N, int C, int bpf) {
+  WsLayout w; size_t o = 0;
+  auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 255) & ~(size_t)255; return at; };
+  w.state = take((size_t)n_utt * 2 * N * 4);
+  w.cost = take((size_t)n_utt * 2 * N * 8);
+  w.sta = take((size_t)n_utt * C * 4);
+  w.stb = take((size_t)n_utt * C * 4);
+  w.stkey = take((size_t)n_utt * C * 8);
+  w.bp = take((size_t)total_frames * bpf * 8);
+  w.tokoff = take((size_t)(total_frames + n_utt) * 4);
+  w.hash = take((size_t)n_utt * 4);
+  w.list = take((size_t)n_utt * 4);
+  w.count = take(256);
+  w.total = o;
+  return w;
+}
+
+int pick_caps(const mfa_align_opts *o, int max_states, int pass, int *N, int *C) {
+  int n = o->max_tokens > 0 ? o->max_tokens : 1024;
+  if (pass == 1) n = n * 4;                 // the retry beam keeps far more tokens alive
+  if (n > max_states) n = max_states;       // one token per state at most
+  n = (n + 63) & ~63;
+  if (n < 64) n = 64;
+  *N = n; *C = 2 * n < 256 ? 256 : 2 * n;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+MFA_API size_t mfa_align_workspace_bytes(mfa_ctx *c, int32_t n_utt, int64_t total_frames, const mfa_align_opts *o) {
+  (void)c;
+  int N = (o->max_tokens > 0 ? o->max_tokens : 1024) * 4, C = 2 * N;
+  return ws_layout(n_utt, total_frames, N, C, o->bp_tokens_per_frame > 0 ? o->bp_tokens_per_frame : 512).total;
+}
+
+MFA_API int mfa_align_batch(mfa_ctx *c, const mfa_graph_batch *g, const float *d_loglikes, const int64_t *d_ll_off,
+                            const int32_t *d_ll_cols, const int64_t *d_frame_off, int32_t max_states,
+                            const mfa_align_opts *o, int32_t *d_ali, int32_t *d_words, int32_t *d_n_words,
+                            float *d_like, float *d_frame_like, int32_t *d_status) {
+  hipSetDevice(c->device);
+  const int n_utt = g->n_utt;
+  if (n_utt <= 0) return 0;
+  if (o->beam <= 0.0f || (o->retry_beam != 0.0f && o->retry_beam <= o->beam))
+    return c->fail("Beams do not make sense: beam %f, retry-beam %f", o->beam, o->retry_beam);
+  if (max_states <= 0) return c->fail("max_states must be positive");
+  // total frames: last entry of frame_off (one small D2H read; the call stays otherwise asynchronous)
+  int64_t total_frames = 0;
+  MFA_HIP_CHECK(c, hipMemcpyAsync(&total_frames, d_frame_off + n_utt, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+  MFA_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+  const int bpf = o->bp_tokens_per_frame > 0 ? o->bp_tokens_per_frame : 512;
+  const int passes = o->retry_beam != 0.0f ? 2 : 1;
+  int N[2], C[2];
+  for (int ps = 0; ps < 2; ps++) pick_caps(o, max_states, ps, &N[ps], &C[ps]);
+  const int Nw = passes == 2 ? N[1] : N[0], Cw = passes == 2 ? C[1] : C[0];
+  WsLayout w = ws_layout(n_utt, total_frames, Nw, Cw, bpf);
+  if (c->ws_bytes < w.total) {
+    if (c->d_ws) { hipFree(c->d_ws); c->d_ws = nullptr; c->ws_bytes = 0; }
+    MFA_HIP_CHECK(c, hipMalloc(&c->d_ws, w.total));
+    c->ws_bytes = w.total;
+  }
+  unsigned char *base = (unsigned char *)c->d_ws;
+  for (int ps = 0; ps < passes; ps++) {
+    size_t lds = lds_bytes(max_states, N[ps], C[ps]);
+    if (lds > 160 * 1024) return c->fail("Viterbi tables need %zu bytes of LDS (> 160 KiB): %d states, %d tokens", lds, max_states, N[ps]);
+    VitParams p;
+    p.g = *g; p.ll = d_loglikes; p.ll_off = d_ll_off; p.ll_cols = d_ll_cols; p.frame_off = d_frame_off;
+    p.beam = ps == 0 ? o->beam : o->retry_beam; p.scale = o->acoustic_scale;
+    p.nmax = N[ps]; p.cmax = C[ps]; p.bpf = bpf; p.pass = ps;
+    // workspace strides follow this pass's capacities (lists and stash are per-pass scratch)
+    WsLayout wp = ws_layout(n_utt, total_frames, N[ps], C[ps], bpf);
+    p.w_state = (u32 *)(base + wp.state); p.w_cost = (double *)(base + wp.cost);
+    p.w_stash_a = (u32 *)(base + wp.sta); p.w_stash_b = (u32 *)(base + wp.stb); p.w_stash_key = (u64 *)(base + wp.stkey);
+    p.w_bp = (u64 *)(base + wp.bp); p.w_tokoff = (u32 *)(base + wp.tokoff);
+    p.w_hash = (u32 *)(base + w.hash);     // fixed location across passes
+    int32_t *d_list = (int32_t *)(base + w.list), *d_count = (int32_t *)(base + w.count);
+    p.utt_list = nullptr; p.n_list = nullptr;
+    p.ali = d_ali; p.words = d_words; p.n_words = d_n_words; p.like = d_like; p.frame_like = d_frame_like; p.status = d_status;
+    if (ps == 1) {
+      MFA_HIP_CHECK(c, hipMemsetAsync(d_count, 0, sizeof(int32_t), c->stream));
+      hipLaunchKernelGGL(collect_pending_kernel, dim3((n_utt + 255) / 256), dim3(256), 0, c->stream, d_status, n_utt, d_list, d_count);
+      p.utt_list = d_list; p.n_list = d_count;
+    }
+    MFA_HIP_CHECK(c, hipFuncSetAttribute((const void *)viterbi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    {
+      KernelTimer kt(c, MFA_K_VITERBI);
+      hipLaunchKernelGGL(viterbi_kernel, dim3(n_utt), dim3(64), lds, c->stream, p);
+    }
+    MFA_HIP_CHECK(c, hipGetLastError());
+  }
+  hipLaunchKernelGGL(finalize_pending_kernel, dim3((n_utt + 255) / 256), dim3(256), 0, c->stream, d_status, n_utt);
+  MFA_HIP_CHECK(c, hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"

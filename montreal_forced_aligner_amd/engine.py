@@ -1,0 +1,271 @@
+"""Batched device pipeline: PCM → MFCC → CMVN → Δ/LDA/fMLLR → GMM scores → Viterbi alignment.
+
+Host orchestration over the C ABI (include/mfa_hip.h).  torch is used only for device memory and streams
+("plumbing, not the product"): every kernel runs inside libmfa_hip.so.  The stages mirror the reference's job
+functions — MfccFunction / calc_cmvn / FinalFeatureFunction / AlignFunction
+(MFA/corpus/features.py:193-376, MFA/corpus/acoustic_corpus.py:1315-1367, MFA/alignment/multiprocessing.py:791-863) —
+but operate on ragged batches resident in HBM instead of ark/scp files between processes.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import AlignOpts, GraphBatch, MfccOpts, check
+from .kaldi_io import Fst
+from .model import DiagGmmModel, TransitionModel
+
+STATUS_OK, STATUS_RETRIED, STATUS_FAILED, STATUS_TOKEN_OVERFLOW, STATUS_BP_OVERFLOW, STATUS_UNSUPPORTED = 0, 1, 2, 3, 4, 5
+
+DEFAULT_MFCC = dict(sample_frequency=16000.0, frame_length_ms=25.0, frame_shift_ms=10.0, preemphasis=0.97,
+                    low_frequency=20.0, high_frequency=7800.0, cepstral_lifter=22.0, energy_floor=0.0,
+                    num_mel_bins=23, num_coefficients=13, snip_edges=0, remove_dc_offset=1, use_energy=0, raw_energy=1)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+@dataclass
+class PackedGraphs:
+    """Graphs of a batch in the device layout mfa_align_batch consumes (see mfa_graph_batch)."""
+
+    n_utt: int
+    max_states: int
+    tensors: Dict[str, torch.Tensor]
+    pdf_list: torch.Tensor      # int32 [ΣP_u] (slot-sorted per utterance)
+    pdf_off: torch.Tensor       # int64 [n_utt+1]
+    class_counts: torch.Tensor  # int32 [n_utt,5]
+    pdf_off_host: np.ndarray
+    pdf_lists_host: List[np.ndarray]
+
+    def struct(self) -> GraphBatch:
+        t = self.tensors
+        return GraphBatch(self.n_utt, t["state_off"].data_ptr(), t["arc_base"].data_ptr(), t["start"].data_ptr(),
+                          t["arc_off"].data_ptr(), t["final"].data_ptr(), t["arc_next"].data_ptr(),
+                          t["arc_weight"].data_ptr(), t["arc_col"].data_ptr(), t["arc_ilabel"].data_ptr(),
+                          t["arc_olabel"].data_ptr())
+
+
+class AlignmentEngine:
+    """One engine per (process, GPU).  All tensors handed in must live on ``device``."""
+
+    def __init__(self, device: int = 0):
+        if not torch.cuda.is_available():
+            raise _lib.MfaHipError("no GPU visible: the alignment engine has no CPU fallback")
+        self.lib = _lib.lib()
+        self.device = torch.device("cuda", device)
+        self.ctx = self.lib.mfa_create(device)
+        if not self.ctx:
+            raise _lib.MfaHipError(f"mfa_create({device}) failed")
+        self.ctx = C.c_void_p(self.ctx)
+        self.use_torch_stream()
+        self.mfcc_opts: Optional[MfccOpts] = None
+        self.num_ceps = 13
+        self.gmm: Optional[DiagGmmModel] = None
+        self.slot_class: Optional[np.ndarray] = None
+
+    def close(self) -> None:
+        if self.ctx:
+            self.lib.mfa_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def use_torch_stream(self) -> None:
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        check(self.ctx, self.lib.mfa_set_stream(self.ctx, C.c_void_p(stream)), "mfa_set_stream")
+
+    # ------------------------------------------------------------------ configuration
+    def configure_mfcc(self, **kw) -> None:
+        d = dict(DEFAULT_MFCC)
+        for k, v in kw.items():
+            if k not in d:
+                raise KeyError(f"unknown MFCC option {k!r}")
+            d[k] = v
+        for k in ("num_mel_bins", "num_coefficients", "snip_edges", "remove_dc_offset", "use_energy", "raw_energy"):
+            d[k] = int(d[k])
+        self.mfcc_opts = MfccOpts(**d)
+        self.num_ceps = d["num_coefficients"]
+        check(self.ctx, self.lib.mfa_mfcc_configure(self.ctx, C.byref(self.mfcc_opts)), "mfa_mfcc_configure")
+
+    def load_gmm(self, gmm: DiagGmmModel) -> None:
+        po = np.ascontiguousarray(gmm.pdf_offsets, dtype=np.int32)
+        gc = np.ascontiguousarray(gmm.gconsts, dtype=np.float32)
+        mi = np.ascontiguousarray(gmm.means_invvars, dtype=np.float32)
+        iv = np.ascontiguousarray(gmm.inv_vars, dtype=np.float32)
+        check(self.ctx, self.lib.mfa_load_gmm(self.ctx, gmm.dim, gmm.num_pdfs, po.ctypes.data, gc.ctypes.data,
+                                              mi.ctypes.data, iv.ctypes.data), "mfa_load_gmm")
+        self.gmm = gmm
+        slots = np.array([self.lib.mfa_gmm_slot(self.ctx, p) for p in range(gmm.num_pdfs)], dtype=np.int32)
+        cls = np.full(gmm.num_pdfs, 4, dtype=np.int32)
+        for i, s in enumerate((32, 16, 8, 4, 1)):
+            cls[slots == s] = i
+        self.slot_class = cls
+
+    def num_frames(self, num_samples: int) -> int:
+        return int(self.lib.mfa_mfcc_num_frames(self.ctx, num_samples))
+
+    # ------------------------------------------------------------------ stages
+    def _dev(self, a: np.ndarray) -> torch.Tensor:
+        return torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+
+    def frame_offsets(self, sample_off: np.ndarray) -> np.ndarray:
+        lens = np.diff(sample_off)
+        frames = np.array([self.num_frames(int(n)) for n in lens], dtype=np.int64)
+        return np.concatenate([[0], np.cumsum(frames)]).astype(np.int64)
+
+    def mfcc(self, pcm: torch.Tensor, sample_off: np.ndarray, frame_off: Optional[np.ndarray] = None):
+        """pcm: int16 [ΣN] on device.  Returns (mfcc float32 [ΣT, num_ceps], frame_off host int64 [n+1])."""
+        if self.mfcc_opts is None:
+            self.configure_mfcc()
+        assert pcm.dtype == torch.int16 and pcm.is_cuda
+        if frame_off is None:
+            frame_off = self.frame_offsets(sample_off)
+        n_utt = len(sample_off) - 1
+        total = int(frame_off[-1])
+        out = torch.empty((total, self.num_ceps), dtype=torch.float32, device=self.device)
+        d_so, d_fo = self._dev(sample_off.astype(np.int64)), self._dev(frame_off)
+        max_frames = int(np.diff(frame_off).max()) if n_utt else 0
+        check(self.ctx, self.lib.mfa_mfcc_batch(self.ctx, _ptr(pcm), _ptr(d_so), _ptr(d_fo), n_utt, max_frames, _ptr(out)),
+              "mfa_mfcc_batch")
+        return out, frame_off
+
+    def cmvn_stats(self, feats: torch.Tensor, frame_off: np.ndarray, utt2spk: np.ndarray, n_spk: int) -> torch.Tensor:
+        n_utt = len(frame_off) - 1
+        order = np.argsort(utt2spk, kind="stable").astype(np.int32)
+        counts = np.bincount(utt2spk, minlength=n_spk)
+        spk_off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+        dim = feats.shape[1]
+        stats = torch.empty((n_spk, 2, dim + 1), dtype=torch.float64, device=self.device)
+        d_fo, d_so, d_su = self._dev(frame_off), self._dev(spk_off), self._dev(order)
+        check(self.ctx, self.lib.mfa_cmvn_stats(self.ctx, _ptr(feats), _ptr(d_fo), n_utt, dim, _ptr(d_so), _ptr(d_su), n_spk,
+                                                _ptr(stats)), "mfa_cmvn_stats")
+        return stats
+
+    def features(self, mfcc: torch.Tensor, frame_off: np.ndarray, utt2spk: Optional[np.ndarray] = None,
+                 cmvn: Optional[torch.Tensor] = None, lda: Optional[torch.Tensor] = None,
+                 fmllr: Optional[torch.Tensor] = None, splice_context: int = 3) -> torch.Tensor:
+        """CMVN → Δ+ΔΔ (no ``lda``) or splice+LDA(+fMLLR).  Mirrors FeatureArchive's chain (MFA/db.py:2101-2136)."""
+        n_utt = len(frame_off) - 1
+        dim = mfcc.shape[1]
+        total = int(frame_off[-1])
+        d_fo = self._dev(frame_off)
+        d_u2s = self._dev(np.asarray(utt2spk, dtype=np.int32)) if utt2spk is not None else None
+        max_frames = int(np.diff(frame_off).max()) if n_utt else 0
+        if lda is None:
+            out = torch.empty((total, 3 * dim), dtype=torch.float32, device=self.device)
+            rc = self.lib.mfa_feats_batch(self.ctx, _ptr(mfcc), _ptr(d_fo), n_utt, max_frames, dim, _ptr(d_u2s), _ptr(cmvn), 0, 0,
+                                          None, 0, 0, None, _ptr(out))
+        else:
+            rows, cols = lda.shape
+            out = torch.empty((total, rows), dtype=torch.float32, device=self.device)
+            rc = self.lib.mfa_feats_batch(self.ctx, _ptr(mfcc), _ptr(d_fo), n_utt, max_frames, dim, _ptr(d_u2s), _ptr(cmvn), 1,
+                                          splice_context, _ptr(lda), rows, cols, _ptr(fmllr), _ptr(out))
+        check(self.ctx, rc, "mfa_feats_batch")
+        return out
+
+    def sort_pdf_list(self, pdfs: np.ndarray):
+        """Order a pdf list by slot class (32,16,8,4,1) as the scoring kernel requires; returns (sorted, counts[5])."""
+        pdfs = np.asarray(pdfs, dtype=np.int32)
+        cls = self.slot_class[pdfs]
+        order = np.argsort(cls, kind="stable")
+        return pdfs[order], np.bincount(cls, minlength=5).astype(np.int32)
+
+    def score(self, feats: torch.Tensor, frame_off: np.ndarray, pdf_list: torch.Tensor, pdf_off_host: np.ndarray,
+              class_counts: torch.Tensor):
+        """Returns (loglikes float32 flat, ll_off host int64 [n+1], ll_cols int32 tensor)."""
+        n_utt = len(frame_off) - 1
+        T = np.diff(frame_off)
+        P = np.diff(pdf_off_host)
+        ll_off = np.concatenate([[0], np.cumsum(T * P)]).astype(np.int64)
+        out = torch.empty(int(ll_off[-1]), dtype=torch.float32, device=self.device)
+        d_fo, d_po, d_lo = self._dev(frame_off), self._dev(pdf_off_host.astype(np.int64)), self._dev(ll_off)
+        max_frames = int(T.max()) if n_utt else 0
+        check(self.ctx, self.lib.mfa_gmm_score_batch(self.ctx, _ptr(feats), _ptr(d_fo), n_utt, max_frames, _ptr(pdf_list),
+                                                     _ptr(d_po), _ptr(class_counts), _ptr(d_lo), _ptr(out)),
+              "mfa_gmm_score_batch")
+        return out, ll_off, self._dev(P.astype(np.int32))
+
+    def pack_graphs(self, fsts: Sequence[Fst], tm: TransitionModel) -> PackedGraphs:
+        """Concatenate per-utterance graphs (with transition probabilities already applied) into the device layout."""
+        n = len(fsts)
+        S = np.array([f.num_states for f in fsts], dtype=np.int64)
+        A = np.array([f.num_arcs for f in fsts], dtype=np.int64)
+        state_off = np.concatenate([[0], np.cumsum(S)]).astype(np.int64)
+        arc_base = np.concatenate([[0], np.cumsum(A)]).astype(np.int64)
+        arc_off = np.concatenate([f.arc_offsets.astype(np.int32) for f in fsts]) if n else np.zeros(0, np.int32)
+        final = np.concatenate([f.final for f in fsts]).astype(np.float32)
+        arcs = np.concatenate([f.arcs for f in fsts])
+        if np.any(arcs["ilabel"] <= 0):
+            raise _lib.MfaHipError("graphs with epsilon input arcs are not supported by the device decoder")
+        max_deg = max(int(np.diff(f.arc_offsets).max()) for f in fsts) if n else 0
+        if max_deg > 64:
+            raise _lib.MfaHipError(f"a graph state has {max_deg} arcs; the device decoder supports at most 64")
+        pdf_of_arc = tm.id2pdf[arcs["ilabel"]]
+        cols = np.empty(arcs.shape[0], dtype=np.int32)
+        pdf_lists, counts = [], []
+        lut = np.full(tm.num_pdfs, -1, dtype=np.int32)
+        for u in range(n):
+            a0, a1 = int(arc_base[u]), int(arc_base[u + 1])
+            pl, cc = self.sort_pdf_list(np.unique(pdf_of_arc[a0:a1]))
+            lut[pl] = np.arange(pl.shape[0], dtype=np.int32)
+            cols[a0:a1] = lut[pdf_of_arc[a0:a1]]
+            pdf_lists.append(pl)
+            counts.append(cc)
+        pdf_off = np.concatenate([[0], np.cumsum([len(p) for p in pdf_lists])]).astype(np.int64)
+        t = dict(
+            state_off=self._dev(state_off), arc_base=self._dev(arc_base),
+            start=self._dev(np.array([f.start for f in fsts], dtype=np.int32)),
+            arc_off=self._dev(arc_off), final=self._dev(final),
+            arc_next=self._dev(arcs["nextstate"].astype(np.int32)), arc_weight=self._dev(arcs["weight"].astype(np.float32)),
+            arc_col=self._dev(cols), arc_ilabel=self._dev(arcs["ilabel"].astype(np.int32)),
+            arc_olabel=self._dev(arcs["olabel"].astype(np.int32)),
+        )
+        return PackedGraphs(n, int(S.max()) if n else 0, t, self._dev(np.concatenate(pdf_lists).astype(np.int32)),
+                            self._dev(pdf_off), self._dev(np.stack(counts).astype(np.int32)), pdf_off, pdf_lists)
+
+    def align(self, graphs: PackedGraphs, loglikes: torch.Tensor, ll_off: np.ndarray, ll_cols: torch.Tensor,
+              frame_off: np.ndarray, beam: float = 10.0, retry_beam: float = 40.0, acoustic_scale: float = 0.1,
+              max_tokens: int = 1024, bp_tokens_per_frame: int = 512, want_frame_likes: bool = False):
+        """Returns device tensors: ali [ΣT], words [ΣT] (+ n_words [n]), like [n], status [n], frame_like or None."""
+        n = graphs.n_utt
+        total = int(frame_off[-1])
+        dev = self.device
+        ali = torch.zeros(total, dtype=torch.int32, device=dev)
+        words = torch.zeros(total, dtype=torch.int32, device=dev)
+        n_words = torch.zeros(n, dtype=torch.int32, device=dev)
+        like = torch.zeros(n, dtype=torch.float32, device=dev)
+        status = torch.full((n,), -1, dtype=torch.int32, device=dev)
+        flike = torch.zeros(total, dtype=torch.float32, device=dev) if want_frame_likes else None
+        opts = AlignOpts(beam, retry_beam, acoustic_scale, max_tokens, bp_tokens_per_frame)
+        gs = graphs.struct()
+        d_lo, d_fo = self._dev(ll_off), self._dev(frame_off)
+        check(self.ctx, self.lib.mfa_align_batch(self.ctx, C.byref(gs), _ptr(loglikes), _ptr(d_lo), _ptr(ll_cols), _ptr(d_fo),
+                                                 graphs.max_states, C.byref(opts), _ptr(ali), _ptr(words), _ptr(n_words),
+                                                 _ptr(like), _ptr(flike), _ptr(status)), "mfa_align_batch")
+        return dict(ali=ali, words=words, n_words=n_words, like=like, status=status, frame_like=flike)
+
+    # ------------------------------------------------------------------ timing helpers (bench.py)
+    def kernel_timing(self, enable: bool) -> None:
+        check(self.ctx, self.lib.mfa_kernel_timing(self.ctx, int(enable)), "mfa_kernel_timing")
+
+    def kernel_times(self) -> Dict[str, Dict[str, float]]:
+        out = {}
+        for i, name in enumerate(("mfcc", "cmvn", "feats", "gmm", "viterbi")):
+            ms, n = C.c_float(0), C.c_int(0)
+            check(self.ctx, self.lib.mfa_kernel_time_ms(self.ctx, i, C.byref(ms), C.byref(n)), "mfa_kernel_time_ms")
+            out[name] = dict(ms=float(ms.value), launches=int(n.value))
+        return out
+
+    def reset_kernel_times(self) -> None:
+        check(self.ctx, self.lib.mfa_kernel_time_reset(self.ctx), "mfa_kernel_time_reset")

@@ -488,7 +488,7 @@ def read_fst(r: BinaryReader) -> Fst:
 
 
 def write_fst(f: BinaryIO, fst: Fst) -> None:
-    f.write(struct.pack("<i", FST_MAGIC - (1 << 32)))
+    f.write(struct.pack("<i", FST_MAGIC))
     for s in ("vector", "standard"):
         f.write(struct.pack("<i", len(s)) + s.encode("ascii"))
     f.write(struct.pack("<ii", 2, 0))

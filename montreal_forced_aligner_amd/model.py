@@ -8,12 +8,30 @@ are Kaldi's ``TransitionModel::ComputeDerived`` (SURVEY Appendix A.5); the scali
 """
 from __future__ import annotations
 
+import ctypes
+import ctypes.util
 from dataclasses import dataclass
 from typing import Iterable, List, Optional
 
 import numpy as np
 
 from . import kaldi_io
+
+# Kaldi's Exp()/Log() on BaseFloat are the C library's expf/logf; numpy's float32 exp/log are separate SIMD
+# implementations that differ in the last bit now and then, so bind libm directly for the model tables.
+_libm = ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6")
+_libm.expf.restype = ctypes.c_float
+_libm.expf.argtypes = [ctypes.c_float]
+_libm.logf.restype = ctypes.c_float
+_libm.logf.argtypes = [ctypes.c_float]
+
+
+def _expf(x) -> np.float32:
+    return np.float32(_libm.expf(float(x)))
+
+
+def _logf(x) -> np.float32:
+    return np.float32(_libm.logf(float(x)))
 
 
 class TransitionModel:
@@ -64,10 +82,10 @@ class TransitionModel:
         sl = int(self.self_loop_of[ts])
         if sl == 0:
             return np.float32(0.0)
-        p = np.float32(1.0) - np.exp(self.log_probs[sl], dtype=np.float32)
+        p = np.float32(1.0) - _expf(self.log_probs[sl])
         if p <= 0:
             p = np.float32(1.0e-10)
-        return np.log(p, dtype=np.float32)
+        return _logf(p)
 
     def scaled_log_probs(self, transition_scale: float, self_loop_scale: float) -> np.ndarray:
         """``GetScaledTransitionLogProb`` for every transition-id (index 0 = 0)."""
@@ -149,7 +167,7 @@ class DiagGmmModel:
         """
         if factor == 1.0:
             return
-        lf = np.float32(np.log(np.float32(factor)))
+        lf = _logf(np.float32(factor))
         for p in sorted(set(int(x) for x in pdf_ids)):
             a, b = int(self.pdf_offsets[p]), int(self.pdf_offsets[p + 1])
             self.gconsts[a:b] += lf
