@@ -34,8 +34,9 @@ MFA_API mfa_ctx *mfa_create(int device_id);
 MFA_API void mfa_destroy(mfa_ctx *ctx);
 MFA_API const char *mfa_last_error(mfa_ctx *ctx);
 MFA_API int mfa_version(void);
-/* Enqueue on the caller's hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = the ctx's own stream. */
-MFA_API int mfa_set_stream(mfa_ctx *ctx, void *hip_stream);
+/* Enqueue on the caller's hipStream_t (e.g. torch.cuda.current_stream().cuda_stream; NULL is HIP's default stream, which
+ * is what torch uses unless told otherwise).  use_own != 0 switches back to the ctx's private non-blocking stream. */
+MFA_API int mfa_set_stream(mfa_ctx *ctx, void *hip_stream, int use_own);
 MFA_API int mfa_synchronize(mfa_ctx *ctx);
 /* Device-memory helpers for callers without torch. */
 MFA_API void *mfa_device_alloc(mfa_ctx *ctx, size_t bytes);
@@ -148,11 +149,13 @@ typedef struct {
 /* d_utt_list: which utterances to decode (NULL = all n_utt); outputs (device):
  *   d_ali [total_frames] transition-ids (at frame_off), d_words [total_frames] word ids packed at frame_off[u] with
  *   d_n_words[u] valid entries, d_like[u] = -(graph+acoustic cost)/acoustic_scale, d_frame_like [total_frames] or NULL,
- *   d_status[u]: 0 ok, 1 ok after retry, 2 no final token (failed), 3 token-capacity overflow, 4 back-pointer overflow.
- * max_states = largest S_u in the batch. */
+ *   d_status[u]: 0 ok, 1 ok after retry, 2 no final token (failed), 3 token-capacity overflow, 4 back-pointer overflow,
+ *                5 unsupported graph (a state with more than 64 arcs), 6 internal consistency check failed.
+ * total_frames = frame_off[n_utt] (host copy, so the call never synchronises); max_states / max_arcs = largest S_u / A_u
+ * in the batch (they bound the token and candidate tables). */
 MFA_API int mfa_align_batch(mfa_ctx *ctx, const mfa_graph_batch *graphs, const float *d_loglikes, const int64_t *d_ll_off,
-                            const int32_t *d_ll_cols, const int64_t *d_frame_off, int32_t max_states,
-                            const mfa_align_opts *opts, int32_t *d_ali, int32_t *d_words, int32_t *d_n_words,
+                            const int32_t *d_ll_cols, const int64_t *d_frame_off, int64_t total_frames,
+                            int32_t max_states, int32_t max_arcs, const mfa_align_opts *opts, int32_t *d_ali, int32_t *d_words, int32_t *d_n_words,
                             float *d_like, float *d_frame_like, int32_t *d_status);
 /* Bytes of device workspace mfa_align_batch will hold for a batch shape (so callers can budget HBM). */
 MFA_API size_t mfa_align_workspace_bytes(mfa_ctx *ctx, int32_t n_utt, int64_t total_frames, const mfa_align_opts *opts);

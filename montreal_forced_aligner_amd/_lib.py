@@ -69,7 +69,7 @@ SIGNATURES = {
     "mfa_destroy": (None, [_vp]),
     "mfa_last_error": (C.c_char_p, [_vp]),
     "mfa_version": (C.c_int, []),
-    "mfa_set_stream": (C.c_int, [_vp, _vp]),
+    "mfa_set_stream": (C.c_int, [_vp, _vp, C.c_int]),
     "mfa_synchronize": (C.c_int, [_vp]),
     "mfa_device_alloc": (_vp, [_vp, C.c_size_t]),
     "mfa_device_free": (C.c_int, [_vp, _vp]),
@@ -89,7 +89,7 @@ SIGNATURES = {
     "mfa_gmm_slot": (_i32, [_vp, _i32]),
     "mfa_gmm_sort_pdf_list": (C.c_int, [_vp, _vp, _i32, _vp]),
     "mfa_gmm_score_batch": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
-    "mfa_align_batch": (C.c_int, [_vp, C.POINTER(GraphBatch), _vp, _vp, _vp, _vp, _i32, C.POINTER(AlignOpts),
+    "mfa_align_batch": (C.c_int, [_vp, C.POINTER(GraphBatch), _vp, _vp, _vp, _vp, _i64, _i32, _i32, C.POINTER(AlignOpts),
                                   _vp, _vp, _vp, _vp, _vp, _vp]),
     "mfa_align_workspace_bytes": (C.c_size_t, [_vp, _i32, _i64, C.POINTER(AlignOpts)]),
 }

@@ -35,9 +35,9 @@ MFA_API void mfa_destroy(mfa_ctx *c) {
 
 MFA_API const char *mfa_last_error(mfa_ctx *c) { return c ? c->err.c_str() : "null context"; }
 
-MFA_API int mfa_set_stream(mfa_ctx *c, void *s) {
+MFA_API int mfa_set_stream(mfa_ctx *c, void *s, int use_own) {
   if (!c) return -1;
-  c->stream = s ? (hipStream_t)s : c->own_stream;
+  c->stream = use_own ? c->own_stream : (hipStream_t)s;  // s == NULL is HIP's default (null) stream
   return 0;
 }
 

@@ -36,7 +36,7 @@ constexpr float kHashRatio = 2.0f;
 constexpr int kArcBits = 6;               // at most 64 arcs per state
 constexpr int kMaxArcsPerState = 1 << kArcBits;
 
-enum { ST_OK = 0, ST_RETRIED = 1, ST_FAILED = 2, ST_TOKEN_OVERFLOW = 3, ST_BP_OVERFLOW = 4, ST_UNSUPPORTED = 5, ST_PENDING = -1 };
+enum { ST_OK = 0, ST_RETRIED = 1, ST_FAILED = 2, ST_TOKEN_OVERFLOW = 3, ST_BP_OVERFLOW = 4, ST_UNSUPPORTED = 5, ST_INTERNAL = 6, ST_PENDING = -1 };
 
 struct VitParams {
   mfa_graph_batch g;
@@ -348,13 +348,14 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
         u32 o = o0 + lane;
         u32 v = o < cand_base ? cntord[o] : 0u;
         u32 ex = excl_prefix_sum(v, lane);
-        if (o < cand_base) cntord[o] = carry + ex;
+        if (o < cand_base && v != 0) cntord[o] = carry + ex;  // only leader ordinals are ever non-zero (and reset below)
         carry += wave_sum_u32(v);
       }
     }
     // ---------------- write the new list + back-pointers, reset the tables
     if (bp_used + nslots > bp_cap) { status = ST_BP_OVERFLOW; break; }
     const int nxt = cur ^ 1;
+    bool broken = false;  // defensive: an inconsistent table must never turn into an out-of-range store
     for (u32 j0 = 0; j0 < nslots; j0 += 64) {
       u32 j = j0 + lane;
       if (j < nslots) {
@@ -362,12 +363,16 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
         const u32 pos = cntord[aux & 0xFFFFFFu] + (aux >> 24);
         const u32 d = s_state[j], W = s_W[j];
         const u32 ppos = W >> kArcBits, k = W & (kMaxArcsPerState - 1);
-        const u32 arc = (u32)arc_off[l_state[cur][ppos]] + k;
-        l_state[nxt][pos] = d;
-        l_cost[nxt][pos] = dunkey(s_cost[j]);
-        bp[bp_used + pos] = ((u64)arc << 32) | (u64)ppos;
+        if (pos >= nslots || ppos >= (u32)n || d >= (u32)S) broken = true;
+        else {
+          const u32 arc = (u32)arc_off[l_state[cur][ppos]] + k;
+          l_state[nxt][pos] = d;
+          l_cost[nxt][pos] = dunkey(s_cost[j]);
+          bp[bp_used + pos] = ((u64)arc << 32) | (u64)ppos;
+        }
       }
     }
+    if (__any(broken)) { status = ST_INTERNAL; break; }
     for (u32 j0 = 0; j0 < nslots; j0 += 64) {
       u32 j = j0 + lane;
       if (j < nslots) { slot_of[s_state[j]] = kEmpty; cntord[s_aux[j] & 0xFFFFFFu] = 0; }
@@ -500,13 +505,19 @@ WsLayout ws_layout(int n_utt, int64_t total_frames, int N, int C, int bpf) {
   return w;
 }
 
-int pick_caps(const mfa_align_opts *o, int max_states, int pass, int *N, int *C) {
+// N = live-token capacity, C = per-frame candidate capacity.  One token per state and one candidate per arc are hard
+// upper bounds, so the retry pass (whose beam keeps most of the graph alive) can always be given room that cannot overflow.
+int pick_caps(const mfa_align_opts *o, int max_states, int max_arcs, int pass, int *N, int *C) {
   int n = o->max_tokens > 0 ? o->max_tokens : 1024;
-  if (pass == 1) n = n * 4;                 // the retry beam keeps far more tokens alive
-  if (n > max_states) n = max_states;       // one token per state at most
+  if (pass == 1) n = n * 4;
+  if (n > max_states) n = max_states;
   n = (n + 63) & ~63;
   if (n < 64) n = 64;
-  *N = n; *C = 2 * n < 256 ? 256 : 2 * n;
+  int c = pass == 1 ? 8 * n : 4 * n;
+  if (c > max_arcs) c = max_arcs;
+  c = (c + 63) & ~63;
+  if (c < 256) c = 256;
+  *N = n; *C = c;
   return 0;
 }
 
@@ -516,28 +527,25 @@ extern "C" {
 
 MFA_API size_t mfa_align_workspace_bytes(mfa_ctx *c, int32_t n_utt, int64_t total_frames, const mfa_align_opts *o) {
   (void)c;
-  int N = (o->max_tokens > 0 ? o->max_tokens : 1024) * 4, C = 2 * N;
+  int N = (o->max_tokens > 0 ? o->max_tokens : 1024) * 4, C = 8 * N;
   return ws_layout(n_utt, total_frames, N, C, o->bp_tokens_per_frame > 0 ? o->bp_tokens_per_frame : 512).total;
 }
 
 MFA_API int mfa_align_batch(mfa_ctx *c, const mfa_graph_batch *g, const float *d_loglikes, const int64_t *d_ll_off,
-                            const int32_t *d_ll_cols, const int64_t *d_frame_off, int32_t max_states,
-                            const mfa_align_opts *o, int32_t *d_ali, int32_t *d_words, int32_t *d_n_words,
+                            const int32_t *d_ll_cols, const int64_t *d_frame_off, int64_t total_frames,
+                            int32_t max_states, int32_t max_arcs, const mfa_align_opts *o, int32_t *d_ali, int32_t *d_words, int32_t *d_n_words,
                             float *d_like, float *d_frame_like, int32_t *d_status) {
   hipSetDevice(c->device);
   const int n_utt = g->n_utt;
   if (n_utt <= 0) return 0;
   if (o->beam <= 0.0f || (o->retry_beam != 0.0f && o->retry_beam <= o->beam))
     return c->fail("Beams do not make sense: beam %f, retry-beam %f", o->beam, o->retry_beam);
-  if (max_states <= 0) return c->fail("max_states must be positive");
-  // total frames: last entry of frame_off (one small D2H read; the call stays otherwise asynchronous)
-  int64_t total_frames = 0;
-  MFA_HIP_CHECK(c, hipMemcpyAsync(&total_frames, d_frame_off + n_utt, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
-  MFA_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+  if (max_states <= 0 || max_arcs <= 0) return c->fail("max_states and max_arcs must be positive");
+  if (total_frames <= 0) return c->fail("total_frames must be positive");
   const int bpf = o->bp_tokens_per_frame > 0 ? o->bp_tokens_per_frame : 512;
   const int passes = o->retry_beam != 0.0f ? 2 : 1;
   int N[2], C[2];
-  for (int ps = 0; ps < 2; ps++) pick_caps(o, max_states, ps, &N[ps], &C[ps]);
+  for (int ps = 0; ps < 2; ps++) pick_caps(o, max_states, max_arcs, ps, &N[ps], &C[ps]);
   const int Nw = passes == 2 ? N[1] : N[0], Cw = passes == 2 ? C[1] : C[0];
   WsLayout w = ws_layout(n_utt, total_frames, Nw, Cw, bpf);
   if (c->ws_bytes < w.total) {

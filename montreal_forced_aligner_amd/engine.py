@@ -37,6 +37,7 @@ class PackedGraphs:
 
     n_utt: int
     max_states: int
+    max_arcs: int
     tensors: Dict[str, torch.Tensor]
     pdf_list: torch.Tensor      # int32 [ΣP_u] (slot-sorted per utterance)
     pdf_off: torch.Tensor       # int64 [n_utt+1]
@@ -83,7 +84,7 @@ class AlignmentEngine:
 
     def use_torch_stream(self) -> None:
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        check(self.ctx, self.lib.mfa_set_stream(self.ctx, C.c_void_p(stream)), "mfa_set_stream")
+        check(self.ctx, self.lib.mfa_set_stream(self.ctx, C.c_void_p(stream), 0), "mfa_set_stream")
 
     # ------------------------------------------------------------------ configuration
     def configure_mfcc(self, **kw) -> None:
@@ -231,7 +232,7 @@ class AlignmentEngine:
             arc_col=self._dev(cols), arc_ilabel=self._dev(arcs["ilabel"].astype(np.int32)),
             arc_olabel=self._dev(arcs["olabel"].astype(np.int32)),
         )
-        return PackedGraphs(n, int(S.max()) if n else 0, t, self._dev(np.concatenate(pdf_lists).astype(np.int32)),
+        return PackedGraphs(n, int(S.max()) if n else 0, int(A.max()) if n else 0, t, self._dev(np.concatenate(pdf_lists).astype(np.int32)),
                             self._dev(pdf_off), self._dev(np.stack(counts).astype(np.int32)), pdf_off, pdf_lists)
 
     def align(self, graphs: PackedGraphs, loglikes: torch.Tensor, ll_off: np.ndarray, ll_cols: torch.Tensor,
@@ -251,8 +252,8 @@ class AlignmentEngine:
         gs = graphs.struct()
         d_lo, d_fo = self._dev(ll_off), self._dev(frame_off)
         check(self.ctx, self.lib.mfa_align_batch(self.ctx, C.byref(gs), _ptr(loglikes), _ptr(d_lo), _ptr(ll_cols), _ptr(d_fo),
-                                                 graphs.max_states, C.byref(opts), _ptr(ali), _ptr(words), _ptr(n_words),
-                                                 _ptr(like), _ptr(flike), _ptr(status)), "mfa_align_batch")
+                                                 total, graphs.max_states, graphs.max_arcs, C.byref(opts), _ptr(ali), _ptr(words),
+                                                 _ptr(n_words), _ptr(like), _ptr(flike), _ptr(status)), "mfa_align_batch")
         return dict(ali=ali, words=words, n_words=n_words, like=like, status=status, frame_like=flike)
 
     # ------------------------------------------------------------------ timing helpers (bench.py)
@@ -269,3 +270,80 @@ class AlignmentEngine:
 
     def reset_kernel_times(self) -> None:
         check(self.ctx, self.lib.mfa_kernel_time_reset(self.ctx), "mfa_kernel_time_reset")
+
+
+class Pipeline:
+    """A fixed-shape batch whose inputs, offsets, graphs and output buffers all live in HBM, so that one ``step()`` is
+    nothing but the five kernel launches of the hot path (MFCC → CMVN stats → features → GMM scores → Viterbi).
+
+    This is the unit bench.py times and the shape a corpus aligner would feed: build once per batch shape, refill the
+    PCM/graph tensors, call ``step()``.
+    """
+
+    def __init__(self, engine: AlignmentEngine, pcm: torch.Tensor, sample_off: np.ndarray, utt2spk: np.ndarray,
+                 graphs: PackedGraphs, lda: Optional[torch.Tensor] = None, fmllr: Optional[torch.Tensor] = None,
+                 splice_context: int = 3, beam: float = 10.0, retry_beam: float = 40.0, acoustic_scale: float = 0.1,
+                 max_tokens: int = 1024, bp_tokens_per_frame: int = 256):
+        e = self.e = engine
+        dev = e.device
+        self.pcm = pcm
+        self.n_utt = len(sample_off) - 1
+        self.graphs = graphs
+        self.lda, self.fmllr, self.ctx_frames = lda, fmllr, splice_context
+        self.frame_off = e.frame_offsets(sample_off)
+        T = np.diff(self.frame_off)
+        self.total_frames = int(self.frame_off[-1])
+        self.max_frames = int(T.max())
+        P = np.diff(graphs.pdf_off_host)
+        self.ll_off = np.concatenate([[0], np.cumsum(T * P)]).astype(np.int64)
+        utt2spk = np.asarray(utt2spk, dtype=np.int32)
+        spk_ids, inv = np.unique(utt2spk, return_inverse=True)
+        self.n_spk = len(spk_ids)
+        order = np.argsort(inv, kind="stable").astype(np.int32)
+        spk_off = np.concatenate([[0], np.cumsum(np.bincount(inv, minlength=self.n_spk))]).astype(np.int32)
+        d = e._dev
+        self.d_sample_off, self.d_frame_off = d(sample_off.astype(np.int64)), d(self.frame_off)
+        self.d_utt2spk, self.d_spk_off, self.d_spk_utt = d(inv.astype(np.int32)), d(spk_off), d(order)
+        self.d_ll_off, self.d_ll_cols = d(self.ll_off), d(P.astype(np.int32))
+        self.num_ceps = e.num_ceps
+        self.feat_dim = 3 * self.num_ceps if lda is None else int(lda.shape[0])
+        f32, i32 = torch.float32, torch.int32
+        self.mfcc = torch.empty((self.total_frames, self.num_ceps), dtype=f32, device=dev)
+        self.cmvn = torch.empty((self.n_spk, 2, self.num_ceps + 1), dtype=torch.float64, device=dev)
+        self.feats = torch.empty((self.total_frames, self.feat_dim), dtype=f32, device=dev)
+        self.loglikes = torch.empty(int(self.ll_off[-1]), dtype=f32, device=dev)
+        self.ali = torch.zeros(self.total_frames, dtype=i32, device=dev)
+        self.words = torch.zeros(self.total_frames, dtype=i32, device=dev)
+        self.n_words = torch.zeros(self.n_utt, dtype=i32, device=dev)
+        self.like = torch.zeros(self.n_utt, dtype=f32, device=dev)
+        self.status = torch.full((self.n_utt,), -1, dtype=i32, device=dev)
+        self.opts = AlignOpts(beam, retry_beam, acoustic_scale, max_tokens, bp_tokens_per_frame)
+        self.gstruct = graphs.struct()
+        # algorithmic work of one step (SURVEY §8d): GMM flops 4·D·g·P·T summed over utterances
+        g_of_pdf = np.diff(e.gmm.pdf_offsets)
+        gauss = np.array([int(g_of_pdf[pl].sum()) for pl in graphs.pdf_lists_host], dtype=np.float64)
+        self.gmm_flops = float((4.0 * e.gmm.dim * gauss * T).sum())
+        self.audio_seconds = float(np.diff(sample_off).sum() / e.mfcc_opts.sample_frequency)
+
+    def step(self) -> None:
+        e, L, c = self.e, self.e.lib, self.e.ctx
+        check(c, L.mfa_mfcc_batch(c, _ptr(self.pcm), _ptr(self.d_sample_off), _ptr(self.d_frame_off), self.n_utt,
+                                  self.max_frames, _ptr(self.mfcc)), "mfa_mfcc_batch")
+        check(c, L.mfa_cmvn_stats(c, _ptr(self.mfcc), _ptr(self.d_frame_off), self.n_utt, self.num_ceps, _ptr(self.d_spk_off),
+                                  _ptr(self.d_spk_utt), self.n_spk, _ptr(self.cmvn)), "mfa_cmvn_stats")
+        if self.lda is None:
+            rc = L.mfa_feats_batch(c, _ptr(self.mfcc), _ptr(self.d_frame_off), self.n_utt, self.max_frames, self.num_ceps,
+                                   _ptr(self.d_utt2spk), _ptr(self.cmvn), 0, 0, None, 0, 0, None, _ptr(self.feats))
+        else:
+            rc = L.mfa_feats_batch(c, _ptr(self.mfcc), _ptr(self.d_frame_off), self.n_utt, self.max_frames, self.num_ceps,
+                                   _ptr(self.d_utt2spk), _ptr(self.cmvn), 1, self.ctx_frames, _ptr(self.lda),
+                                   int(self.lda.shape[0]), int(self.lda.shape[1]), _ptr(self.fmllr), _ptr(self.feats))
+        check(c, rc, "mfa_feats_batch")
+        g = self.graphs
+        check(c, L.mfa_gmm_score_batch(c, _ptr(self.feats), _ptr(self.d_frame_off), self.n_utt, self.max_frames,
+                                       _ptr(g.pdf_list), _ptr(g.pdf_off), _ptr(g.class_counts), _ptr(self.d_ll_off),
+                                       _ptr(self.loglikes)), "mfa_gmm_score_batch")
+        check(c, L.mfa_align_batch(c, C.byref(self.gstruct), _ptr(self.loglikes), _ptr(self.d_ll_off), _ptr(self.d_ll_cols),
+                                   _ptr(self.d_frame_off), self.total_frames, g.max_states, g.max_arcs, C.byref(self.opts), _ptr(self.ali),
+                                   _ptr(self.words), _ptr(self.n_words), _ptr(self.like), None, _ptr(self.status)),
+              "mfa_align_batch")

@@ -1,0 +1,275 @@
+"""GPU parity tests: every kernel of libmfa_hip.so, called through the C ABI (ctypes → engine), against the CPU oracle on
+the same inputs.  Integer/index results (alignments, words, status) must be identical; floating point within the stated
+tolerance (north_star: log-likelihoods within 1e-3).  PARITY STATUS of the oracle itself: unpinned."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(e, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(e.device)
+
+
+def _segments(fx):
+    sr = 16000
+    cuts = [(0.0, 3.0), (3.0, 3.21), (5.0, 12.5), (12.5, 12.62), (14.0, 26.7)]
+    return [fx.pcm[int(a * sr): int(b * sr)] for a, b in cuts]
+
+
+@pytest.mark.parametrize("snip", [0, 1])
+def test_mfcc_matches_oracle(engine, fx, snip):
+    segs = _segments(fx)
+    engine.configure_mfcc(snip_edges=snip)
+    sample_off = np.concatenate([[0], np.cumsum([len(s) for s in segs])]).astype(np.int64)
+    pcm = _dev(engine, np.concatenate(segs).astype(np.int16))
+    out, frame_off = engine.mfcc(pcm, sample_off)
+    out = out.cpu().numpy()
+    opts = O.default_mfcc_opts(snip_edges=snip)
+    worst = 0.0
+    for u, s in enumerate(segs):
+        ref = O.mfcc(s.astype(np.float32), opts)
+        got = out[frame_off[u]: frame_off[u + 1]]
+        assert got.shape == ref.shape
+        if ref.size:
+            worst = max(worst, float(np.abs(got - ref).max()))
+    # two float32 FFTs of different radix on int16-scale audio: values reach ~100, agreement ~1e-4
+    assert worst < 2e-3, worst
+    engine.configure_mfcc()
+
+
+def test_mfcc_digital_silence_and_full_scale(engine):
+    engine.configure_mfcc()
+    rng = np.random.default_rng(7)
+    segs = [np.zeros(4000, np.int16), np.full(4000, 32767, np.int16), rng.integers(-32768, 32767, 8000).astype(np.int16)]
+    sample_off = np.concatenate([[0], np.cumsum([len(s) for s in segs])]).astype(np.int64)
+    out, frame_off = engine.mfcc(_dev(engine, np.concatenate(segs)), sample_off)
+    out = out.cpu().numpy()
+    for u, s in enumerate(segs):
+        ref = O.mfcc(s.astype(np.float32), O.default_mfcc_opts())
+        assert np.abs(out[frame_off[u]: frame_off[u + 1]] - ref).max() < 5e-3
+
+
+def test_cmvn_and_delta_features_match_oracle(engine, fx):
+    segs = _segments(fx)
+    mf = [O.mfcc(s.astype(np.float32), O.default_mfcc_opts()) for s in segs]
+    frame_off = np.concatenate([[0], np.cumsum([m.shape[0] for m in mf])]).astype(np.int64)
+    utt2spk = np.array([0, 1, 0, 1, 2], dtype=np.int32)
+    d_mf = _dev(engine, np.concatenate(mf))
+    stats = engine.cmvn_stats(d_mf, frame_off, utt2spk, 3)
+    feats = engine.features(d_mf, frame_off, utt2spk, stats).cpu().numpy()
+    stats = stats.cpu().numpy()
+    exact = total = 0
+    for spk in range(3):
+        ref = O.cmvn_stats([mf[u] for u in range(5) if utt2spk[u] == spk])
+        assert np.allclose(stats[spk], ref, rtol=1e-13, atol=1e-9)
+    for u in range(5):
+        ref_stats = O.cmvn_stats([mf[v] for v in range(5) if utt2spk[v] == utt2spk[u]])
+        ref = O.deltas(O.cmvn_apply(ref_stats, mf[u]))
+        got = feats[frame_off[u]: frame_off[u + 1]]
+        assert got.shape == ref.shape
+        assert np.abs(got - ref).max() < 1e-4
+        exact += int((got == ref).sum()); total += ref.size
+    assert exact / total > 0.999  # same fmaf chain: bit-identical except where a CMVN offset rounds the other way
+
+
+def test_lda_fmllr_features_match_oracle(engine, fx):
+    segs = _segments(fx)[:3]
+    mf = [O.mfcc(s.astype(np.float32), O.default_mfcc_opts(snip_edges=1)) for s in segs]
+    frame_off = np.concatenate([[0], np.cumsum([m.shape[0] for m in mf])]).astype(np.int64)
+    utt2spk = np.array([0, 1, 0], dtype=np.int32)
+    rng = np.random.default_rng(0)
+    fm = np.stack([np.concatenate([np.eye(40) + 0.05 * rng.normal(size=(40, 40)), 0.1 * rng.normal(size=(40, 1))], axis=1)
+                   for _ in range(2)]).astype(np.float32)
+    d_mf = _dev(engine, np.concatenate(mf))
+    stats = engine.cmvn_stats(d_mf, frame_off, utt2spk, 2)
+    lda = _dev(engine, fx.g2p_lda)
+    no_fmllr = engine.features(d_mf, frame_off, utt2spk, stats, lda=lda).cpu().numpy()
+    with_fmllr = engine.features(d_mf, frame_off, utt2spk, stats, lda=lda, fmllr=_dev(engine, fm)).cpu().numpy()
+    for u in range(3):
+        ref_stats = O.cmvn_stats([mf[v] for v in range(3) if utt2spk[v] == utt2spk[u]])
+        y = O.affine(O.splice(O.cmvn_apply(ref_stats, mf[u])), fx.g2p_lda)
+        assert np.abs(no_fmllr[frame_off[u]: frame_off[u + 1]] - y).max() < 1e-4
+        z = O.affine(y, fm[utt2spk[u]])
+        assert np.abs(with_fmllr[frame_off[u]: frame_off[u + 1]] - z).max() < 1e-4
+
+
+def _score(engine, am, feats_list, pdf_lists):
+    engine.load_gmm(am)
+    frame_off = np.concatenate([[0], np.cumsum([f.shape[0] for f in feats_list])]).astype(np.int64)
+    sorted_lists, counts = zip(*[engine.sort_pdf_list(p) for p in pdf_lists])
+    pdf_off = np.concatenate([[0], np.cumsum([len(p) for p in sorted_lists])]).astype(np.int64)
+    ll, ll_off, _ = engine.score(_dev(engine, np.concatenate(feats_list).astype(np.float32)), frame_off,
+                                 _dev(engine, np.concatenate(sorted_lists).astype(np.int32)), pdf_off,
+                                 _dev(engine, np.stack(counts).astype(np.int32)))
+    ll = ll.cpu().numpy()
+    out = []
+    for u, f in enumerate(feats_list):
+        P = len(sorted_lists[u])
+        out.append(ll[ll_off[u]: ll_off[u + 1]].reshape(f.shape[0], P))
+    return out, sorted_lists
+
+
+def test_gmm_single_gaussian_is_bit_exact(engine, fx):
+    """mono_model has one Gaussian per pdf: LL is the MFMA's fmaf chain itself, which must equal the oracle's bit for bit."""
+    am = fx.mono_am
+    feats = [fx.mono_feats(s) for s in _segments(fx)[:3]]
+    rng = np.random.default_rng(1)
+    lists = [np.arange(am.num_pdfs, dtype=np.int32), rng.permutation(am.num_pdfs)[:37].astype(np.int32),
+             np.array([5], dtype=np.int32)]
+    got, sorted_lists = _score(engine, am, feats, lists)
+    for u in range(3):
+        ref = O.gmm_loglikes(feats[u], am.gconsts, am.means_invvars, am.inv_vars, am.pdf_offsets, sorted_lists[u])
+        assert np.array_equal(got[u], ref), float(np.abs(got[u] - ref).max())
+
+
+def test_gmm_real_mixture_model(engine, fx):
+    am = fx.g2p_am  # 80 pdfs with 1..26 Gaussians: every slot class
+    mf = [O.mfcc(s.astype(np.float32), O.default_mfcc_opts(snip_edges=1)) for s in _segments(fx)[:3]]
+    feats = [O.affine(O.splice(O.cmvn_apply(O.cmvn_stats([m]), m)), fx.g2p_lda) for m in mf]
+    rng = np.random.default_rng(2)
+    lists = [np.arange(am.num_pdfs, dtype=np.int32), rng.permutation(am.num_pdfs)[:33].astype(np.int32),
+             rng.permutation(am.num_pdfs)[:7].astype(np.int32)]
+    got, sorted_lists = _score(engine, am, feats, lists)
+    for u in range(3):
+        ref = O.gmm_loglikes(feats[u], am.gconsts, am.means_invvars, am.inv_vars, am.pdf_offsets, sorted_lists[u])
+        err = np.abs(got[u] - ref)
+        assert err.max() < 1e-4 * max(1.0, np.abs(ref).max()), err.max()  # device expf/log vs libm: last-bit differences
+        assert (got[u] == ref).mean() > 0.9
+
+
+@pytest.mark.parametrize("dim", [40, 39, 45])
+def test_gmm_random_models_all_slot_classes(engine, dim):
+    rng = np.random.default_rng(dim)
+    sizes = [1, 1, 2, 3, 4, 4, 5, 7, 8, 8, 9, 12, 16, 16, 17, 26, 32, 32, 33, 64, 70, 1, 4, 8]
+    am = helpers.random_gmm(rng, dim, sizes)
+    feats = [rng.normal(0, 3, size=(t, dim)).astype(np.float32) for t in (1, 63, 64, 65, 300)]
+    lists = [rng.permutation(am.num_pdfs)[:n].astype(np.int32) for n in (24, 24, 5, 1, 17)]
+    got, sorted_lists = _score(engine, am, feats, lists)
+    for u in range(len(feats)):
+        ref = O.gmm_loglikes(feats[u], am.gconsts, am.means_invvars, am.inv_vars, am.pdf_offsets, sorted_lists[u])
+        assert np.abs(got[u] - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
+
+
+def _align_case(engine, tm, fx_am, fsts, lls_full, beam, retry, max_tokens=1024, scale=0.1):
+    """lls_full[u]: [T, num_pdfs] oracle scores for every pdf; the GPU gets the utterance's own columns."""
+    engine.load_gmm(fx_am)  # pdf lists are ordered by the loaded model's slot classes
+    graphs = engine.pack_graphs(fsts, tm)
+    frame_off = np.concatenate([[0], np.cumsum([l.shape[0] for l in lls_full])]).astype(np.int64)
+    cols = [lls_full[u][:, graphs.pdf_lists_host[u]] for u in range(len(fsts))]
+    ll_off = np.concatenate([[0], np.cumsum([c.size for c in cols])]).astype(np.int64)
+    d_ll = _dev(engine, np.concatenate([c.reshape(-1) for c in cols]).astype(np.float32))
+    ll_cols = _dev(engine, np.array([c.shape[1] for c in cols], dtype=np.int32))
+    res = engine.align(graphs, d_ll, ll_off, ll_cols, frame_off, beam=beam, retry_beam=retry, acoustic_scale=scale,
+                       max_tokens=max_tokens, want_frame_likes=True)
+    res = {k: (v.cpu().numpy() if v is not None else None) for k, v in res.items()}
+    for u, f in enumerate(fsts):
+        ref = helpers.oracle_align(tm, f, cols[u], graphs.pdf_lists_host[u], acoustic_scale=scale, beam=beam, retry_beam=retry)
+        assert res["status"][u] == ref["status"], (u, res["status"][u], ref["status"])
+        if ref["status"] in (0, 1):
+            a, b = frame_off[u], frame_off[u + 1]
+            if not np.array_equal(res["ali"][a:b], ref["ali"]):
+                bad = np.nonzero(res["ali"][a:b] != ref["ali"])[0]
+                raise AssertionError(f"utt {u}: alignment differs at {bad.size}/{b - a} frames, first {bad[:5]}, "
+                                     f"gpu {res['ali'][a:b][bad[:5]]} ref {ref['ali'][bad[:5]]} beam {beam}")
+            nw = res["n_words"][u]
+            assert np.array_equal(res["words"][a: a + nw], ref["words"])
+            assert res["like"][u] == np.float32(ref["like"]), (res["like"][u], ref["like"])
+            assert np.array_equal(res["frame_like"][a:b], ref["per_frame"])
+    return res
+
+
+def test_viterbi_real_audio_identical_to_oracle(engine, fx):
+    tm, am = fx.mono_tm, fx.mono_am
+    texts = ["this is the acoustic corpus i'm talking pretty fast here", "there's nothing going else going on",
+             fx.text, "um and that should be all thanks"]
+    sr = 16000
+    cuts = [(0.0, 4.2), (4.0, 6.5), (0.0, 26.72), (23.5, 26.72)]
+    feats = [fx.mono_feats(fx.pcm[int(a * sr): int(b * sr)]) for a, b in cuts]
+    pdfs = np.arange(am.num_pdfs, dtype=np.int32)
+    lls = [O.gmm_loglikes(x, am.gconsts, am.means_invvars, am.inv_vars, am.pdf_offsets, pdfs) for x in feats]
+    fsts = [fx.mono_graph(t) for t in texts]
+    assert fsts[2].num_states > 2000  # more states than the decoder's 1000 hash buckets: bucket-order path
+    for beam, retry in ((100.0, 400.0), (10.0, 40.0), (30.0, 120.0)):
+        res = _align_case(engine, tm, am, fsts, lls, beam, retry, max_tokens=2048)
+        assert set(res["status"].tolist()) <= {0, 1, 2}
+
+
+def test_viterbi_random_scores_all_paths(engine, fx):
+    tm = fx.mono_tm
+    rng = np.random.default_rng(11)
+    words = [w for w in fx.text.split() if fx.mono_lex.word_table.member(w)]
+    for trial in range(4):
+        fsts, lls = [], []
+        for u in range(24):
+            n = int(rng.integers(1, 9))
+            text = " ".join(rng.choice(words, size=n))
+            f = fx.mono_graph(text)
+            nph = sum(len(fx.mono_lex.word_pronunciations(w)[0].pronunciation.split()) for w in text.split())
+            T = int(3 * nph * rng.uniform(0.9, 3.0)) + int(rng.integers(0, 5))
+            sd = float(rng.choice([3.0, 12.0, 30.0, 80.0]))
+            fsts.append(f)
+            lls.append(rng.normal(-60.0, sd, size=(max(T, 1), tm.num_pdfs)).astype(np.float32))
+        beam, retry = [(0.5, 2.0), (2.0, 8.0), (10.0, 40.0), (1.0, 1000.0)][trial]
+        res = _align_case(engine, tm, fx.mono_am, fsts, lls, beam, retry)
+        if trial == 3:
+            assert 1 in res["status"].tolist()  # the retry launch really ran
+
+
+def test_viterbi_ties_and_duplicate_paths(engine, fx):
+    """Constant scores make many paths cost exactly the same: the winner is decided purely by Kaldi's first-come order."""
+    tm = fx.mono_tm
+    fsts = [fx.mono_graph("words words words"), fx.mono_graph("this is"), fx.mono_graph("um")]
+    lls = [np.full((T, tm.num_pdfs), -50.0, dtype=np.float32) for T in (90, 40, 30)]
+    _align_case(engine, tm, fx.mono_am, fsts, lls, 10.0, 40.0)
+    _align_case(engine, tm, fx.mono_am, fsts, lls, 1.0e4, 0.0)
+
+
+def test_viterbi_token_capacity_overflow_is_reported(engine, fx):
+    tm = fx.mono_tm
+    rng = np.random.default_rng(5)
+    f = fx.mono_graph(fx.text)
+    ll = rng.normal(-60.0, 1.0, size=(400, tm.num_pdfs)).astype(np.float32)
+    engine.load_gmm(fx.mono_am)
+    graphs = engine.pack_graphs([f], tm)
+    cols = ll[:, graphs.pdf_lists_host[0]]
+    frame_off = np.array([0, 400], dtype=np.int64)
+    res = engine.align(graphs, _dev(engine, cols.reshape(-1)), np.array([0, cols.size], dtype=np.int64),
+                       _dev(engine, np.array([cols.shape[1]], dtype=np.int32)), frame_off, beam=1000.0, retry_beam=0.0,
+                       max_tokens=64)
+    assert int(res["status"].cpu()[0]) == 3  # loud, per-utterance, never a silent wrong answer
+
+
+def test_end_to_end_pcm_to_alignment(engine, fx):
+    """Whole device pipeline from int16 PCM versus the whole oracle pipeline."""
+    tm, am = fx.mono_tm, fx.mono_am
+    sr = 16000
+    cuts = [(0.0, 4.2), (4.0, 6.5), (23.5, 26.72)]
+    texts = ["this is the acoustic corpus i'm talking pretty fast here", "there's nothing going else going on",
+             "um and that should be all thanks"]
+    segs = [fx.pcm[int(a * sr): int(b * sr)] for a, b in cuts]
+    engine.configure_mfcc()
+    engine.load_gmm(am)
+    sample_off = np.concatenate([[0], np.cumsum([len(s) for s in segs])]).astype(np.int64)
+    mfcc, frame_off = engine.mfcc(_dev(engine, np.concatenate(segs)), sample_off)
+    utt2spk = np.arange(3, dtype=np.int32)
+    stats = engine.cmvn_stats(mfcc, frame_off, utt2spk, 3)
+    feats = engine.features(mfcc, frame_off, utt2spk, stats)
+    fsts = [fx.mono_graph(t) for t in texts]
+    graphs = engine.pack_graphs(fsts, tm)
+    ll, ll_off, ll_cols = engine.score(feats, frame_off, graphs.pdf_list, graphs.pdf_off_host, graphs.class_counts)
+    res = engine.align(graphs, ll, ll_off, ll_cols, frame_off, beam=100.0, retry_beam=400.0)
+    res = {k: (v.cpu().numpy() if v is not None else None) for k, v in res.items()}
+    for u in range(3):
+        x = fx.mono_feats(segs[u])
+        pl = graphs.pdf_lists_host[u]
+        ref_ll = O.gmm_loglikes(x, am.gconsts, am.means_invvars, am.inv_vars, am.pdf_offsets, pl)
+        ref = helpers.oracle_align(tm, fsts[u], ref_ll, pl, beam=100.0, retry_beam=400.0)
+        assert res["status"][u] == ref["status"] and ref["status"] in (0, 1)
+        a, b = frame_off[u], frame_off[u + 1]
+        assert np.array_equal(res["ali"][a:b], ref["ali"])  # frame-identical boundaries
+        assert abs(res["like"][u] - ref["like"]) / (b - a) < 1e-3  # per-frame log-likelihood (what MFA reports) within 1e-3

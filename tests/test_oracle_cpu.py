@@ -208,3 +208,37 @@ def test_real_audio_plumbing_with_reference_test_beams(fx):
     words = [fx.mono_lex.word_table.find(int(w)) for w in r["words"]]
     expect = [w if fx.mono_lex.word_table.member(w) else "<unk>" for w in fx.text.split()]
     assert words == expect
+
+
+def test_parallel_formulation_of_the_decoder_matches_sequential_oracle(fx):
+    """tests/viterbi_emul.py restates the GPU kernel's data-parallel formulation (prefix-min cutoff, first-creator
+    ordering, bucket order) in numpy; it must reproduce the sequential decoder exactly, including under tight beams,
+    ties, and graphs with more states than hash buckets."""
+    from tests import viterbi_emul as E
+
+    tm = fx.mono_tm
+    rng = np.random.default_rng(21)
+    words = [w for w in fx.text.split() if fx.mono_lex.word_table.member(w)]
+    pdfs = np.arange(tm.num_pdfs, dtype=np.int32)
+    tid2col = np.maximum(tm.id2pdf, 0).astype(np.int32)
+    cases = []
+    for u in range(10):
+        text = " ".join(rng.choice(words, size=int(rng.integers(1, 7))))
+        nph = sum(len(fx.mono_lex.word_pronunciations(w)[0].pronunciation.split()) for w in text.split())
+        T = int(3 * nph * rng.uniform(1.0, 2.5)) + 2
+        sd = float(rng.choice([0.0, 3.0, 12.0, 40.0]))
+        cases.append((fx.mono_graph(text), rng.normal(-60.0, sd, size=(T, tm.num_pdfs)).astype(np.float32)))
+    big = fx.mono_graph(" ".join(fx.text.split()[:24]))
+    assert big.num_states > 1000
+    cases.append((big, rng.normal(-60.0, 6.0, size=(330, tm.num_pdfs)).astype(np.float32)))
+    n_ok = 0
+    for f, ll in cases:
+        for beam in (0.7, 3.0, 10.0, 200.0):
+            ref = helpers.oracle_align(tm, f, ll, pdfs, beam=beam, retry_beam=0.0)
+            got = E.decode(f.num_states, f.start, f.arc_offsets, f.arcs, f.final, ll, tid2col, 0.1, beam)
+            assert got["status"] == ref["status"], (beam, got["status"], ref["status"])
+            if ref["status"] == 0:
+                n_ok += 1
+                assert np.array_equal(got["ali"], ref["ali"]) and np.array_equal(got["words"], ref["words"])
+                assert np.float32(got["like"]) == np.float32(ref["like"])
+    assert n_ok >= 20
