@@ -235,8 +235,13 @@ def main():
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cores = os.cpu_count() or 1
-        n_s = args.cpu_sample or min(args.pool, max(2 * cores, 8) if mono else cores)
+        # a 1-GPU box grants a 16-core CPU share (of a much larger host): never size the pool by os.cpu_count() alone
+        try:
+            avail = len(os.sched_getaffinity(0))
+        except AttributeError:
+            avail = os.cpu_count() or 1
+        cores = max(1, min(16, avail))
+        n_s = args.cpu_sample or min(args.pool, (16 if mono else 4) * cores)
         am = model.am
         tid2pdf = np.maximum(model.tm.id2pdf, 0)
         sample = []

@@ -1,0 +1,297 @@
+"""Host-side mirror of the kalpy objects MFA's alignment path calls — same names, argument meaning and
+error behaviour, backed by libmfa_hip.so instead of Kaldi.
+
+With these in place ``align_utterance_online``-style code (MFA/online/alignment.py:29-123) runs unchanged:
+
+    graph_compiler = TrainingGraphCompiler(model_path, tree_path, lexicon_compiler)
+    utterance.generate_mfccs(mfcc_computer); cmvn = CmvnComputer().compute_cmvn_from_features([utterance.mfccs])
+    utterance.apply_cmvn(cmvn); feats = utterance.generate_features(mfcc_computer, None, lda_mat=…, fmllr_trans=…)
+    fst = graph_compiler.compile_fst(text)
+    aligner = GmmAligner(model_path, beam=10, retry_beam=40, transition_scale=1.0, acoustic_scale=0.1, self_loop_scale=0.1)
+    alignment = aligner.align_utterance(fst, feats)          # None when the utterance cannot be aligned
+    ctm = lexicon_compiler.phones_to_pronunciations(alignment.words, alignment.generate_ctm(tm, phone_table, shift), …)
+
+Matrices cross this API as numpy arrays (kalpy: FloatMatrix/DoubleMatrix).  Every numeric step runs on the GPU through
+the C ABI; a missing library or GPU raises ``MfaHipError`` — there is no CPU path.
+"""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass
+from pathlib import Path
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+from . import ctm as _ctm
+from . import graph as _graph
+from . import kaldi_io
+from . import model as _model
+from .graph import LexiconCompiler as _LexiconCompiler
+from .graph import Pronunciation as KalpyPronunciation  # noqa: F401  (name used by the reference)
+
+_ENGINE = None
+
+
+def get_engine(device: int = 0):
+    """One engine per process (the reference: one aligner object per worker, never shared across processes)."""
+    global _ENGINE
+    if _ENGINE is None:
+        from .engine import AlignmentEngine
+
+        _ENGINE = AlignmentEngine(device)
+    return _ENGINE
+
+
+# ------------------------------------------------------------------------------------------------ audio / features
+class Segment:
+    """``Segment(path, begin, end, channel)`` — PCM16 16 kHz wav only (resampling is outside the parity domain)."""
+
+    def __init__(self, file_path, begin: Optional[float] = None, end: Optional[float] = None, channel: int = 0):
+        self.file_path = str(file_path)
+        self.begin, self.end, self.channel = begin, end, channel or 0
+
+    def load_audio(self) -> np.ndarray:
+        pcm, sr = kaldi_io.read_wav_pcm16(self.file_path)
+        if sr != 16000:
+            raise kaldi_io.KaldiFormatError(f"{self.file_path}: {sr} Hz audio; only native 16 kHz PCM16 is supported")
+        x = pcm[min(self.channel, pcm.shape[0] - 1)]
+        b = 0 if self.begin is None else int(round(self.begin * sr))
+        e = x.shape[0] if self.end is None else int(round(self.end * sr))
+        return np.ascontiguousarray(x[b:e])
+
+
+class MfccComputer:
+    """``MfccComputer(**mfcc_options)`` with MFA's option names (MFA/corpus/features.py:780-820)."""
+
+    _MAP = dict(sample_frequency="sample_frequency", frame_length="frame_length_ms", frame_shift="frame_shift_ms",
+                preemphasis_coefficient="preemphasis", low_frequency="low_frequency", high_frequency="high_frequency",
+                cepstral_lifter="cepstral_lifter", energy_floor="energy_floor", num_mel_bins="num_mel_bins",
+                num_coefficients="num_coefficients", snip_edges="snip_edges", remove_dc_offset="remove_dc_offset",
+                use_energy="use_energy", raw_energy="raw_energy")
+
+    def __init__(self, **options):
+        self.parameters = dict(options)
+        dither = options.get("dither", 0.0)
+        if dither not in (0, 0.0, None):
+            raise ValueError("dither must be 0: dithered features are random and outside the parity domain")
+        self._opts = {self._MAP[k]: v for k, v in options.items() if k in self._MAP and v is not None}
+        self.frame_shift = float(options.get("frame_shift", 10)) / 1000.0
+
+    def _configure(self):
+        eng = get_engine()
+        eng.configure_mfcc(**{k: (int(v) if isinstance(v, bool) else v) for k, v in self._opts.items()})
+        return eng
+
+    def compute_mfccs(self, segment: Union[Segment, np.ndarray]) -> np.ndarray:
+        import torch
+
+        eng = self._configure()
+        pcm = segment.load_audio() if isinstance(segment, Segment) else np.asarray(segment, dtype=np.int16)
+        out, _ = eng.mfcc(torch.from_numpy(pcm.copy()).to(eng.device), np.array([0, pcm.shape[0]], dtype=np.int64))
+        return out.cpu().numpy()
+
+    def compute_mfccs_for_export(self, segment, compress: bool = True) -> np.ndarray:
+        """The corpus path writes these 8-bit compressed; this engine keeps float32."""
+        return self.compute_mfccs(segment)
+
+
+class CmvnComputer:
+    def compute_cmvn_from_features(self, feats: Sequence[np.ndarray]) -> np.ndarray:
+        """Kaldi layout float64 [2, dim+1]: sums + count / sums of squares."""
+        import torch
+
+        eng = get_engine()
+        frame_off = np.concatenate([[0], np.cumsum([f.shape[0] for f in feats])]).astype(np.int64)
+        d = torch.from_numpy(np.concatenate(feats).astype(np.float32)).to(eng.device)
+        return eng.cmvn_stats(d, frame_off, np.zeros(len(feats), dtype=np.int32), 1).cpu().numpy()[0]
+
+
+class Utterance:
+    def __init__(self, segment: Segment, transcript: str, cmvn: Optional[np.ndarray] = None, fmllr: Optional[np.ndarray] = None):
+        self.segment, self.transcript = segment, transcript
+        self.cmvn, self.fmllr = cmvn, fmllr
+        self.mfccs: Optional[np.ndarray] = None
+        self._cmvn_applied: Optional[np.ndarray] = None
+
+    def generate_mfccs(self, mfcc_computer: MfccComputer) -> None:
+        self.mfccs = mfcc_computer.compute_mfccs(self.segment)
+
+    def apply_cmvn(self, cmvn: np.ndarray) -> None:
+        self.cmvn = np.asarray(cmvn, dtype=np.float64)
+
+    def generate_features(self, mfcc_computer: MfccComputer, pitch_computer=None, lda_mat: Optional[np.ndarray] = None,
+                          fmllr_trans: Optional[np.ndarray] = None, splice_context: int = 3) -> np.ndarray:
+        """CMVN → Δ+ΔΔ, or splice+LDA (→ fMLLR) when ``lda_mat`` is given (MFA/alignment/multiprocessing.py:1287-1304)."""
+        import torch
+
+        if pitch_computer is not None:
+            raise NotImplementedError("pitch features are not part of this engine")
+        if self.mfccs is None:
+            self.generate_mfccs(mfcc_computer)
+        eng = get_engine()
+        dev = eng.device
+        frame_off = np.array([0, self.mfccs.shape[0]], dtype=np.int64)
+        d = torch.from_numpy(self.mfccs.astype(np.float32)).to(dev)
+        cm = None if self.cmvn is None else torch.from_numpy(self.cmvn[None].copy()).to(dev)
+        u2s = np.zeros(1, dtype=np.int32)
+        lda = None if lda_mat is None else torch.from_numpy(np.asarray(lda_mat, dtype=np.float32)).to(dev)
+        fm = fmllr_trans if fmllr_trans is not None else self.fmllr
+        fm = None if fm is None else torch.from_numpy(np.asarray(fm, dtype=np.float32)[None].copy()).to(dev)
+        if fm is not None and lda is None:
+            raise NotImplementedError("fMLLR without LDA is not supported by the feature kernel")
+        return eng.features(d, frame_off, u2s, cm, lda=lda, fmllr=fm, splice_context=splice_context).cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------------------ lexicon / graphs
+class LexiconCompiler(_LexiconCompiler):
+    def phones_to_pronunciations(self, words, intervals, transcription: bool = False, text: Optional[str] = None):
+        return _ctm.phones_to_pronunciations(self, words, intervals, transcription, text)
+
+
+def _read_model(path_or_bytes) -> Tuple[_model.TransitionModel, _model.DiagGmmModel]:
+    data = path_or_bytes if isinstance(path_or_bytes, (bytes, bytearray)) else Path(path_or_bytes).read_bytes()
+    return _model.load_model_bytes(bytes(data))
+
+
+def read_transition_model(path):
+    return _read_model(path)[0]
+
+
+def read_gmm_model(path):
+    return _read_model(path)
+
+
+class TrainingGraphCompiler(_graph.TrainingGraphCompiler):
+    """``TrainingGraphCompiler(model_path, tree_path, lexicon_compiler, use_g2p=False, batch_size=…)``."""
+
+    def __init__(self, model_path, tree_path, lexicon_compiler, use_g2p: bool = False, batch_size: int = 500):
+        tm = model_path if isinstance(model_path, _model.TransitionModel) else _read_model(model_path)[0]
+        tree = tree_path if isinstance(tree_path, kaldi_io.ContextDependency) else kaldi_io.read_tree(Path(tree_path).read_bytes())
+        super().__init__(tm, tree, lexicon_compiler, use_g2p, batch_size)
+
+    def export_graphs(self, file_name, records: Iterable[Tuple[str, str]], write_scp: bool = False, callback=None,
+                      interjection_words=None) -> None:
+        """Writes ``fsts.*.ark`` (key + OpenFst VectorFst<StdArc> binary per utterance)."""
+        with open(file_name, "wb") as f:
+            for key, text in records:
+                kaldi_io.write_ark_entry(f, key, self.compile_fst(text), "fst")
+                if callback:
+                    callback(key)
+
+
+# ------------------------------------------------------------------------------------------------ alignment
+@dataclass
+class Alignment:
+    utterance_id: Optional[str]
+    alignment: List[int]
+    words: List[int]
+    likelihood: float
+    per_frame_likelihoods: Optional[np.ndarray] = None
+
+    def generate_ctm(self, transition_model, phone_table, frame_shift: float = 0.01):
+        return _ctm.generate_ctm(self.alignment, transition_model, phone_table, frame_shift)
+
+
+class GmmAligner:
+    """``GmmAligner(model_path, beam=, retry_beam=, transition_scale=, acoustic_scale=, self_loop_scale=,
+    disambiguation_symbols=)`` (MFA/alignment/multiprocessing.py:814; MFA/online/alignment.py:97-104)."""
+
+    def __init__(self, acoustic_model_path, beam: float = 10, retry_beam: float = 40, transition_scale: float = 1.0,
+                 acoustic_scale: float = 0.1, self_loop_scale: float = 0.1, disambiguation_symbols=None,
+                 careful: bool = False):
+        if careful:
+            raise NotImplementedError("careful alignment is not implemented")
+        self.acoustic_model_path = acoustic_model_path
+        self.transition_model, self.acoustic_model = _read_model(acoustic_model_path)
+        self.beam, self.retry_beam = float(beam), float(retry_beam)
+        if self.retry_beam != 0 and self.retry_beam <= self.beam:
+            self.retry_beam = 4 * self.beam  # MFA/alignment/mixins.py:91-92
+        self.transition_scale, self.acoustic_scale, self.self_loop_scale = transition_scale, acoustic_scale, self_loop_scale
+        self.disambiguation_symbols = sorted(disambiguation_symbols or [])
+        self._scaled = self.transition_model.scaled_log_probs(transition_scale, self_loop_scale)
+        self._loaded = False
+
+    def boost_silence(self, silence_weight: float, silence_phones: Sequence[int]) -> None:
+        self.acoustic_model.boost_silence(silence_weight, _model.pdfs_of_phones(self.transition_model, silence_phones))
+        self._loaded = False
+
+    def _engine(self):
+        eng = get_engine()
+        if not self._loaded or eng.gmm is not self.acoustic_model:
+            eng.load_gmm(self.acoustic_model)
+            self._loaded = True
+        return eng
+
+    def align_utterances(self, fsts: Sequence[kaldi_io.Fst], feats: Sequence[np.ndarray], utterance_ids=None) -> List[Optional[Alignment]]:
+        """Batched form of ``align_utterance``: one device launch per stage for the whole list."""
+        import torch
+
+        eng = self._engine()
+        graphs = eng.pack_graphs([_graph.add_transition_probs(f, self._scaled) for f in fsts], self.transition_model)
+        frame_off = np.concatenate([[0], np.cumsum([x.shape[0] for x in feats])]).astype(np.int64)
+        d_feats = torch.from_numpy(np.concatenate(feats).astype(np.float32)).to(eng.device)
+        ll, ll_off, ll_cols = eng.score(d_feats, frame_off, graphs.pdf_list, graphs.pdf_off_host, graphs.class_counts)
+        res = eng.align(graphs, ll, ll_off, ll_cols, frame_off, beam=self.beam, retry_beam=self.retry_beam,
+                        acoustic_scale=self.acoustic_scale, want_frame_likes=True)
+        res = {k: v.cpu().numpy() for k, v in res.items() if v is not None}
+        out: List[Optional[Alignment]] = []
+        for u in range(len(fsts)):
+            st = int(res["status"][u])
+            if st not in (0, 1):
+                if st > 2:
+                    raise RuntimeError(f"device decoder reported status {st} for utterance {u} (see include/mfa_hip.h)")
+                out.append(None)  # the reference returns None and lets the caller count the failure
+                continue
+            a, b = int(frame_off[u]), int(frame_off[u + 1])
+            nw = int(res["n_words"][u])
+            out.append(Alignment(utterance_ids[u] if utterance_ids else None, res["ali"][a:b].tolist(),
+                                 res["words"][a: a + nw].tolist(), float(res["like"][u]), res["frame_like"][a:b].copy()))
+        return out
+
+    def align_utterance(self, training_graph: kaldi_io.Fst, features: np.ndarray, utterance_id: Optional[str] = None):
+        return self.align_utterances([training_graph], [features], [utterance_id])[0]
+
+    def export_alignments(self, file_name, training_graph_archive, feature_archive, word_file_name=None,
+                          likelihood_file_name=None, callback=None, batch_size: int = 256) -> None:
+        """``training_graph_archive`` / ``feature_archive``: iterables of (key, Fst) / (key, matrix) with equal key order
+        (kalpy: FstArchive, FeatureArchive).  Writes Kaldi int32-vector / float-vector arks keyed by utterance."""
+        fa = open(file_name, "wb")
+        fw = open(word_file_name, "wb") if word_file_name else None
+        fl = open(likelihood_file_name, "wb") if likelihood_file_name else None
+        try:
+            feats = dict(feature_archive) if not isinstance(feature_archive, dict) else feature_archive
+            batch: List[Tuple[str, kaldi_io.Fst]] = []
+
+            def flush():
+                if not batch:
+                    return
+                keys = [k for k, _ in batch]
+                res = self.align_utterances([f for _, f in batch], [feats[k] for k in keys], keys)
+                for key, al in zip(keys, res):
+                    if al is not None:
+                        kaldi_io.write_ark_entry(fa, key, np.asarray(al.alignment, dtype=np.int32), "int_vector")
+                        if fw:
+                            kaldi_io.write_ark_entry(fw, key, np.asarray(al.words, dtype=np.int32), "int_vector")
+                        if fl:
+                            kaldi_io.write_ark_entry(fl, key, al.per_frame_likelihoods.astype(np.float32), "vector")
+                    if callback:
+                        callback((key, al.likelihood if al is not None else None))
+                batch.clear()
+
+            for key, fst in training_graph_archive:
+                if key not in feats:
+                    continue
+                batch.append((key, fst))
+                if len(batch) >= batch_size:
+                    flush()
+            flush()
+        finally:
+            for f in (fa, fw, fl):
+                if f:
+                    f.close()
+
+
+HierarchicalCtm = _ctm.HierarchicalCtm
+CtmInterval = _ctm.CtmInterval
+WordCtmInterval = _ctm.WordCtmInterval
