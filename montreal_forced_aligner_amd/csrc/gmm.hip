@@ -105,12 +105,24 @@ __device__ __forceinline__ float reg_max(const f32x16 &v) {
   for (int r = R0 + 1; r < R1; r++) m = fmaxf(m, v[r]);
   return m;
 }
+// exp(x) for x in [ln(eps), 0]: 2^(x·log2 e) with the product's rounding error folded back in (≈1.5 ulp, six VALU
+// instructions instead of the ≈20 of the library expf — the epilogue shares the SIMD with the other wavefront's MFMAs).
+__device__ __forceinline__ float exp_neg(float x) {
+  const float kL2E = 1.44269504088896341f, kL2E_lo = 1.92596299112661746e-8f, kLn2 = 0.693147180559945309f;
+  float t = x * kL2E;
+  float e = fmaf(x, kL2E, -t);
+  e = fmaf(x, kL2E_lo, e);
+  float r = __builtin_amdgcn_exp2f(t);
+  return fmaf(r, e * kLn2, r);
+}
 template <int R0, int R1>
 __device__ __forceinline__ double reg_expsum(const f32x16 &v, float mx, float cutoff) {
   double s = 0.0;
 #pragma unroll
-  for (int r = R0; r < R1; r++)
-    if (v[r] >= cutoff) s += (double)expf(v[r] - mx);
+  for (int r = R0; r < R1; r++) {
+    float e = exp_neg(v[r] - mx);
+    s += (double)(v[r] >= cutoff ? e : 0.0f);
+  }
   return s;
 }
 __device__ __forceinline__ float finish(float mx, double sum) { return (float)((double)mx + log(sum)); }
@@ -175,10 +187,13 @@ __global__ __launch_bounds__(256, 2) void gmm_kernel(GmmParams p) {
         }
       }
     }
-#pragma unroll
-    for (int n = 0; n < kNT; n++) {
-      int t = t_base + 32 * n + col;
-      if (h == 0 && t < T) out[(size_t)t * P + j] = finish(mx[n], sum[n]);
+    // both halves hold every tile's (max, sum): half h finishes tile h, so each lane takes one log, not kNT
+    static_assert(kNT == 2, "the finish split assumes two frame tiles per wavefront");
+    {
+      const float mxs = h ? mx[1] : mx[0];
+      const double sums = h ? sum[1] : sum[0];
+      const int t = t_base + 32 * h + col;
+      if (t < T) out[(size_t)t * P + j] = finish(mxs, sums);
     }
   }
 

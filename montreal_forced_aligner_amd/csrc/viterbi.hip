@@ -128,6 +128,11 @@ __device__ __forceinline__ double cand_cost(float w, double cost, float ll, floa
   return ((double)w + cost) + (double)ac;
 }
 
+constexpr int kArcCache = 8;  // arcs per token kept in registers during expansion (deeper states take a slow tail loop)
+
+// kListsInLds: the two token lists (state, cost) live in LDS (fast path) or, for graphs/beams whose tables would not
+// fit in 160 KiB, in the per-utterance HBM workspace.
+template <bool kListsInLds>
 __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x;
@@ -150,21 +155,22 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
   const int P = p.ll_cols[utt];
   const int N = p.nmax, C = p.cmax;
 
-  // ---- LDS carve (all offsets multiples of 8 bytes)
-  // volatile: these tables carry values between lanes of the wavefront; every access must reach LDS in program order
-  volatile u64 *s_cost = (volatile u64 *)smem;                 // [N] best cost key per slot
-  volatile u32 *slot_of = (volatile u32 *)(smem + (size_t)N * 8);  // [S] state → slot
+  // ---- LDS carve (8-byte items first).  volatile: these tables carry values between lanes of the wavefront; every
+  // access must reach LDS in program order.
+  volatile u64 *s_cost = (volatile u64 *)smem;                  // [N] best cost key per slot
+  volatile double *l_cost0 = kListsInLds ? (volatile double *)(s_cost + N)   // [2][N] token costs (current / next list)
+                                         : (volatile double *)(p.w_cost + (size_t)utt * 2 * N);
+  volatile u32 *slot_of = (volatile u32 *)(s_cost + (kListsInLds ? 3 : 1) * (size_t)N);  // [S] state → slot
   const int S2 = (S + 1) & ~1;
   volatile u32 *s_state = slot_of + S2;      // [N]
   volatile u32 *s_F = s_state + N;           // [N] first creating candidate (pos<<6|k)
   volatile u32 *s_W = s_F + N;               // [N] winning candidate
   volatile u32 *s_aux = s_W + N;             // [N] (rank<<24)|ordinal of the bucket leader's first candidate
   volatile u32 *t_cbase = s_aux + N;         // [N] candidate ordinal base per source token
-  volatile u32 *cntord = t_cbase + N;        // [C] bucket sizes at leader ordinals → exclusive sums
+  volatile u32 *l_state0 = kListsInLds ? t_cbase + N : (volatile u32 *)(p.w_state + (size_t)utt * 2 * N);  // [2][N] token states
+  volatile u32 *cntord = t_cbase + N + (kListsInLds ? 2 * N : 0);  // [C] bucket sizes at leader ordinals → exclusive sums
   volatile u32 *ctr = cntord + C;            // [2]: nslots, nstash
 
-  volatile u32 *l_state[2] = {p.w_state + (size_t)utt * 2 * N, p.w_state + (size_t)utt * 2 * N + N};
-  volatile double *l_cost[2] = {p.w_cost + (size_t)utt * 2 * N, p.w_cost + (size_t)utt * 2 * N + N};
   volatile u32 *st_a = p.w_stash_a + (size_t)utt * C;
   volatile u32 *st_b = p.w_stash_b + (size_t)utt * C;
   volatile u64 *st_key = p.w_stash_key + (size_t)utt * C;
@@ -181,7 +187,7 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
   if (S <= 0 || start < 0 || start >= S || T <= 0) status = ST_FAILED;
   // InitDecoding: one token at the start state with cost 0 (graphs are epsilon-free: ProcessNonemitting is a no-op)
   int cur = 0, n = 1;
-  if (lane == 0) { l_state[0][0] = (u32)(start < 0 ? 0 : start); l_cost[0][0] = 0.0; }
+  if (lane == 0) { l_state0[0] = (u32)(start < 0 ? 0 : start); l_cost0[0] = 0.0; }
   u32 H = p.pass == 0 ? 1000u : p.w_hash[utt];
   u64 bp_used = 0;
   __threadfence_block();
@@ -189,11 +195,13 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
   int t = 0;
   for (; t < T && status == ST_OK; t++) {
     const float *llt = ll + (size_t)t * P;
+    volatile u32 *c_state = l_state0 + cur * N, *n_state = l_state0 + (cur ^ 1) * N;
+    volatile double *c_cost = l_cost0 + cur * N, *n_cost = l_cost0 + (cur ^ 1) * N;
     // ---------------- GetCutoff: best cost (first index on ties), count
     double best = INFINITY; u32 best_i = kEmpty;
     for (int c0 = 0; c0 < n; c0 += 64) {
       int i = c0 + lane;
-      double cst = i < n ? l_cost[cur][i] : INFINITY;
+      double cst = i < n ? c_cost[i] : INFINITY;
       double m = wave_min_f64(cst);
       if (m < best) {  // uniform
         u32 cand = (i < n && cst == m) ? (u32)i : kEmpty;
@@ -208,30 +216,21 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
       u32 kle = 0;
       for (int c0 = 0; c0 < n; c0 += 64) {
         int i = c0 + lane;
-        kle += (i < n && l_cost[cur][i] <= beam_cut) ? 1u : 0u;
+        kle += (i < n && c_cost[i] <= beam_cut) ? 1u : 0u;
       }
       kle = wave_sum_u32(kle);
       if (kle > (u32)kMinActive) { wcut = beam_cut; abeam = p.beam; }
       else {
-        // sorted[min_active] > beam_cut: walk up the distinct costs above beam_cut until 21 tokens are covered
-        double v = beam_cut; u32 cnt = kle;
-        for (int it = 0; it <= kMinActive && cnt <= (u32)kMinActive; it++) {
-          double nxt = INFINITY;
-          for (int c0 = 0; c0 < n; c0 += 64) {
-            int i = c0 + lane;
-            double cst = i < n ? l_cost[cur][i] : INFINITY;
-            if (cst > v) nxt = fmin(nxt, cst);
-          }
-          nxt = wave_min_f64(nxt);
-          if (!(nxt < INFINITY)) { v = nxt; break; }
-          u32 eq = 0;
-          for (int c0 = 0; c0 < n; c0 += 64) {
-            int i = c0 + lane;
-            eq += (i < n && l_cost[cur][i] == nxt) ? 1u : 0u;
-          }
-          cnt += wave_sum_u32(eq);
-          v = nxt;
+        // sorted[min_active] (> beam_cut) = the smallest cost that has at least min_active+1 costs ≤ it
+        double v = INFINITY;
+        for (int c0 = 0; c0 < n; c0 += 64) {
+          int i = c0 + lane;
+          double cst = i < n ? c_cost[i] : INFINITY;
+          u32 le = 0;
+          for (int j = 0; j < n; j++) le += (c_cost[j] <= cst) ? 1u : 0u;  // LDS broadcast reads
+          if (i < n && le > (u32)kMinActive) v = fmin(v, cst);
         }
+        v = wave_min_f64(v);
         wcut = v;
         abeam = (float)(v - best + (double)kBeamDelta);
       }
@@ -239,10 +238,12 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
     // PossiblyResizeHash
     { u32 want = (u32)((float)n * kHashRatio); if (want > H) H = want; }
 
-    // ---------------- seed the next cutoff from the best token's arcs
+    // ---------------- seed of the running cutoff: the best token's cheapest candidate.  With a single chunk it is
+    // taken from the expansion's registers below; otherwise computed here.
+    const bool single = n <= 64;
     double run = INFINITY;  // min over candidate costs seen so far (seed + earlier candidates)
-    if (best_i != kEmpty) {
-      const u32 bs = l_state[cur][best_i];
+    if (!single && best_i != kEmpty) {
+      const u32 bs = c_state[best_i];
       const int a0 = arc_off[bs], a1 = arc_off[bs + 1];
       double m = INFINITY;
       for (int a = a0 + lane; a < a1; a += 64) m = fmin(m, cand_cost(a_w[a], best, llt[a_col[a]], p.scale));
@@ -254,34 +255,41 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
     bool bad_degree = false;
     for (int c0 = 0; c0 < n; c0 += 64) {
       const int i = c0 + lane;
-      const u32 st = i < n ? l_state[cur][i] : 0u;
-      const double cst = i < n ? l_cost[cur][i] : INFINITY;
+      const u32 st = i < n ? c_state[i] : 0u;
+      const double cst = i < n ? c_cost[i] : INFINITY;
       const bool act = i < n && cst < wcut;
-      const int a0 = act ? arc_off[st] : 0;
-      const int narc = act ? arc_off[st + 1] - a0 : 0;
+      int a0 = 0, narc = 0;
+      if (act) { a0 = arc_off[st]; narc = arc_off[st + 1] - a0; }
       if (narc > kMaxArcsPerState) bad_degree = true;
       const int maxarc = (int)wave_max_u32((u32)narc);
-      // candidate ordinals
       const u32 cb = cand_base + excl_prefix_sum((u32)narc, lane);
       if (i < n) t_cbase[i] = cb;
       cand_base += wave_sum_u32((u32)narc);
-      // traversal 1: per-token minimum
+      // arcs → registers (independent loads, one round trip), then their scores (second round trip)
+      float w[kArcCache]; int col[kArcCache]; u32 nx[kArcCache]; double nw[kArcCache]; u32 sl[kArcCache];
+#pragma unroll
+      for (int k = 0; k < kArcCache; k++) {
+        w[k] = 0.0f; col[k] = 0; nx[k] = 0;
+        if (k < narc) { w[k] = a_w[a0 + k]; col[k] = a_col[a0 + k]; nx[k] = (u32)a_next[a0 + k]; }
+      }
       double m = INFINITY;
-      for (int k = 0; k < maxarc; k++)
+#pragma unroll
+      for (int k = 0; k < kArcCache; k++) {
+        nw[k] = (k < narc) ? cand_cost(w[k], cst, llt[col[k]], p.scale) : INFINITY;
+        m = fmin(m, nw[k]);
+        sl[k] = kEmpty;
+      }
+      for (int k = kArcCache; k < maxarc; k++)
         if (k < narc) m = fmin(m, cand_cost(a_w[a0 + k], cst, llt[a_col[a0 + k]], p.scale));
+      if (single) run = best_i != kEmpty ? shfl_f64(m, (int)best_i) : INFINITY;  // best token is always expanded
       double local = fmin(run, excl_prefix_min(m, lane));
       run = fmin(run, wave_min_f64(m));
-      // traversal 2: create
-      for (int k = 0; k < maxarc; k++) {
-        bool created = false; double nw = 0.0; u32 d = 0;
-        if (k < narc) {
-          nw = cand_cost(a_w[a0 + k], cst, llt[a_col[a0 + k]], p.scale);
-          created = nw < local + (double)abeam;
-          local = fmin(local, nw);
-          d = (u32)a_next[a0 + k];
-        }
+
+      // one candidate: find-or-create the destination's slot, lower its cost, remember the first creator
+      auto create = [&](u32 d, double cnw, u32 cidx, bool created) -> u32 {
+        u32 s = kEmpty;
         if (created) {
-          u32 s = slot_of[d];
+          s = slot_of[d];
           if (s == kEmpty) {
             u32 old = atomicCAS((u32 *)&slot_of[d], kEmpty, kClaim);
             if (old == kEmpty) {
@@ -293,16 +301,45 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
         }
         // all lanes reconverge here; claims made above are published (LDS is in-order within a wavefront)
         if (created) {
-          u32 s = slot_of[d];
+          s = slot_of[d];
           if (s < (u32)N) {
-            const u32 cidx = ((u32)i << kArcBits) | (u32)k;
-            const u64 key = dkey(nw);
-            atomicMin((u64 *)&s_cost[s], key);
+            atomicMin((u64 *)&s_cost[s], dkey(cnw));
             atomicMin((u32 *)&s_F[s], cidx);
+          } else s = kEmpty;
+        }
+        return s;
+      };
+#pragma unroll
+      for (int k = 0; k < kArcCache; k++) {
+        if (k < maxarc) {  // uniform
+          bool created = (k < narc) && (nw[k] < local + (double)abeam);
+          if (k < narc) local = fmin(local, nw[k]);
+          sl[k] = create(nx[k], nw[k], ((u32)i << kArcBits) | (u32)k, created);
+          if (!single && sl[k] != kEmpty) {
             u32 q = atomicAdd((u32 *)&ctr[1], 1u);
-            if (q < (u32)C) { st_a[q] = s; st_b[q] = cidx; st_key[q] = key; }
+            if (q < (u32)C) { st_a[q] = sl[k]; st_b[q] = ((u32)i << kArcBits) | (u32)k; st_key[q] = dkey(nw[k]); }
           }
         }
+      }
+      for (int k = kArcCache; k < maxarc; k++) {  // slow tail: states with more than kArcCache arcs
+        bool created = false; double cnw = 0.0; u32 d = 0;
+        if (k < narc) {
+          cnw = cand_cost(a_w[a0 + k], cst, llt[a_col[a0 + k]], p.scale);
+          created = cnw < local + (double)abeam;
+          local = fmin(local, cnw);
+          d = (u32)a_next[a0 + k];
+        }
+        u32 s = create(d, cnw, ((u32)i << kArcBits) | (u32)k, created);
+        if (s != kEmpty) {  // tail candidates always go through the stash
+          u32 q = atomicAdd((u32 *)&ctr[1], 1u);
+          if (q < (u32)C) { st_a[q] = s; st_b[q] = ((u32)i << kArcBits) | (u32)k; st_key[q] = dkey(cnw); }
+        }
+      }
+      if (single) {
+        // winners straight from registers: earliest candidate among those that reached the slot's final best cost
+#pragma unroll
+        for (int k = 0; k < kArcCache; k++)
+          if (sl[k] != kEmpty && dkey(nw[k]) == s_cost[sl[k]]) atomicMin((u32 *)&s_W[sl[k]], ((u32)i << kArcBits) | (u32)k);
       }
     }
     __threadfence_block();
@@ -311,7 +348,7 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
     if (nslots > (u32)N || nstash > (u32)C || cand_base > (u32)C) { status = ST_TOKEN_OVERFLOW; break; }
     if (nslots == 0) { n = 0; t++; break; }  // everything pruned: no surviving token
 
-    // ---------------- winners: earliest candidate among those that reached the best cost
+    // ---------------- winners for stashed candidates (multi-chunk frames and deep states)
     for (u32 q0 = 0; q0 < nstash; q0 += 64) {
       u32 q = q0 + lane;
       if (q < nstash) {
@@ -354,7 +391,6 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
     }
     // ---------------- write the new list + back-pointers, reset the tables
     if (bp_used + nslots > bp_cap) { status = ST_BP_OVERFLOW; break; }
-    const int nxt = cur ^ 1;
     bool broken = false;  // defensive: an inconsistent table must never turn into an out-of-range store
     for (u32 j0 = 0; j0 < nslots; j0 += 64) {
       u32 j = j0 + lane;
@@ -365,9 +401,9 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
         const u32 ppos = W >> kArcBits, k = W & (kMaxArcsPerState - 1);
         if (pos >= nslots || ppos >= (u32)n || d >= (u32)S) broken = true;
         else {
-          const u32 arc = (u32)arc_off[l_state[cur][ppos]] + k;
-          l_state[nxt][pos] = d;
-          l_cost[nxt][pos] = dunkey(s_cost[j]);
+          const u32 arc = (u32)arc_off[c_state[ppos]] + k;
+          n_state[pos] = d;
+          n_cost[pos] = dunkey(s_cost[j]);
           bp[bp_used + pos] = ((u64)arc << 32) | (u64)ppos;
         }
       }
@@ -380,10 +416,12 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
     if (lane == 0) { tokoff[t] = (u32)bp_used; ctr[0] = 0; ctr[1] = 0; }
     bp_used += nslots;
     n = (int)nslots;
-    cur = nxt;
+    cur ^= 1;
     __threadfence_block();
   }
   if (p.pass == 0 && lane == 0) p.w_hash[utt] = H;
+  volatile u32 *c_state = l_state0 + cur * N;
+  volatile double *c_cost = l_cost0 + cur * N;
 
   // ---------------- ReachedFinal / best final token (first in list order on ties)
   int32_t out_status = status;
@@ -395,8 +433,8 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
         int i = c0 + lane;
         double tc = INFINITY;
         if (i < n) {
-          float fw = final_w[l_state[cur][i]];
-          if (fw != INFINITY) tc = l_cost[cur][i] + (double)fw;
+          float fw = final_w[c_state[i]];
+          if (fw != INFINITY) tc = c_cost[i] + (double)fw;
         }
         double m = wave_min_f64(tc);
         if (m < bestc) {
@@ -419,7 +457,7 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
 
   // ---------------- traceback (one lane chases the pointers), arc index per frame parked in ali[]
   int32_t *ali = p.ali + f0;
-  const u32 fstate = l_state[cur][bpos];
+  const u32 fstate = c_state[bpos];
   if (lane == 0) {
     u32 pos = bpos;
     for (int tt = T - 1; tt >= 0; tt--) {
@@ -438,7 +476,7 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
   const float inv_scale = -1.0f / p.scale;
   for (int c0 = 0; c0 < T; c0 += 64) {
     const int tt = c0 + lane;
-    int arc = tt < T ? ali[tt] : 0;
+    int arc = tt < T ? ((volatile int32_t *)ali)[tt] : 0;
     int il = 0, ol = 0; float w = 0.0f, ac = 0.0f;
     if (tt < T) {
       il = a_il[arc]; ol = a_ol[arc]; w = a_w[arc];
@@ -480,10 +518,11 @@ __global__ void finalize_pending_kernel(int32_t *status, int n_utt) {
   if (i < n_utt && status[i] == ST_PENDING) status[i] = ST_FAILED;
 }
 
-size_t lds_bytes(int S, int N, int C) {
+size_t lds_bytes(int S, int N, int C, bool lists_in_lds) {
   int S2 = (S + 1) & ~1;
-  return (size_t)N * 8 + (size_t)S2 * 4 + (size_t)N * 5 * 4 + (size_t)C * 4 + 16;
+  return (size_t)N * 8 + (size_t)S2 * 4 + (size_t)N * 5 * 4 + (size_t)C * 4 + 16 + (lists_in_lds ? (size_t)N * 24 : 0);
 }
+constexpr size_t kLdsLimit = 160 * 1024;
 
 struct WsLayout {
   size_t state, cost, sta, stb, stkey, bp, tokoff, hash, list, count, total;
@@ -555,8 +594,16 @@ MFA_API int mfa_align_batch(mfa_ctx *c, const mfa_graph_batch *g, const float *d
   }
   unsigned char *base = (unsigned char *)c->d_ws;
   for (int ps = 0; ps < passes; ps++) {
-    size_t lds = lds_bytes(max_states, N[ps], C[ps]);
-    if (lds > 160 * 1024) return c->fail("Viterbi tables need %zu bytes of LDS (> 160 KiB): %d states, %d tokens", lds, max_states, N[ps]);
+    // token lists in LDS when everything fits comfortably; in HBM for big graphs / the wide retry beam; and if even the
+    // atomically updated tables do not fit, shrink the token capacity (an overflow is then reported per utterance)
+    bool lists_in_lds = lds_bytes(max_states, N[ps], C[ps], true) <= kLdsLimit / 2 ||
+                        (ps == 0 && lds_bytes(max_states, N[ps], C[ps], true) <= kLdsLimit);
+    while (lds_bytes(max_states, N[ps], C[ps], lists_in_lds) > kLdsLimit && N[ps] > 64) {
+      N[ps] = (N[ps] / 2 + 63) & ~63;
+      if (C[ps] > 8 * N[ps]) C[ps] = 8 * N[ps];
+    }
+    size_t lds = lds_bytes(max_states, N[ps], C[ps], lists_in_lds);
+    if (lds > kLdsLimit) return c->fail("Viterbi tables need %zu bytes of LDS (> 160 KiB): %d states, %d tokens", lds, max_states, N[ps]);
     VitParams p;
     p.g = *g; p.ll = d_loglikes; p.ll_off = d_ll_off; p.ll_cols = d_ll_cols; p.frame_off = d_frame_off;
     p.beam = ps == 0 ? o->beam : o->retry_beam; p.scale = o->acoustic_scale;
@@ -575,10 +622,15 @@ MFA_API int mfa_align_batch(mfa_ctx *c, const mfa_graph_batch *g, const float *d
       hipLaunchKernelGGL(collect_pending_kernel, dim3((n_utt + 255) / 256), dim3(256), 0, c->stream, d_status, n_utt, d_list, d_count);
       p.utt_list = d_list; p.n_list = d_count;
     }
-    MFA_HIP_CHECK(c, hipFuncSetAttribute((const void *)viterbi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     {
       KernelTimer kt(c, MFA_K_VITERBI);
-      hipLaunchKernelGGL(viterbi_kernel, dim3(n_utt), dim3(64), lds, c->stream, p);
+      if (lists_in_lds) {
+        MFA_HIP_CHECK(c, hipFuncSetAttribute((const void *)viterbi_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(viterbi_kernel<true>, dim3(n_utt), dim3(64), lds, c->stream, p);
+      } else {
+        MFA_HIP_CHECK(c, hipFuncSetAttribute((const void *)viterbi_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(viterbi_kernel<false>, dim3(n_utt), dim3(64), lds, c->stream, p);
+      }
     }
     MFA_HIP_CHECK(c, hipGetLastError());
   }

@@ -1,0 +1,68 @@
+"""GPU test of the kalpy-shaped host API: the call sequence of align_utterance_online
+(MFA/online/alignment.py:77-122) on the reference's own plumbing fixture, checked against the oracle."""
+import wave
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+def test_align_utterance_online_sequence(fx, tmp_path):
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from montreal_forced_aligner_amd import kalpy_api as KA
+    from montreal_forced_aligner_amd import kaldi_io as K
+
+    ar = K.load_acoustic_model_archive(helpers.REF / "mono_model.zip")
+    (tmp_path / "final.mdl").write_bytes(ar["final.mdl"])
+    (tmp_path / "tree").write_bytes(ar["tree"])
+    seg_pcm = fx.pcm[: 16000 * 4 + 3200]
+    wav_path = tmp_path / "utt.wav"
+    with wave.open(str(wav_path), "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000); w.writeframes(seg_pcm.tobytes())
+    text = "this is the acoustic corpus i'm talking pretty fast here"
+
+    lexicon_compiler = KA.LexiconCompiler(position_dependent_phones=True, phones=fx.mono_meta["phones"],
+                                          silence_phone="sp", oov_phone="spn")
+    lexicon_compiler.load_pronunciations(helpers.REF / "test_acoustic.txt")
+    lexicon_compiler.build_phone_table(["sil", "sp", "spn"])
+    mfcc_computer = KA.MfccComputer(sample_frequency=16000, frame_length=25, frame_shift=10, num_mel_bins=23,
+                                    num_coefficients=13, snip_edges=False, dither=0.0, use_energy=False)
+    utterance = KA.Utterance(KA.Segment(wav_path, 0.0, None, 0), text)
+    graph_compiler = KA.TrainingGraphCompiler(tmp_path / "final.mdl", tmp_path / "tree", lexicon_compiler)
+    utterance.generate_mfccs(mfcc_computer)
+    cmvn = KA.CmvnComputer().compute_cmvn_from_features([utterance.mfccs])
+    utterance.apply_cmvn(cmvn)
+    feats = utterance.generate_features(mfcc_computer, None)
+    assert feats.shape == (420, 39)
+    fst = graph_compiler.compile_fst(text)
+    aligner = KA.GmmAligner(tmp_path / "final.mdl", beam=100, retry_beam=400, transition_scale=1.0, acoustic_scale=0.1,
+                            self_loop_scale=0.1)
+    assert KA.GmmAligner(tmp_path / "final.mdl", beam=10, retry_beam=40).align_utterance(fst, feats[:30]) is None
+    alignment = aligner.align_utterance(fst, feats)
+    assert alignment is not None and len(alignment.alignment) == 420
+    phone_intervals = alignment.generate_ctm(aligner.transition_model, lexicon_compiler.phone_table, mfcc_computer.frame_shift)
+    ctm = lexicon_compiler.phones_to_pronunciations(alignment.words, phone_intervals, transcription=False, text=text)
+    ctm.likelihood = alignment.likelihood
+    ctm.update_utterance_boundaries(0.0, 4.2)
+    words = [w.label for w in ctm.word_intervals if w.label != lexicon_compiler.silence_word]
+    assert words == text.split()
+    out = tmp_path / "utt.TextGrid"
+    ctm.export_textgrid(out, file_duration=4.2, output_format="long_textgrid", silence_words=(lexicon_compiler.silence_word,))
+    assert 'name = "words"' in out.read_text() and 'name = "phones"' in out.read_text()
+
+    # oracle on the same audio/graph
+    x = fx.mono_feats(seg_pcm)
+    am, tm = fx.mono_am, fx.mono_tm
+    pl = np.unique(tm.id2pdf[fst.arcs["ilabel"]])
+    ref = helpers.oracle_align(tm, fx.mono_graph(text), O.gmm_loglikes(x, am.gconsts, am.means_invvars, am.inv_vars,
+                                                                        am.pdf_offsets, pl), pl, beam=100.0, retry_beam=400.0)
+    assert ref["status"] in (0, 1)
+    assert np.array_equal(np.asarray(alignment.alignment), ref["ali"])
+    assert abs(alignment.likelihood - ref["like"]) / 420 < 1e-3

@@ -138,8 +138,11 @@ def test_gmm_real_mixture_model(engine, fx):
     for u in range(3):
         ref = O.gmm_loglikes(feats[u], am.gconsts, am.means_invvars, am.inv_vars, am.pdf_offsets, sorted_lists[u])
         err = np.abs(got[u] - ref)
-        assert err.max() < 1e-4 * max(1.0, np.abs(ref).max()), err.max()  # device expf/log vs libm: last-bit differences
-        assert (got[u] == ref).mean() > 0.9
+        # the device exponential (exp2-based, ≈1.5 ulp) and log differ from libm in the last bits; everything before the
+        # log-sum-exp is bit-identical, so the disagreement stays at the ulp level of a float32 log-likelihood (~1e-5)
+        assert err.max() < 1e-4 * max(1.0, np.abs(ref).max()), err.max()
+        assert err.max() <= 4 * np.spacing(np.float32(np.abs(ref).max())), err.max()
+        assert (got[u] == ref).mean() > 0.5
 
 
 @pytest.mark.parametrize("dim", [40, 39, 45])
