@@ -27,14 +27,12 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kNT = 2;                 // 32-frame tiles per wavefront
-constexpr int kFramesPerWave = 32 * kNT;
-constexpr int kWaves = 4;
+// a wavefront owns NT 32-frame tiles; a workgroup is kWaves wavefronts (template parameter)
 constexpr float kPadGconst = -1.0e30f;
 
 struct GmmParams {
   int dim, kpad, num_rows;  // num_rows = index of the dummy row
-  const float *w; const float *gc; const int32_t *row0; const int32_t *nblk;
+  const float *w; const float *gc; const int32_t *row0; const int32_t *nblk; const int32_t *slot;
   const float *feats; const int64_t *frame_off;
   const int32_t *pdf_list; const int64_t *pdf_off; const int32_t *class_counts; const int64_t *ll_off;
   float *out;
@@ -50,7 +48,29 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
 // row index (within a 32-row MFMA block) held by accumulator register r of a lane in half h
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-template <int M8>
+// partner lane's value across the two 32-lane halves: one v_permlane32_swap instead of a round trip through the LDS
+// crossbar (ds_bpermute)
+__device__ __forceinline__ float swap32(float v, int h) {
+#if __has_builtin(__builtin_amdgcn_permlane32_swap)
+  unsigned u = __float_as_uint(v);
+  auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __uint_as_float(h ? r[0] : r[1]);
+#else
+  return __shfl_xor(v, 32);
+#endif
+}
+__device__ __forceinline__ double swap32_f64(double v, int h) {
+#if __has_builtin(__builtin_amdgcn_permlane32_swap)
+  unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double((int)(h ? b[0] : b[1]), (int)(h ? a[0] : a[1]));
+#else
+  return shfl_xor_f64(v, 32);
+#endif
+}
+
+template <int M8, int kNT>
 struct Tile {
   // One wavefront: B operands for kNT frame tiles, generic block evaluation.
   float b[kNT][4 * M8];
@@ -62,27 +82,47 @@ struct Tile {
       int t = t_base + 32 * n + col;
       t = t < T ? t : T - 1;
       const float *x = p.feats + (f0 + t) * p.dim;
+      // branch-free (independent loads, one round trip): clamp the index, then select x, x² or the zero pad
 #pragma unroll
       for (int s = 0; s < 4 * M8; s++) {
-        int k = 2 * s + h;
-        float v = 0.0f;
-        if (k < p.dim) v = x[k];
-        else if (k < 2 * p.dim) { float xv = x[k - p.dim]; v = xv * xv; }
-        b[n][s] = v;
+        const int k = 2 * s + h;
+        const int idx = k < p.dim ? k : (k < 2 * p.dim ? k - p.dim : 0);
+        const float xv = x[idx];
+        b[n][s] = k < p.dim ? xv : (k < 2 * p.dim ? xv * xv : 0.0f);
       }
     }
   }
 
   // acc[n] = gconst(rows) + W(block rows) · x̃(tile n).  arow: this lane's A row (already offset by 4h floats);
   // gcv: gconst of the row this lane (lane&31) addresses.
-  __device__ __forceinline__ void block(const float *arow, float gcv, int lane, f32x16 (&acc)[kNT]) const {
-    const int h = lane >> 5;
-    f32x4 a[M8];
+  __device__ __forceinline__ static void load_a(const float *arow, f32x4 (&a)[M8]) {
 #pragma unroll
     for (int m = 0; m < M8; m++) a[m] = *reinterpret_cast<const f32x4 *>(arow + 8 * m);
+  }
+  __device__ __forceinline__ void block(const float *arow, float gcv, int lane, f32x16 (&acc)[kNT]) const {
+    f32x4 a[M8];
+    load_a(arow, a);
+    run(a, gcv, lane, acc);
+  }
+  // gconst of the accumulator rows of a contiguous, 4-row-aligned 32-row block: four 16-byte loads (rows 8q+4h..+3)
+  __device__ __forceinline__ static void load_gc32(const float *gc_block, int h, f32x4 (&g)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) g[q] = *reinterpret_cast<const f32x4 *>(gc_block + 8 * q + 4 * h);
+  }
+  __device__ __forceinline__ void run32(const f32x4 (&a)[M8], const f32x4 (&g)[4], f32x16 (&acc)[kNT]) const {
+    f32x16 init;
+#pragma unroll
+    for (int r = 0; r < 16; r++) init[r] = g[r >> 2][r & 3];
+    mfma(a, init, acc);
+  }
+  __device__ __forceinline__ void run(const f32x4 (&a)[M8], float gcv, int lane, f32x16 (&acc)[kNT]) const {
+    const int h = lane >> 5;
     f32x16 init;
 #pragma unroll
     for (int r = 0; r < 16; r++) init[r] = __shfl(gcv, acc_row(r, h));
+    mfma(a, init, acc);
+  }
+  __device__ __forceinline__ void mfma(const f32x4 (&a)[M8], const f32x16 &init, f32x16 (&acc)[kNT]) const {
 #pragma unroll
     for (int n = 0; n < kNT; n++) acc[n] = init;
 #pragma unroll
@@ -125,10 +165,21 @@ __device__ __forceinline__ double reg_expsum(const f32x16 &v, float mx, float cu
   }
   return s;
 }
-__device__ __forceinline__ float finish(float mx, double sum) { return (float)((double)mx + log(sum)); }
+// LL = max + ln(sum).  sum ∈ [1, #Gaussians] is exact in float64; the logarithm is taken with the hardware log2
+// (1 ulp on a value ≤ 5–7, i.e. ≲4e-7 absolute — well inside half an ulp of a float32 log-likelihood of magnitude ≥ 16).
+__device__ __forceinline__ float finish(float mx, double sum) {
+  return fmaf(__builtin_amdgcn_logf((float)sum), 0.693147180559945309f, mx);
+}
+__device__ __forceinline__ float finish_exact(float mx, double sum) { return (float)((double)mx + log(sum)); }
 
-template <int M8>
-__global__ __launch_bounds__(256, 2) void gmm_kernel(GmmParams p) {
+template <int M8, int kNT, int kMinWaves, int kWaves>
+__global__ __launch_bounds__(64 * kWaves, kMinWaves) void gmm_kernel(GmmParams p) {
+  constexpr int kFramesPerWave = 32 * kNT;
+  // 512-thread workgroups put two wavefronts on every SIMD.  Left alone they fall into lockstep (both in their MFMA
+  // phase, then both in their log-sum-exp epilogue, matrix pipe idle).  A static priority for the second half lets that
+  // wavefront own the matrix pipe while the other fills the pipe during the first one's epilogue
+  // (cdna_hip_programming.md T5, static form).
+  if (kWaves == 8 && (threadIdx.x >> 8)) __builtin_amdgcn_s_setprio(2);
   const int utt = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t f0 = p.frame_off[utt];
@@ -142,25 +193,39 @@ __global__ __launch_bounds__(256, 2) void gmm_kernel(GmmParams p) {
   const int32_t *cc = p.class_counts + (size_t)utt * 5;
   float *out = p.out + p.ll_off[utt];
 
-  Tile<M8> tile;
+  Tile<M8, kNT> tile;
   tile.load_b(p, f0, T, t_base, lane);
   f32x16 acc[kNT];
 
-  // ---- slot 32 (one pdf per block; pdfs with more than 32 Gaussians take several blocks, two passes)
+  // ---- slot 32 (one pdf per block; pdfs with more than 32 Gaussians take several blocks, two passes).
+  // Software pipeline: the A rows of block j+1 are requested right after block j's last MFMA has been issued (its
+  // operand registers are dead by then), so their L2 latency hides under block j's log-sum-exp epilogue.
   const int n32 = cc[0];
+  f32x4 a_next[M8];
+  f32x4 gc_next[4];
+  int nb_next = 0, r0_next = 0;
+  auto request = [&](int jj) {
+    const int pdf = list[jj];
+    r0_next = p.row0[pdf];
+    nb_next = p.nblk[pdf];
+    if (nb_next == 1) {
+      Tile<M8, kNT>::load_a(p.w + (size_t)(r0_next + col) * p.kpad + 4 * h, a_next);
+      Tile<M8, kNT>::load_gc32(p.gc + r0_next, h, gc_next);
+    }
+  };
+  if (n32 > 0) request(0);
   for (int j = 0; j < n32; j++) {
-    const int pdf = list[j];
-    const int r0 = p.row0[pdf], nb = p.nblk[pdf];
+    const int r0 = r0_next, nb = nb_next;
     float mx[kNT]; double sum[kNT];
     if (nb == 1) {
-      const float *arow = p.w + (size_t)(r0 + col) * p.kpad + 4 * h;
-      tile.block(arow, p.gc[r0 + col], lane, acc);
+      tile.run32(a_next, gc_next, acc);
+      if (j + 1 < n32) request(j + 1);
 #pragma unroll
       for (int n = 0; n < kNT; n++) {
         float m = reg_max<0, 16>(acc[n]);
-        m = fmaxf(m, __shfl_xor(m, 32));
+        m = fmaxf(m, swap32(m, h));
         double s = reg_expsum<0, 16>(acc[n], m, m + p.min_log_diff);
-        s += shfl_xor_f64(s, 32);
+        s += swap32_f64(s, h);
         mx[n] = m; sum[n] = s;
       }
     } else {
@@ -186,14 +251,20 @@ __global__ __launch_bounds__(256, 2) void gmm_kernel(GmmParams p) {
           sum[n] += s;
         }
       }
+      if (j + 1 < n32) request(j + 1);
     }
-    // both halves hold every tile's (max, sum): half h finishes tile h, so each lane takes one log, not kNT
-    static_assert(kNT == 2, "the finish split assumes two frame tiles per wavefront");
-    {
+    // both halves hold every tile's (max, sum): with two tiles half h finishes tile h (one log per lane)
+    if constexpr (kNT == 2) {
       const float mxs = h ? mx[1] : mx[0];
       const double sums = h ? sum[1] : sum[0];
       const int t = t_base + 32 * h + col;
       if (t < T) out[(size_t)t * P + j] = finish(mxs, sums);
+    } else {
+#pragma unroll
+      for (int n = 0; n < kNT; n++) {
+        const int t = t_base + 32 * n + col;
+        if (h == (n & 1) && t < T) out[(size_t)t * P + j] = finish(mx[n], sum[n]);
+      }
     }
   }
 
@@ -299,7 +370,7 @@ __global__ void gmm_naive_kernel(GmmParams p) {
   const int t = (int)(idx / P), j = (int)(idx % P);
   const int pdf = p.pdf_list[l0 + j];
   const int r0 = p.row0[pdf];
-  const int rows = p.row0[pdf + 1] - r0;  // row0 has num_pdfs+1 entries; pad rows carry gconst -1e30
+  const int rows = p.slot[pdf] == 32 ? 32 * p.nblk[pdf] : p.slot[pdf];  // pad rows carry gconst -1e30
   const float *x = p.feats + (f0 + t) * p.dim;
   float mx = -INFINITY;
   double sum = 0.0;
@@ -333,16 +404,19 @@ MFA_API int mfa_load_gmm(mfa_ctx *c, int32_t dim, int32_t num_pdfs, const int32_
   // the MFMA kernel is instantiated for rows of exactly 80 or 96 floats; wider models use the naive kernel
   const int kpad = 2 * dim <= 80 ? 80 : (2 * dim <= 96 ? 96 : ((2 * dim + 7) / 8) * 8);
   std::vector<int32_t> row0(num_pdfs + 1), nblk(num_pdfs), slot(num_pdfs);
-  int rows = 0;
   for (int p = 0; p < num_pdfs; p++) {
     int g = h_pdf_offsets[p + 1] - h_pdf_offsets[p];
     if (g <= 0) return c->fail("mfa_load_gmm: pdf %d has no Gaussians", p);
-    int s = slot_of(g);
-    slot[p] = s;
-    nblk[p] = s == 32 ? (g + 31) / 32 : 1;
-    row0[p] = rows;
-    rows += s == 32 ? 32 * nblk[p] : s;
+    slot[p] = slot_of(g);
+    nblk[p] = slot[p] == 32 ? (g + 31) / 32 : 1;
   }
+  // rows are handed out class by class (32, 16, 8, 4, 1): every pdf then starts at a multiple of its slot size, so the
+  // gconst rows of a 32-row block can be fetched with aligned 16-byte loads
+  int rows = 0;
+  for (int cls : {32, 16, 8, 4, 1})
+    for (int p = 0; p < num_pdfs; p++)
+      if (slot[p] == cls) { row0[p] = rows; rows += cls == 32 ? 32 * nblk[p] : cls; }
+  rows = (rows + 3) & ~3;
   row0[num_pdfs] = rows;
   std::vector<float> w((size_t)(rows + 1) * kpad, 0.0f), gc(rows + 1, kPadGconst);
   for (int p = 0; p < num_pdfs; p++) {
@@ -406,7 +480,7 @@ MFA_API int mfa_gmm_score_batch(mfa_ctx *c, const float *d_feats, const int64_t 
   if (n_utt > 65535) return c->fail("at most 65535 utterances per scoring launch (got %d)", n_utt);
   GmmParams p;
   p.dim = c->dim; p.kpad = c->kpad; p.num_rows = c->num_rows;
-  p.w = c->d_w; p.gc = c->d_gc; p.row0 = c->d_row0; p.nblk = c->d_nblk;
+  p.w = c->d_w; p.gc = c->d_gc; p.row0 = c->d_row0; p.nblk = c->d_nblk; p.slot = c->d_slot;
   p.feats = d_feats; p.frame_off = d_frame_off; p.pdf_list = d_pdf_list; p.pdf_off = d_pdf_off;
   p.class_counts = d_class_counts; p.ll_off = d_ll_off; p.out = d_loglikes;
   p.min_log_diff = logf(1.1920928955078125e-07f);
@@ -419,9 +493,25 @@ MFA_API int mfa_gmm_score_batch(mfa_ctx *c, const float *d_feats, const int64_t 
     dim3 grid((unsigned)((per_utt + 255) / 256), n_utt);
     hipLaunchKernelGGL(gmm_naive_kernel, grid, dim3(256), 0, c->stream, p);
   } else {
-    dim3 grid((max_frames + kWaves * kFramesPerWave - 1) / (kWaves * kFramesPerWave), n_utt);
-    if (m8 <= 10) hipLaunchKernelGGL(gmm_kernel<10>, grid, dim3(256), 0, c->stream, p);
-    else hipLaunchKernelGGL(gmm_kernel<12>, grid, dim3(256), 0, c->stream, p);
+    // frame tiles per wavefront: 1 → more resident wavefronts (≤128 VGPRs, 4 per SIMD) to interleave MFMA and epilogue
+    // phases; 2 → half the model-row traffic.  MFA_GMM_NT overrides for experiments.
+    const char *nt_env = getenv("MFA_GMM_NT");
+    const int nt = nt_env ? atoi(nt_env) : 2;
+    const char *wg_env = getenv("MFA_GMM_WG");
+    const int wg = wg_env ? atoi(wg_env) : 512;
+    const int fpw = 32 * (nt == 2 ? 2 : 1);
+    const int waves_per_wg = (nt == 2 && wg == 512) ? 8 : 4;
+    dim3 grid((max_frames + waves_per_wg * fpw - 1) / (waves_per_wg * fpw), n_utt);
+    if (nt == 2 && wg == 512) {
+      if (m8 <= 10) hipLaunchKernelGGL((gmm_kernel<10, 2, 2, 8>), grid, dim3(512), 0, c->stream, p);
+      else hipLaunchKernelGGL((gmm_kernel<12, 2, 2, 8>), grid, dim3(512), 0, c->stream, p);
+    } else if (nt == 2) {
+      if (m8 <= 10) hipLaunchKernelGGL((gmm_kernel<10, 2, 2, 4>), grid, dim3(256), 0, c->stream, p);
+      else hipLaunchKernelGGL((gmm_kernel<12, 2, 2, 4>), grid, dim3(256), 0, c->stream, p);
+    } else {
+      if (m8 <= 10) hipLaunchKernelGGL((gmm_kernel<10, 1, 3, 4>), grid, dim3(256), 0, c->stream, p);
+      else hipLaunchKernelGGL((gmm_kernel<12, 1, 3, 4>), grid, dim3(256), 0, c->stream, p);
+    }
   }
   MFA_HIP_CHECK(c, hipGetLastError());
   return 0;

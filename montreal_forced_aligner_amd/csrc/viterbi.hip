@@ -81,46 +81,44 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int m) {
   lo = __shfl_xor(lo, m); hi = __shfl_xor(hi, m);
   return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double wave_min_f64(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmin(v, shfl_xor_f64(v, o));
+// ---- wavefront primitives on the DPP crossbar (row_shr / row_bcast / wave_shr are single VALU operand modifiers on
+// gfx950; the ds_bpermute-based __shfl costs an LDS round trip per step).  Inclusive scan: Kogge-Stone inside each row
+// of 16 lanes, then row_bcast:15 / row_bcast:31 carry the row totals; lane 63 ends up holding the reduction.
+template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF>
+__device__ __forceinline__ u32 dpp_u32(u32 old, u32 v) {
+  return (u32)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROW_MASK, BANK_MASK, false);
+}
+template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF>
+__device__ __forceinline__ double dpp_f64(double old, double v) {
+  int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, ROW_MASK, BANK_MASK, false);
+  int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, ROW_MASK, BANK_MASK, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ u32 incl_scan_sum(u32 v) {
+  v += dpp_u32<0x111>(0, v); v += dpp_u32<0x112>(0, v); v += dpp_u32<0x114>(0, v); v += dpp_u32<0x118>(0, v);
+  v += dpp_u32<0x142, 0xA>(0, v); v += dpp_u32<0x143, 0xC>(0, v);
   return v;
 }
-__device__ __forceinline__ u32 wave_min_u32(u32 v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = min(v, (u32)__shfl_xor((int)v, o));
+__device__ __forceinline__ u32 incl_scan_max(u32 v) {
+  v = max(v, dpp_u32<0x111>(0, v)); v = max(v, dpp_u32<0x112>(0, v)); v = max(v, dpp_u32<0x114>(0, v));
+  v = max(v, dpp_u32<0x118>(0, v)); v = max(v, dpp_u32<0x142, 0xA>(0, v)); v = max(v, dpp_u32<0x143, 0xC>(0, v));
   return v;
 }
-__device__ __forceinline__ u32 wave_sum_u32(u32 v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += (u32)__shfl_xor((int)v, o);
+__device__ __forceinline__ double incl_scan_min(double v) {
+  const double inf = INFINITY;
+  v = fmin(v, dpp_f64<0x111>(inf, v)); v = fmin(v, dpp_f64<0x112>(inf, v)); v = fmin(v, dpp_f64<0x114>(inf, v));
+  v = fmin(v, dpp_f64<0x118>(inf, v)); v = fmin(v, dpp_f64<0x142, 0xA>(inf, v)); v = fmin(v, dpp_f64<0x143, 0xC>(inf, v));
   return v;
 }
-__device__ __forceinline__ u32 wave_max_u32(u32 v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = max(v, (u32)__shfl_xor((int)v, o));
-  return v;
-}
-// exclusive prefix-min over lanes (lane 0 gets +inf)
-__device__ __forceinline__ double excl_prefix_min(double v, int lane) {
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    double t = shfl_up_f64(v, o);
-    if (lane >= o) v = fmin(v, t);
-  }
-  double e = shfl_up_f64(v, 1);
-  return lane == 0 ? INFINITY : e;
-}
-// exclusive prefix-sum over lanes
-__device__ __forceinline__ u32 excl_prefix_sum(u32 v, int lane) {
-  u32 inc = v;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    u32 t = (u32)__shfl_up((int)inc, o);
-    if (lane >= o) inc += t;
-  }
-  return inc - v;
-}
+__device__ __forceinline__ double wave_min_f64(double v) { return readlane_f64(incl_scan_min(v), 63); }
+__device__ __forceinline__ u32 wave_sum_u32(u32 v) { return (u32)__builtin_amdgcn_readlane((int)incl_scan_sum(v), 63); }
+__device__ __forceinline__ u32 wave_max_u32(u32 v) { return (u32)__builtin_amdgcn_readlane((int)incl_scan_max(v), 63); }
+// exclusive prefixes from an inclusive scan: shift the wavefront right by one lane (wave_shr:1), identity into lane 0
+__device__ __forceinline__ double shift_in_min(double incl) { return dpp_f64<0x138>((double)INFINITY, incl); }
 
 // Kaldi: ac_cost = -(scale * loglike) in float; new_weight = (double)arc.weight + tok.cost + ac_cost
 __device__ __forceinline__ double cand_cost(float w, double cost, float ll, float scale) {
@@ -204,8 +202,8 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
       double cst = i < n ? c_cost[i] : INFINITY;
       double m = wave_min_f64(cst);
       if (m < best) {  // uniform
-        u32 cand = (i < n && cst == m) ? (u32)i : kEmpty;
-        best_i = wave_min_u32(cand);
+        const u64 hit = __ballot(i < n && cst == m);
+        best_i = (u32)c0 + (u32)__ffsll((long long)hit) - 1u;  // first index holding the minimum
         best = m;
       }
     }
@@ -216,9 +214,8 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
       u32 kle = 0;
       for (int c0 = 0; c0 < n; c0 += 64) {
         int i = c0 + lane;
-        kle += (i < n && c_cost[i] <= beam_cut) ? 1u : 0u;
+        kle += (u32)__popcll(__ballot(i < n && c_cost[i] <= beam_cut));
       }
-      kle = wave_sum_u32(kle);
       if (kle > (u32)kMinActive) { wcut = beam_cut; abeam = p.beam; }
       else {
         // sorted[min_active] (> beam_cut) = the smallest cost that has at least min_active+1 costs ≤ it
@@ -262,9 +259,10 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
       if (act) { a0 = arc_off[st]; narc = arc_off[st + 1] - a0; }
       if (narc > kMaxArcsPerState) bad_degree = true;
       const int maxarc = (int)wave_max_u32((u32)narc);
-      const u32 cb = cand_base + excl_prefix_sum((u32)narc, lane);
+      const u32 narc_incl = incl_scan_sum((u32)narc);
+      const u32 cb = cand_base + narc_incl - (u32)narc;
       if (i < n) t_cbase[i] = cb;
-      cand_base += wave_sum_u32((u32)narc);
+      cand_base += (u32)__builtin_amdgcn_readlane((int)narc_incl, 63);
       // arcs → registers (independent loads, one round trip), then their scores (second round trip)
       float w[kArcCache]; int col[kArcCache]; u32 nx[kArcCache]; double nw[kArcCache]; u32 sl[kArcCache];
 #pragma unroll
@@ -281,9 +279,10 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
       }
       for (int k = kArcCache; k < maxarc; k++)
         if (k < narc) m = fmin(m, cand_cost(a_w[a0 + k], cst, llt[a_col[a0 + k]], p.scale));
-      if (single) run = best_i != kEmpty ? shfl_f64(m, (int)best_i) : INFINITY;  // best token is always expanded
-      double local = fmin(run, excl_prefix_min(m, lane));
-      run = fmin(run, wave_min_f64(m));
+      if (single) run = best_i != kEmpty ? readlane_f64(m, __builtin_amdgcn_readfirstlane((int)best_i)) : INFINITY;  // best token is always expanded
+      const double m_incl = incl_scan_min(m);
+      double local = fmin(run, shift_in_min(m_incl));
+      run = fmin(run, readlane_f64(m_incl, 63));
 
       // one candidate: find-or-create the destination's slot, lower its cost, remember the first creator
       auto create = [&](u32 d, double cnw, u32 cidx, bool created) -> u32 {
@@ -384,9 +383,9 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
       for (u32 o0 = 0; o0 < cand_base; o0 += 64) {
         u32 o = o0 + lane;
         u32 v = o < cand_base ? cntord[o] : 0u;
-        u32 ex = excl_prefix_sum(v, lane);
-        if (o < cand_base && v != 0) cntord[o] = carry + ex;  // only leader ordinals are ever non-zero (and reset below)
-        carry += wave_sum_u32(v);
+        const u32 inc = incl_scan_sum(v);
+        if (o < cand_base && v != 0) cntord[o] = carry + inc - v;  // only leader ordinals are ever non-zero (and reset below)
+        carry += (u32)__builtin_amdgcn_readlane((int)inc, 63);
       }
     }
     // ---------------- write the new list + back-pointers, reset the tables
@@ -438,8 +437,8 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
         }
         double m = wave_min_f64(tc);
         if (m < bestc) {
-          u32 cand = (i < n && tc == m) ? (u32)i : kEmpty;
-          bpos = wave_min_u32(cand);
+          const u64 hit = __ballot(i < n && tc == m);
+          bpos = (u32)c0 + (u32)__ffsll((long long)hit) - 1u;
           bestc = m;
         }
       }
