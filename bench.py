@@ -46,6 +46,8 @@ def parse_args():
     ap.add_argument("--max-tokens", type=int, default=256)
     ap.add_argument("--bp-tokens", type=int, default=128)
     ap.add_argument("--streams", type=int, default=1, help="split the batch over this many HIP streams (stage overlap)")
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo to rehearse "
+                                                           "several ranks on one GPU)")
     ap.add_argument("--verbose", action="store_true")
     return ap.parse_args()
 
@@ -98,9 +100,19 @@ def main():
     from montreal_forced_aligner_amd.engine import AlignmentEngine, Pipeline
     from tests import synth
 
+    n_dev = torch.cuda.device_count()
+    if n_dev == 0:
+        raise SystemExit("bench.py needs a GPU: the alignment engine has no CPU fallback")
+    if local_rank >= n_dev:
+        if args.dist_backend == "nccl":
+            raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {n_dev} GPU(s) visible")
+        local_rank %= n_dev  # rehearsal: several gloo ranks share one GPU
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.dist_backend)
     mono = args.workload == "mono"
     t_setup = time.time()
     eng = AlignmentEngine(local_rank)
@@ -239,7 +251,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ktimes = {}

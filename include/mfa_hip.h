@@ -103,13 +103,13 @@ MFA_API int mfa_load_gmm(mfa_ctx *ctx, int32_t dim, int32_t num_pdfs, const int3
 /* Slot class of a pdf in the packed model (rows it occupies in an MFMA block: 1, 4, 8, 16 or 32); the host must order
  * each utterance's pdf list by descending slot class (mfa_gmm_sort_pdf_list does it). */
 MFA_API int32_t mfa_gmm_slot(mfa_ctx *ctx, int32_t pdf);
-/* Sort h_pdfs[n] in place into the order the scoring kernel requires; h_class_counts[5] receives how many pdfs fall in
- * slot classes 32,16,8,4,1. */
+/* Sort h_pdfs[n] in place into the order the scoring kernels require; h_class_counts[6] receives how many pdfs fall in
+ * the classes {32 rows single block, 32 rows multi-block (>32 Gaussians), 16, 8, 4, 1}. */
 MFA_API int mfa_gmm_sort_pdf_list(mfa_ctx *ctx, int32_t *h_pdfs, int32_t n, int32_t *h_class_counts);
 
 /* ---- Acoustic scoring: replaces DecodableAmDiagGmmScaled::LogLikelihood inside GmmAligner.align_utterance and
  *      gmm_compute_likes (MFA/alignment/multiprocessing.py:846-853, :1415).
- * Per utterance u: pdf list d_pdf_list[pdf_off[u]..pdf_off[u+1]) (sorted as above) with d_class_counts[u][5];
+ * Per utterance u: pdf list d_pdf_list[pdf_off[u]..pdf_off[u+1]) (sorted as above) with d_class_counts[u][6];
  * output d_loglikes + ll_off[u]: float32 [T_u][P_u] row-major (UNSCALED log-likelihoods). */
 MFA_API int mfa_gmm_score_batch(mfa_ctx *ctx, const float *d_feats, const int64_t *d_frame_off, int32_t n_utt,
                                 int32_t max_frames, const int32_t *d_pdf_list, const int64_t *d_pdf_off,

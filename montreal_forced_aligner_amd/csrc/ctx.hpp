@@ -46,7 +46,7 @@ struct mfa_ctx {
   int32_t *d_row0 = nullptr;   // [num_pdfs] first packed row
   int32_t *d_nblk = nullptr;   // [num_pdfs] number of 32-row blocks (slot 32) else 1
   int32_t *d_slot = nullptr;   // [num_pdfs] slot class rows (1,4,8,16,32)
-  std::vector<int32_t> h_slot;
+  std::vector<int32_t> h_slot, h_nblk;
 
   // Viterbi workspace
   void *d_ws = nullptr;

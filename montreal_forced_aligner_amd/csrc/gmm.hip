@@ -37,6 +37,7 @@ struct GmmParams {
   const int32_t *pdf_list; const int64_t *pdf_off; const int32_t *class_counts; const int64_t *ll_off;
   float *out;
   float min_log_diff;  // logf(FLT_EPSILON), computed on the host so device and oracle use the same constant
+  int skip_single;     // >0: that many leading single-block 32-row pdfs are handled by gmm_sp_kernel
 };
 
 __device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
@@ -190,7 +191,12 @@ __global__ __launch_bounds__(64 * kWaves, kMinWaves) void gmm_kernel(GmmParams p
   const int64_t l0 = p.pdf_off[utt];
   const int P = (int)(p.pdf_off[utt + 1] - l0);
   const int32_t *list = p.pdf_list + l0;
-  const int32_t *cc = p.class_counts + (size_t)utt * 5;
+  const int32_t *cc6 = p.class_counts + (size_t)utt * 6;
+  // class_counts[u] = {32-row single-block, 32-row multi-block, 16, 8, 4, 1}; with p.skip_single the single-block pdfs
+  // are scored by gmm_sp_kernel and this kernel starts after them
+  const int first32 = p.skip_single ? min(cc6[0], p.skip_single) : 0;
+  const int32_t cc[5] = {cc6[0] + cc6[1], cc6[2], cc6[3], cc6[4], cc6[5]};
+  if (first32 == cc[0] && cc[1] + cc[2] + cc[3] + cc[4] == 0) return;  // nothing left for this kernel
   float *out = p.out + p.ll_off[utt];
 
   Tile<M8, kNT> tile;
@@ -213,8 +219,8 @@ __global__ __launch_bounds__(64 * kWaves, kMinWaves) void gmm_kernel(GmmParams p
       Tile<M8, kNT>::load_gc32(p.gc + r0_next, h, gc_next);
     }
   };
-  if (n32 > 0) request(0);
-  for (int j = 0; j < n32; j++) {
+  if (n32 > first32) request(first32);
+  for (int j = first32; j < n32; j++) {
     const int r0 = r0_next, nb = nb_next;
     float mx[kNT]; double sum[kNT];
     if (nb == 1) {
@@ -357,6 +363,98 @@ __global__ __launch_bounds__(64 * kWaves, kMinWaves) void gmm_kernel(GmmParams p
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Software-pipelined scoring of the single-block 32-row pdfs (the bulk of a context-dependent model).
+// One wavefront per SIMD (whole 512-register file): it owns 4 frame tiles (128 frames, x̃ in 160 VGPRs) and two
+// accumulator sets.  While the matrix pipe works through block j's 160 MFMAs, the same wavefront's VALU stream runs the
+// log-sum-exp epilogue of block j-1 from the other accumulator set, and block j+1's model rows are already in flight —
+// the pipe never waits for an epilogue phase (two co-resident wavefronts running [MFMA phase | epilogue phase] fall
+// into lockstep and leave it idle ≈40 % of the time).
+constexpr int kSpMaxBlocks = 2048;
+template <int M8>
+__global__ __launch_bounds__(256, 1) void gmm_sp_kernel(GmmParams p) {
+  constexpr int NT = 4;
+  const int utt = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t f0 = p.frame_off[utt];
+  const int T = (int)(p.frame_off[utt + 1] - f0);
+  const int t_base = (blockIdx.x * 4 + wave) * (32 * NT);
+  const int32_t *cc = p.class_counts + (size_t)utt * 6;
+  const int n1 = min(cc[0], kSpMaxBlocks);  // the generic kernel takes whatever exceeds the row cache
+  const int64_t l0 = p.pdf_off[utt];
+  const int P = (int)(p.pdf_off[utt + 1] - l0);
+  const int32_t *list = p.pdf_list + l0;
+  // first packed row of every block, staged in LDS once per workgroup: the per-block lookups then ride on lgkmcnt and
+  // never serialise with the model-row prefetch on vmcnt
+  __shared__ int rows_lds[kSpMaxBlocks];
+  for (int i = threadIdx.x; i < n1; i += blockDim.x) rows_lds[i] = p.row0[list[i]];
+  __syncthreads();
+  if (t_base >= T || n1 == 0) return;
+  const int col = lane & 31, h = lane >> 5;
+  float *out = p.out + p.ll_off[utt];
+
+  Tile<M8, NT> tile;
+  tile.load_b(p, f0, T, t_base, lane);
+
+  f32x4 aA[M8], aB[M8], gA[4], gB[4];
+  f32x16 accA[NT], accB[NT];
+  // first packed row of block jj; fetched two blocks ahead of its use (two dependent loads that must not stall the pipe)
+  auto row_of = [&](int jj) { return jj < n1 ? rows_lds[jj] : 0; };
+  auto request = [&](int r0, f32x4 (&a)[M8], f32x4 (&g)[4]) {
+    r0 = __builtin_amdgcn_readfirstlane(r0);
+    Tile<M8, NT>::load_a(p.w + (size_t)(r0 + col) * p.kpad + 4 * h, a);
+    Tile<M8, NT>::load_gc32(p.gc + r0, h, g);
+  };
+  auto epilogue = [&](const f32x16 (&acc)[NT], int j) {
+    float mx[NT]; double sum[NT];
+#pragma unroll
+    for (int n = 0; n < NT; n++) {
+      float m = reg_max<0, 16>(acc[n]);
+      m = fmaxf(m, swap32(m, h));
+      double s = reg_expsum<0, 16>(acc[n], m, m + p.min_log_diff);
+      s += swap32_f64(s, h);
+      mx[n] = m; sum[n] = s;
+    }
+    // half h finishes tiles 2i+h
+#pragma unroll
+    for (int i = 0; i < NT / 2; i++) {
+      const float mxs = h ? mx[2 * i + 1] : mx[2 * i];
+      const double sums = h ? sum[2 * i + 1] : sum[2 * i];
+      const int t = t_base + 32 * (2 * i + h) + col;
+      if (t < T) out[(size_t)t * P + j] = finish(mxs, sums);
+    }
+  };
+
+  // Operand sets are requested one whole block (160 MFMAs) before their first use; the sched_barrier keeps the compiler
+  // from sinking the loads down to that use.
+  request(row_of(0), aA, gA);
+  if (n1 > 1) request(row_of(1), aB, gB);
+  int r_next = row_of(2);   // row of block j+1 at the top of each half-trip below
+  __builtin_amdgcn_sched_barrier(0);
+  tile.run32(aA, gA, accA);  // block 0
+  int j = 1;
+  // two blocks per trip so the accumulator/operand sets alternate by name (no register copies)
+  for (; j + 1 < n1; j += 2) {
+    request(r_next, aA, gA);    // block j+1, for the second half of this trip (aA is free: block j-1's MFMAs are issued)
+    r_next = row_of(j + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    tile.run32(aB, gB, accB);   // block j      → accB   ┐ independent MFMA and VALU streams:
+    epilogue(accA, j - 1);      // block j-1 from accA   ┘ the scheduler interleaves them
+    if (j + 2 < n1) request(r_next, aB, gB);
+    r_next = row_of(j + 3);
+    __builtin_amdgcn_sched_barrier(0);
+    tile.run32(aA, gA, accA);   // block j+1    → accA
+    epilogue(accB, j);
+  }
+  if (j < n1) {
+    tile.run32(aB, gB, accB);
+    epilogue(accA, j - 1);
+    epilogue(accB, j);
+  } else {
+    epilogue(accA, j - 1);
+  }
+}
+
 // Straightforward one-thread-per-(frame,pdf) kernel: used for feature dims the MFMA kernel is not instantiated for and,
 // with MFA_GMM_NAIVE=1, as an on-device cross-check of the MFMA path.  Same fmaf chain, same log-sum-exp.
 __global__ void gmm_naive_kernel(GmmParams p) {
@@ -447,6 +545,7 @@ MFA_API int mfa_load_gmm(mfa_ctx *c, int32_t dim, int32_t num_pdfs, const int32_
   MFA_HIP_CHECK(c, hipMemcpy(c->d_slot, slot.data(), slot.size() * 4, hipMemcpyHostToDevice));
   c->dim = dim; c->kpad = kpad; c->num_pdfs = num_pdfs; c->num_rows = rows;
   c->h_slot = slot;
+  c->h_nblk = nblk;
   c->gmm_ready = true;
   return 0;
 }
@@ -458,14 +557,15 @@ MFA_API int32_t mfa_gmm_slot(mfa_ctx *c, int32_t pdf) {
 
 MFA_API int mfa_gmm_sort_pdf_list(mfa_ctx *c, int32_t *h_pdfs, int32_t n, int32_t *h_class_counts) {
   if (!c->gmm_ready) return c->fail("mfa_load_gmm has not been called");
-  std::vector<int32_t> bucket[5];
+  std::vector<int32_t> bucket[6];
   for (int i = 0; i < n; i++) {
     int p = h_pdfs[i];
     if (p < 0 || p >= c->num_pdfs) return c->fail("pdf id %d out of range [0,%d)", p, c->num_pdfs);
-    bucket[class_index(c->h_slot[p])].push_back(p);
+    int ci = class_index(c->h_slot[p]);
+    bucket[ci == 0 ? (c->h_nblk[p] == 1 ? 0 : 1) : ci + 1].push_back(p);
   }
   int k = 0;
-  for (int b = 0; b < 5; b++) {
+  for (int b = 0; b < 6; b++) {
     h_class_counts[b] = (int32_t)bucket[b].size();
     for (int p : bucket[b]) h_pdfs[k++] = p;
   }
@@ -484,6 +584,7 @@ MFA_API int mfa_gmm_score_batch(mfa_ctx *c, const float *d_feats, const int64_t 
   p.feats = d_feats; p.frame_off = d_frame_off; p.pdf_list = d_pdf_list; p.pdf_off = d_pdf_off;
   p.class_counts = d_class_counts; p.ll_off = d_ll_off; p.out = d_loglikes;
   p.min_log_diff = logf(1.1920928955078125e-07f);
+  p.skip_single = 0;
   const char *naive = getenv("MFA_GMM_NAIVE");
   const int m8 = c->kpad / 8;
   KernelTimer kt(c, MFA_K_GMM);
@@ -497,8 +598,18 @@ MFA_API int mfa_gmm_score_batch(mfa_ctx *c, const float *d_feats, const int64_t 
     // phases; 2 → half the model-row traffic.  MFA_GMM_NT overrides for experiments.
     const char *nt_env = getenv("MFA_GMM_NT");
     const int nt = nt_env ? atoi(nt_env) : 2;
+    // single-block 32-row pdfs can go through the software-pipelined one-wavefront-per-SIMD kernel (MFA_GMM_SP=1).
+    // Measured on MI355X (round 1): 88.6 TFLOP/s vs 94.8 for the generic two-wavefront kernel, so it is off by default.
+    const char *sp_env = getenv("MFA_GMM_SP");
+    const bool use_sp = sp_env && sp_env[0] == '1';
+    p.skip_single = use_sp ? kSpMaxBlocks : 0;
+    if (use_sp) {
+      dim3 gsp((max_frames + 511) / 512, n_utt);
+      if (m8 <= 10) hipLaunchKernelGGL((gmm_sp_kernel<10>), gsp, dim3(256), 0, c->stream, p);
+      else hipLaunchKernelGGL((gmm_sp_kernel<12>), gsp, dim3(256), 0, c->stream, p);
+    }
     const char *wg_env = getenv("MFA_GMM_WG");
-    const int wg = wg_env ? atoi(wg_env) : 512;
+    const int wg = wg_env ? atoi(wg_env) : 256;
     const int fpw = 32 * (nt == 2 ? 2 : 1);
     const int waves_per_wg = (nt == 2 && wg == 512) ? 8 : 4;
     dim3 grid((max_frames + waves_per_wg * fpw - 1) / (waves_per_wg * fpw), n_utt);

@@ -41,7 +41,7 @@ class PackedGraphs:
     tensors: Dict[str, torch.Tensor]
     pdf_list: torch.Tensor      # int32 [ΣP_u] (slot-sorted per utterance)
     pdf_off: torch.Tensor       # int64 [n_utt+1]
-    class_counts: torch.Tensor  # int32 [n_utt,5]
+    class_counts: torch.Tensor  # int32 [n_utt,6]
     pdf_off_host: np.ndarray
     pdf_lists_host: List[np.ndarray]
 
@@ -108,9 +108,12 @@ class AlignmentEngine:
                                               mi.ctypes.data, iv.ctypes.data), "mfa_load_gmm")
         self.gmm = gmm
         slots = np.array([self.lib.mfa_gmm_slot(self.ctx, p) for p in range(gmm.num_pdfs)], dtype=np.int32)
-        cls = np.full(gmm.num_pdfs, 4, dtype=np.int32)
+        n_gauss = np.diff(gmm.pdf_offsets)
+        # classes in kernel order: 32 rows single block, 32 rows multi-block (> 32 Gaussians), 16, 8, 4, 1
+        cls = np.full(gmm.num_pdfs, 5, dtype=np.int32)
         for i, s in enumerate((32, 16, 8, 4, 1)):
-            cls[slots == s] = i
+            cls[slots == s] = i + 1
+        cls[(slots == 32) & (n_gauss <= 32)] = 0
         self.slot_class = cls
 
     def num_frames(self, num_samples: int) -> int:
@@ -176,11 +179,11 @@ class AlignmentEngine:
         return out
 
     def sort_pdf_list(self, pdfs: np.ndarray):
-        """Order a pdf list by slot class (32,16,8,4,1) as the scoring kernel requires; returns (sorted, counts[5])."""
+        """Order a pdf list by slot class as the scoring kernels require; returns (sorted, counts[6])."""
         pdfs = np.asarray(pdfs, dtype=np.int32)
         cls = self.slot_class[pdfs]
         order = np.argsort(cls, kind="stable")
-        return pdfs[order], np.bincount(cls, minlength=5).astype(np.int32)
+        return pdfs[order], np.bincount(cls, minlength=6).astype(np.int32)
 
     def score(self, feats: torch.Tensor, frame_off: np.ndarray, pdf_list: torch.Tensor, pdf_off_host: np.ndarray,
               class_counts: torch.Tensor):

@@ -749,3 +749,144 @@ ORC_API int32_t orc_split_to_phones(const int32_t *ali, int32_t T, const int32_t
 }
 
 ORC_API int32_t orc_version() { return 1; }
+
+// ---------------------------------------------------------------------------
+// N3  fMLLR estimation — reference: CalcFmllrFunction (MFA/corpus/features.py:460-548; options :759-766: update type
+// "full", silence weight 0) between the two alignment passes (MFA/alignment/base.py:510-539).  Restates Kaldi
+// transform/fmllr-diag-gmm.cc: FmllrDiagGmmAccs::AccumulateForGmm / AccumulateFromPosteriors / CommitSingleFrameStats
+// and ComputeFmllrMatrixDiagGmmFull + FmllrInnerUpdate + FmllrAuxFuncDiagGmm (min_count 500, num_iters 40).
+// Statistics: beta (count), K [D][D+1], G [D][(D+1)x(D+1)] (full symmetric storage here), all double.
+// ---------------------------------------------------------------------------
+// One utterance: frame t is aligned to pdf ali_pdf[t] with weight w[t] (0 for silence frames when silence_weight = 0).
+ORC_API void orc_fmllr_acc(const float *feats, int32_t T, int32_t D, const int32_t *ali_pdf, const float *weight,
+                           const float *gconsts, const float *means_invvars, const float *inv_vars,
+                           const int32_t *pdf_offsets, double *beta, double *K /*[D][D+1]*/, double *G /*[D][D+1][D+1]*/) {
+  const int D1 = D + 1;
+  std::vector<float> x2(D), ll, a(D), b(D);
+  std::vector<double> xplus(D1);
+  for (int t = 0; t < T; t++) {
+    if (weight[t] == 0.0f) continue;
+    const float *x = feats + (size_t)t * D;
+    for (int d = 0; d < D; d++) x2[d] = x[d] * x[d];
+    int p = ali_pdf[t], g0 = pdf_offsets[p], g1 = pdf_offsets[p + 1], n = g1 - g0;
+    ll.resize(n);
+    for (int g = 0; g < n; g++)
+      ll[g] = gauss_ll(x, x2.data(), D, gconsts[g0 + g], means_invvars + (size_t)(g0 + g) * D, inv_vars + (size_t)(g0 + g) * D);
+    // ComponentPosteriors: ApplySoftMax in float, then scale by the frame weight
+    float mx = ll[0];
+    for (int g = 1; g < n; g++) mx = std::max(mx, ll[g]);
+    float sum = 0.0f;
+    for (int g = 0; g < n; g++) { ll[g] = expf(ll[g] - mx); sum += ll[g]; }
+    float inv = 1.0f / sum;
+    float count = 0.0f;
+    for (int d = 0; d < D; d++) { a[d] = 0.0f; b[d] = 0.0f; }
+    for (int g = 0; g < n; g++) {
+      float post = ll[g] * inv * weight[t];
+      count += post;
+      const float *mi = means_invvars + (size_t)(g0 + g) * D, *iv = inv_vars + (size_t)(g0 + g) * D;
+      for (int d = 0; d < D; d++) { a[d] = fmaf(mi[d], post, a[d]); b[d] = fmaf(iv[d], post, b[d]); }
+    }
+    if (count == 0.0f) continue;
+    for (int d = 0; d < D; d++) xplus[d] = x[d];
+    xplus[D] = 1.0;
+    *beta += count;
+    for (int d = 0; d < D; d++)
+      for (int e = 0; e < D1; e++) K[(size_t)d * D1 + e] += (double)a[d] * xplus[e];
+    for (int d = 0; d < D; d++) {
+      double bd = b[d];
+      double *Gd = G + (size_t)d * D1 * D1;
+      for (int e = 0; e < D1; e++)
+        for (int f = 0; f < D1; f++) Gd[(size_t)e * D1 + f] += bd * xplus[e] * xplus[f];
+    }
+  }
+}
+
+static bool invert_spd(std::vector<double> &m, int n) {  // Gauss-Jordan with partial pivoting, in place
+  std::vector<double> inv((size_t)n * n, 0.0);
+  for (int i = 0; i < n; i++) inv[(size_t)i * n + i] = 1.0;
+  for (int c = 0; c < n; c++) {
+    int piv = c;
+    for (int r = c + 1; r < n; r++) if (std::fabs(m[(size_t)r * n + c]) > std::fabs(m[(size_t)piv * n + c])) piv = r;
+    if (m[(size_t)piv * n + c] == 0.0) return false;
+    if (piv != c) for (int k = 0; k < n; k++) { std::swap(m[(size_t)c * n + k], m[(size_t)piv * n + k]); std::swap(inv[(size_t)c * n + k], inv[(size_t)piv * n + k]); }
+    double d = 1.0 / m[(size_t)c * n + c];
+    for (int k = 0; k < n; k++) { m[(size_t)c * n + k] *= d; inv[(size_t)c * n + k] *= d; }
+    for (int r = 0; r < n; r++) if (r != c) {
+      double f = m[(size_t)r * n + c];
+      if (f != 0.0) for (int k = 0; k < n; k++) { m[(size_t)r * n + k] -= f * m[(size_t)c * n + k]; inv[(size_t)r * n + k] -= f * inv[(size_t)c * n + k]; }
+    }
+  }
+  m = inv;
+  return true;
+}
+
+static double fmllr_auxf(const std::vector<double> &W, int D, double beta, const double *K, const double *G) {
+  const int D1 = D + 1;
+  std::vector<double> A((size_t)D * D);
+  for (int i = 0; i < D; i++) for (int j = 0; j < D; j++) A[(size_t)i * D + j] = W[(size_t)i * D1 + j];
+  // log |det A| by elimination
+  double logdet = 0.0;
+  for (int c = 0; c < D; c++) {
+    int piv = c;
+    for (int r = c + 1; r < D; r++) if (std::fabs(A[(size_t)r * D + c]) > std::fabs(A[(size_t)piv * D + c])) piv = r;
+    if (piv != c) for (int k = 0; k < D; k++) std::swap(A[(size_t)c * D + k], A[(size_t)piv * D + k]);
+    double p = A[(size_t)c * D + c];
+    logdet += std::log(std::fabs(p));
+    for (int r = c + 1; r < D; r++) { double f = A[(size_t)r * D + c] / p; for (int k = c; k < D; k++) A[(size_t)r * D + k] -= f * A[(size_t)c * D + k]; }
+  }
+  double obj = beta * logdet;
+  for (int i = 0; i < D; i++) for (int e = 0; e < D1; e++) obj += W[(size_t)i * D1 + e] * K[(size_t)i * D1 + e];
+  for (int d = 0; d < D; d++) {
+    const double *Gd = G + (size_t)d * D1 * D1;
+    double q = 0.0;
+    for (int e = 0; e < D1; e++) { double r = 0.0; for (int f = 0; f < D1; f++) r += Gd[(size_t)e * D1 + f] * W[(size_t)d * D1 + f]; q += r * W[(size_t)d * D1 + e]; }
+    obj -= 0.5 * q;
+  }
+  return obj;
+}
+
+// Returns the auxiliary-function improvement (0 and identity transform when beta < min_count or no improvement).
+ORC_API double orc_fmllr_solve(int32_t D, double beta, const double *K, const double *G, int32_t num_iters, double min_count,
+                               float *out /*[D][D+1]*/) {
+  const int D1 = D + 1;
+  std::vector<double> W((size_t)D * D1, 0.0);
+  for (int i = 0; i < D; i++) W[(size_t)i * D1 + i] = 1.0;
+  auto store = [&](const std::vector<double> &M) { for (size_t i = 0; i < M.size(); i++) out[i] = (float)M[i]; };
+  store(W);
+  if (beta < min_count) return 0.0;
+  std::vector<std::vector<double> > invG(D);
+  for (int d = 0; d < D; d++) {
+    invG[d].assign(G + (size_t)d * D1 * D1, G + (size_t)(d + 1) * D1 * D1);
+    if (!invert_spd(invG[d], D1)) return 0.0;
+  }
+  std::vector<double> Wn(W);
+  double old_obj = fmllr_auxf(W, D, beta, K, G);
+  std::vector<double> At((size_t)D * D), cof(D1), cg(D1);
+  for (int it = 0; it < num_iters; it++) {
+    for (int row = 0; row < D; row++) {
+      // cofactor row = row of inverse(A^T)
+      for (int i = 0; i < D; i++) for (int j = 0; j < D; j++) At[(size_t)i * D + j] = Wn[(size_t)j * D1 + i];
+      std::vector<double> inv(At);
+      if (!invert_spd(inv, D)) return 0.0;
+      for (int j = 0; j < D; j++) cof[j] = inv[(size_t)row * D + j];
+      cof[D] = 0.0;
+      const std::vector<double> &iG = invG[row];
+      const double *k = K + (size_t)row * D1;
+      for (int e = 0; e < D1; e++) { double r = 0.0; for (int f = 0; f < D1; f++) r += iG[(size_t)e * D1 + f] * cof[f]; cg[e] = r; }
+      double e1 = 0.0, e2 = 0.0;
+      for (int e = 0; e < D1; e++) { e1 += cg[e] * cof[e]; e2 += cg[e] * k[e]; }
+      double discr = std::sqrt(e2 * e2 + 4 * e1 * beta);
+      double alpha1 = (-e2 + discr) / (2 * e1), alpha2 = (-e2 - discr) / (2 * e1);
+      double auxf1 = beta * std::log(std::fabs(alpha1 * e1 + e2)) - 0.5 * alpha1 * alpha1 * e1;
+      double auxf2 = beta * std::log(std::fabs(alpha2 * e1 + e2)) - 0.5 * alpha2 * alpha2 * e1;
+      double alpha = auxf1 > auxf2 ? alpha1 : alpha2;
+      for (int e = 0; e < D1; e++) cof[e] = alpha * cof[e] + k[e];
+      for (int e = 0; e < D1; e++) { double r = 0.0; for (int f = 0; f < D1; f++) r += iG[(size_t)e * D1 + f] * cof[f]; Wn[(size_t)row * D1 + e] = r; }
+    }
+  }
+  double new_obj = fmllr_auxf(Wn, D, beta, K, G);
+  double impr = new_obj - old_obj;
+  if (impr < 0.0 && !(std::fabs(new_obj - old_obj) <= 0.001 * (std::fabs(new_obj) + std::fabs(old_obj)))) return 0.0;
+  store(Wn);
+  return impr;
+}

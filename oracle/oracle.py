@@ -221,3 +221,26 @@ def split_to_phones(ali, id2state, is_self_loop, is_final, tuples):
                                   _p(np.ascontiguousarray(is_self_loop, np.int32)), _p(np.ascontiguousarray(is_final, np.int32)),
                                   _p(np.ascontiguousarray(tuples, np.int32)), _p(out), C.c_int32(T + 1), C.byref(ok))
     return out[:n].copy(), bool(ok.value)
+
+
+def fmllr_acc(feats, ali_pdf, weight, gconsts, means_invvars, inv_vars, pdf_offsets, stats=None):
+    """Accumulate fMLLR statistics of one utterance; stats = (beta[1], K[D,D+1], G[D,D+1,D+1]) float64, created if None."""
+    feats = np.ascontiguousarray(feats, np.float32)
+    T, D = feats.shape
+    if stats is None:
+        stats = (np.zeros(1), np.zeros((D, D + 1)), np.zeros((D, D + 1, D + 1)))
+    beta, K, G = stats
+    lib().orc_fmllr_acc(_p(feats), C.c_int32(T), C.c_int32(D), _p(np.ascontiguousarray(ali_pdf, np.int32)),
+                        _p(np.ascontiguousarray(weight, np.float32)), _p(np.ascontiguousarray(gconsts, np.float32)),
+                        _p(np.ascontiguousarray(means_invvars, np.float32)), _p(np.ascontiguousarray(inv_vars, np.float32)),
+                        _p(np.ascontiguousarray(pdf_offsets, np.int32)), _p(beta), _p(K), _p(G))
+    return stats
+
+
+def fmllr_solve(beta, K, G, num_iters=40, min_count=500.0):
+    D = K.shape[0]
+    out = np.zeros((D, D + 1), np.float32)
+    lib().orc_fmllr_solve.restype = C.c_double
+    impr = lib().orc_fmllr_solve(C.c_int32(D), C.c_double(float(beta)), _p(np.ascontiguousarray(K, np.float64)),
+                                 _p(np.ascontiguousarray(G, np.float64)), C.c_int32(num_iters), C.c_double(min_count), _p(out))
+    return out, float(impr)
