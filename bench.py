@@ -358,7 +358,7 @@ def tile_graphs(eng, packed_pool, fsts, idx):
     lists = [packed_pool.pdf_lists_host[i] for i in idx]
     pdf_off = np.concatenate([[0], np.cumsum([len(p) for p in lists])]).astype(np.int64)
     cc = packed_pool.class_counts.cpu().numpy()[idx]
-    return PackedGraphs(n, int(S.max()), int(A.max()), tensors, eng._dev(np.concatenate(lists).astype(np.int32)),
+    return PackedGraphs(n, int(S.max()), int(A.max()), int(A.sum()), tensors, eng._dev(np.concatenate(lists).astype(np.int32)),
                         eng._dev(pdf_off), eng._dev(cc.astype(np.int32)), pdf_off, lists)
 
 

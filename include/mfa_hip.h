@@ -151,14 +151,26 @@ typedef struct {
  *   d_n_words[u] valid entries, d_like[u] = -(graph+acoustic cost)/acoustic_scale, d_frame_like [total_frames] or NULL,
  *   d_status[u]: 0 ok, 1 ok after retry, 2 no final token (failed), 3 token-capacity overflow, 4 back-pointer overflow,
  *                5 unsupported graph (a state with more than 64 arcs), 6 internal consistency check failed.
- * total_frames = frame_off[n_utt] (host copy, so the call never synchronises); max_states / max_arcs = largest S_u / A_u
+ * total_frames = frame_off[n_utt], total_arcs = arc_base[n_utt] (host copies, so the call never synchronises); max_states / max_arcs = largest S_u / A_u
  * in the batch (they bound the token and candidate tables). */
 MFA_API int mfa_align_batch(mfa_ctx *ctx, const mfa_graph_batch *graphs, const float *d_loglikes, const int64_t *d_ll_off,
                             const int32_t *d_ll_cols, const int64_t *d_frame_off, int64_t total_frames,
-                            int32_t max_states, int32_t max_arcs, const mfa_align_opts *opts, int32_t *d_ali, int32_t *d_words, int32_t *d_n_words,
+                            int64_t total_arcs, int32_t max_states, int32_t max_arcs, const mfa_align_opts *opts, int32_t *d_ali, int32_t *d_words, int32_t *d_n_words,
                             float *d_like, float *d_frame_like, int32_t *d_status);
 /* Bytes of device workspace mfa_align_batch will hold for a batch shape (so callers can budget HBM). */
 MFA_API size_t mfa_align_workspace_bytes(mfa_ctx *ctx, int32_t n_utt, int64_t total_frames, const mfa_align_opts *opts);
+
+/* ---- fMLLR statistics: replaces the accumulation of CalcFmllrFunction / kalpy FmllrComputer
+ *      (MFA/corpus/features.py:506-527; Kaldi FmllrDiagGmmAccs) between the two alignment passes
+ *      (MFA/alignment/base.py:510-539).  d_feats [total_frames][dim]: the features the transform will be applied to;
+ * d_ali_pdf [total_frames]: pdf-id of the first-pass alignment per frame (<0 = skip); d_weight [total_frames]: frame
+ * weights (0 for silence frames: silence_weight 0.0, MFA/corpus/features.py:759-766).  Outputs per speaker, float64,
+ * deterministic: d_beta[n_spk], d_K[n_spk][dim][dim+1], d_G[n_spk][dim][dim+1][dim+1].  The per-speaker solve
+ * (Kaldi ComputeFmllrMatrixDiagGmmFull) is host-side: montreal_forced_aligner_amd/fmllr.py. */
+MFA_API int mfa_fmllr_acc_batch(mfa_ctx *ctx, const float *d_feats, const int64_t *d_frame_off, int32_t n_utt,
+                                int64_t total_frames, const int32_t *d_ali_pdf, const float *d_weight,
+                                const int32_t *d_spk_utt_off, const int32_t *d_spk_utt, int32_t n_spk, double *d_beta,
+                                double *d_K, double *d_G);
 
 #ifdef __cplusplus
 }

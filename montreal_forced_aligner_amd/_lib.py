@@ -12,7 +12,7 @@ from pathlib import Path
 
 _PKG = Path(__file__).resolve().parent
 _SO = _PKG / "libmfa_hip.so"
-_SOURCES = ["api.hip", "mfcc.hip", "feats.hip", "gmm.hip", "viterbi.hip"]
+_SOURCES = ["api.hip", "mfcc.hip", "feats.hip", "gmm.hip", "viterbi.hip", "fmllr.hip"]
 _LIB = None
 
 
@@ -89,8 +89,9 @@ SIGNATURES = {
     "mfa_gmm_slot": (_i32, [_vp, _i32]),
     "mfa_gmm_sort_pdf_list": (C.c_int, [_vp, _vp, _i32, _vp]),
     "mfa_gmm_score_batch": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
-    "mfa_align_batch": (C.c_int, [_vp, C.POINTER(GraphBatch), _vp, _vp, _vp, _vp, _i64, _i32, _i32, C.POINTER(AlignOpts),
+    "mfa_align_batch": (C.c_int, [_vp, C.POINTER(GraphBatch), _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, C.POINTER(AlignOpts),
                                   _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mfa_fmllr_acc_batch": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
     "mfa_align_workspace_bytes": (C.c_size_t, [_vp, _i32, _i64, C.POINTER(AlignOpts)]),
 }
 

@@ -47,6 +47,7 @@ struct mfa_ctx {
   int32_t *d_nblk = nullptr;   // [num_pdfs] number of 32-row blocks (slot 32) else 1
   int32_t *d_slot = nullptr;   // [num_pdfs] slot class rows (1,4,8,16,32)
   std::vector<int32_t> h_slot, h_nblk;
+  int32_t *d_nrows = nullptr;  // [num_pdfs] packed rows per pdf (fmllr.hip)
 
   // Viterbi workspace
   void *d_ws = nullptr;

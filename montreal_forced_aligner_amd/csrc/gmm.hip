@@ -202,6 +202,10 @@ __global__ __launch_bounds__(64 * kWaves, kMinWaves) void gmm_kernel(GmmParams p
   Tile<M8, kNT> tile;
   tile.load_b(p, f0, T, t_base, lane);
   f32x16 acc[kNT];
+  // per-wavefront output staging tile (volatile: written lane-per-frame, read row-wise by the same wavefront)
+  __shared__ float stage_all[kWaves][64 * 33];
+  volatile float *stage = stage_all[wave];
+  const int n_single = cc6[0];
 
   // ---- slot 32 (one pdf per block; pdfs with more than 32 Gaussians take several blocks, two passes).
   // Software pipeline: the A rows of block j+1 are requested right after block j's last MFMA has been issued (its
@@ -263,8 +267,25 @@ __global__ __launch_bounds__(64 * kWaves, kMinWaves) void gmm_kernel(GmmParams p
     if constexpr (kNT == 2) {
       const float mxs = h ? mx[1] : mx[0];
       const double sums = h ? sum[1] : sum[0];
-      const int t = t_base + 32 * h + col;
-      if (t < T) out[(size_t)t * P + j] = finish(mxs, sums);
+      const float v = finish(mxs, sums);
+      if (j < n_single) {
+        // Stage [64 frames][32 pdfs] in LDS and flush whole 128-byte row segments: a lane-per-frame store would touch 64
+        // different lines per instruction and (measured, round 1) inflate HBM write traffic 11x with partial lines.
+        const int jj = (j - first32) & 31;
+        stage[(32 * h + col) * 33 + jj] = v;
+        if (jj == 31 || j + 1 == n_single) {
+          const int j0 = j - jj, cnt = jj + 1;
+          const int c = lane & 31;
+#pragma unroll 4
+          for (int i = 0; i < 32; i++) {
+            const int r = (lane >> 5) + 2 * i, t = t_base + r;
+            if (c < cnt && t < T) out[(size_t)t * P + j0 + c] = stage[r * 33 + c];
+          }
+        }
+      } else {
+        const int t = t_base + 32 * h + col;
+        if (t < T) out[(size_t)t * P + j] = v;
+      }
     } else {
 #pragma unroll
       for (int n = 0; n < kNT; n++) {
@@ -530,9 +551,9 @@ MFA_API int mfa_load_gmm(mfa_ctx *c, int32_t dim, int32_t num_pdfs, const int32_
       gc[row0[p] + i] = h_gconsts[g0 + i];
     }
   }
-  void *old[] = {c->d_w, c->d_gc, c->d_row0, c->d_nblk, c->d_slot};
+  void *old[] = {c->d_w, c->d_gc, c->d_row0, c->d_nblk, c->d_slot, c->d_nrows};
   for (void *q : old) if (q) hipFree(q);
-  c->d_w = nullptr; c->d_gc = nullptr; c->d_row0 = nullptr; c->d_nblk = nullptr; c->d_slot = nullptr;
+  c->d_w = nullptr; c->d_gc = nullptr; c->d_row0 = nullptr; c->d_nblk = nullptr; c->d_slot = nullptr; c->d_nrows = nullptr;
   MFA_HIP_CHECK(c, hipMalloc((void **)&c->d_w, w.size() * 4));
   MFA_HIP_CHECK(c, hipMalloc((void **)&c->d_gc, gc.size() * 4));
   MFA_HIP_CHECK(c, hipMalloc((void **)&c->d_row0, row0.size() * 4));

@@ -33,6 +33,15 @@ struct MfccParams {
   const float *lifter;      // [nceps]
 };
 
+// Every wavefront works in its own LDS slice, so no workgroup barrier is needed: LDS operations of one wavefront execute
+// in program order; the fences only stop the compiler from moving accesses across the hand-over points.
+#define WAVE_SYNC()                                              \
+  do {                                                           \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       \
+    __builtin_amdgcn_wave_barrier();                             \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");       \
+  } while (0)
+
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
   return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
@@ -46,7 +55,7 @@ __global__ __launch_bounds__(256) void mfcc_kernel(MfccParams p, const int16_t *
   const int64_t s0 = sample_off[utt], n = sample_off[utt + 1] - s0;
   const int64_t f0 = frame_off[utt];
   const int T = (int)(frame_off[utt + 1] - f0);
-  if ((int)blockIdx.x * kFramesPerBlock >= T) return;  // whole block idle (uniform)
+  if ((int)blockIdx.x * kFramesPerBlock + wave * kFramesPerWave >= T) return;  // wavefronts are independent
   float *frame = lds[wave];             // [512] staging / power spectrum
   float2 *bufA = (float2 *)(lds[wave] + kNfft);      // [256]
   float2 *bufB = (float2 *)(lds[wave] + 2 * kNfft);  // [256]
@@ -79,7 +88,7 @@ __global__ __launch_bounds__(256) void mfcc_kernel(MfccParams p, const int16_t *
       int s = lane + 64 * j;
       frame[s] = (s < p.win) ? v[j] + off : 0.0f;
     }
-    __syncthreads();
+    WAVE_SYNC();
     // ---- pre-emphasis + window, packed as complex z[m] = x[2m] + i x[2m+1]
 #pragma unroll
     for (int j = 0; j < 8; j++) {
@@ -91,10 +100,10 @@ __global__ __launch_bounds__(256) void mfcc_kernel(MfccParams p, const int16_t *
       }
       v[j] = val;
     }
-    __syncthreads();
+    WAVE_SYNC();
 #pragma unroll
     for (int j = 0; j < 8; j++) ((float *)bufA)[lane + 64 * j] = v[j];
-    __syncthreads();
+    WAVE_SYNC();
     // ---- 256-point complex FFT, Stockham radix-4, 4 stages, one butterfly per lane per stage
     float2 *src = bufA, *dst = bufB;
 #pragma unroll
@@ -119,7 +128,7 @@ __global__ __launch_bounds__(256) void mfcc_kernel(MfccParams p, const int16_t *
       dst[idxD + Ns] = make_float2(d02.x + d13.x, d02.y + d13.y);
       dst[idxD + 2 * Ns] = make_float2(s02.x - s13.x, s02.y - s13.y);
       dst[idxD + 3 * Ns] = make_float2(d02.x - d13.x, d02.y - d13.y);
-      __syncthreads();
+      WAVE_SYNC();
       float2 *t = src; src = dst; dst = t;
     }
     // src now holds Z[0..255] in natural order.  Real-FFT post-processing → power spectrum P[0..256] into frame[].
@@ -136,7 +145,7 @@ __global__ __launch_bounds__(256) void mfcc_kernel(MfccParams p, const int16_t *
       frame[k] = (k == 0) ? re * re : re * re + im * im;  // Kaldi ComputePowerSpectrum: bin 0 = DC^2
       if (k == 0) { float ny = zk.x - zk.y; frame[kHalf] = ny * ny; }
     }
-    __syncthreads();
+    WAVE_SYNC();
     // ---- mel filterbank: lane = (bin, half); each half sums a contiguous part of the triangle in ascending order
     float *mel = (float *)dst;  // reuse the idle ping-pong buffer: mel[0..nbins)
     {
@@ -155,14 +164,14 @@ __global__ __launch_bounds__(256) void mfcc_kernel(MfccParams p, const int16_t *
         mel[bin] = logf(e);
       }
     }
-    __syncthreads();
+    WAVE_SYNC();
     // ---- DCT-II rows 0..nceps-1 + lifter
     if (valid && lane < p.nceps) {
       float acc = 0.0f;
       for (int b = 0; b < p.nbins; b++) acc = fmaf(p.dct[lane * p.nbins + b], mel[b], acc);
       out[(f0 + f) * p.nceps + lane] = acc * p.lifter[lane];
     }
-    __syncthreads();
+    WAVE_SYNC();
   }
 }
 

@@ -53,6 +53,8 @@ struct VitParams {
   u64 *w_bp;                           // [total_frames*bpf] (arc index <<32 | prev pos)
   u32 *w_tokoff;                       // [total_frames + n_utt]
   u32 *w_hash;                         // [n_utt] hash size carried from pass 0 to the retry pass
+  const u32 *w_arcnext;                // [total_arcs] (arc_off[next] << 7) | out-degree(next), built once per call
+  int llcap;                           // score-row cache capacity in LDS (floats); rows longer than this are read from HBM
   // outputs
   int32_t *ali; int32_t *words; int32_t *n_words; float *like; float *frame_like; int32_t *status;
 };
@@ -126,6 +128,14 @@ __device__ __forceinline__ double cand_cost(float w, double cost, float ll, floa
   return ((double)w + cost) + (double)ac;
 }
 
+// hand-over point between lanes of one wavefront (see the LDS carve comment in the kernel)
+#define WSYNC()                                            \
+  do {                                                     \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+    __builtin_amdgcn_wave_barrier();                       \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+  } while (0)
+
 constexpr int kArcCache = 8;  // arcs per token kept in registers during expansion (deeper states take a slow tail loop)
 
 // kListsInLds: the two token lists (state, cost) live in LDS (fast path) or, for graphs/beams whose tables would not
@@ -147,34 +157,40 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
   const int32_t *a_next = p.g.d_arc_next + ab_;
   const float *a_w = p.g.d_arc_weight + ab_;
   const int32_t *a_col = p.g.d_arc_col + ab_;
+  const u32 *a_an = p.w_arcnext + ab_;
   const int64_t f0 = p.frame_off[utt];
   const int T = (int)(p.frame_off[utt + 1] - f0);
   const float *ll = p.ll + p.ll_off[utt];
   const int P = p.ll_cols[utt];
   const int N = p.nmax, C = p.cmax;
 
-  // ---- LDS carve (8-byte items first).  volatile: these tables carry values between lanes of the wavefront; every
-  // access must reach LDS in program order.
-  volatile u64 *s_cost = (volatile u64 *)smem;                  // [N] best cost key per slot
-  volatile double *l_cost0 = kListsInLds ? (volatile double *)(s_cost + N)   // [2][N] token costs (current / next list)
-                                         : (volatile double *)(p.w_cost + (size_t)utt * 2 * N);
-  volatile u32 *slot_of = (volatile u32 *)(s_cost + (kListsInLds ? 3 : 1) * (size_t)N);  // [S] state → slot
+  // ---- LDS carve (8-byte items first).  These tables carry values between lanes of ONE wavefront: LDS operations of
+  // a wavefront execute in program order, so plain accesses are enough provided the compiler keeps them on the right
+  // side of each hand-over point — that is what WSYNC() (a wavefront-scope fence pair + scheduling barrier) is for.
+  // Within a phase the loads stay free to be issued back to back (the volatile version of round 1 waited on every one).
+  u64 *s_cost = (u64 *)smem;                  // [N] best cost key per slot
+  double *l_cost0 = kListsInLds ? (double *)(s_cost + N)   // [2][N] token costs (current / next list)
+                                         : (double *)(p.w_cost + (size_t)utt * 2 * N);
+  u32 *slot_of = (u32 *)(s_cost + (kListsInLds ? 3 : 1) * (size_t)N);  // [S] state → slot
   const int S2 = (S + 1) & ~1;
-  volatile u32 *s_state = slot_of + S2;      // [N]
-  volatile u32 *s_F = s_state + N;           // [N] first creating candidate (pos<<6|k)
-  volatile u32 *s_W = s_F + N;               // [N] winning candidate
-  volatile u32 *s_aux = s_W + N;             // [N] (rank<<24)|ordinal of the bucket leader's first candidate
-  volatile u32 *t_cbase = s_aux + N;         // [N] candidate ordinal base per source token
-  volatile u32 *l_state0 = kListsInLds ? t_cbase + N : (volatile u32 *)(p.w_state + (size_t)utt * 2 * N);  // [2][N] token states
-  volatile u32 *cntord = t_cbase + N + (kListsInLds ? 2 * N : 0);  // [C] bucket sizes at leader ordinals → exclusive sums
-  volatile u32 *ctr = cntord + C;            // [2]: nslots, nstash
+  u32 *s_state = slot_of + S2;      // [N]
+  u32 *s_F = s_state + N;           // [N] first creating candidate (pos<<6|k)
+  u32 *s_W = s_F + N;               // [N] winning candidate
+  u32 *s_aux = s_W + N;             // [N] (rank<<24)|ordinal of the bucket leader's first candidate
+  u32 *t_cbase = s_aux + N;         // [N] candidate ordinal base per source token
+  u32 *s_an = t_cbase + N;          // [N] (first arc << 7 | out-degree) of the slot's state
+  u32 *l_state0 = kListsInLds ? s_an + N : (u32 *)(p.w_state + (size_t)utt * 2 * N);  // [2][N] token states
+  u32 *l_an0 = kListsInLds ? l_state0 + 2 * N : (u32 *)(p.w_state + (size_t)p.g.n_utt * 2 * N + (size_t)utt * 2 * N);
+  u32 *cntord = s_an + N + (kListsInLds ? 4 * N : 0);  // [C] bucket sizes at leader ordinals → exclusive sums
+  float *ll_row = (float *)(cntord + C);      // [llcap] this frame's score row
+  u32 *ctr = (u32 *)(ll_row + p.llcap);       // [2]: nslots, nstash
 
-  volatile u32 *st_a = p.w_stash_a + (size_t)utt * C;
-  volatile u32 *st_b = p.w_stash_b + (size_t)utt * C;
-  volatile u64 *st_key = p.w_stash_key + (size_t)utt * C;
-  volatile u64 *bp = p.w_bp + (size_t)f0 * p.bpf;
+  u32 *st_a = p.w_stash_a + (size_t)utt * C;
+  u32 *st_b = p.w_stash_b + (size_t)utt * C;
+  u64 *st_key = p.w_stash_key + (size_t)utt * C;
+  u64 *bp = p.w_bp + (size_t)f0 * p.bpf;
   const u64 bp_cap = (u64)T * (u64)p.bpf;
-  volatile u32 *tokoff = p.w_tokoff + f0 + utt;
+  u32 *tokoff = p.w_tokoff + f0 + utt;
 
   for (int i = lane; i < S; i += 64) slot_of[i] = kEmpty;
   for (int i = lane; i < C; i += 64) cntord[i] = 0;
@@ -185,16 +201,38 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
   if (S <= 0 || start < 0 || start >= S || T <= 0) status = ST_FAILED;
   // InitDecoding: one token at the start state with cost 0 (graphs are epsilon-free: ProcessNonemitting is a no-op)
   int cur = 0, n = 1;
-  if (lane == 0) { l_state0[0] = (u32)(start < 0 ? 0 : start); l_cost0[0] = 0.0; }
+  if (lane == 0) {
+    const int s0 = start < 0 || start >= S ? 0 : start;
+    l_state0[0] = (u32)s0; l_cost0[0] = 0.0;
+    l_an0[0] = S > 0 ? ((u32)arc_off[s0] << 7) | (u32)(arc_off[s0 + 1] - arc_off[s0]) : 0u;
+  }
+  // score rows are staged through LDS one frame ahead (registers hold row t+1 while frame t is processed)
+  constexpr int kPre = 8;
+  const bool row_cached = P <= p.llcap && P <= 64 * kPre;
+  float pre[kPre];
+#pragma unroll
+  for (int r = 0; r < kPre; r++) pre[r] = (row_cached && T > 0 && lane + 64 * r < P) ? ll[lane + 64 * r] : 0.0f;
   u32 H = p.pass == 0 ? 1000u : p.w_hash[utt];
   u64 bp_used = 0;
-  __threadfence_block();
+  WSYNC();
 
   int t = 0;
   for (; t < T && status == ST_OK; t++) {
     const float *llt = ll + (size_t)t * P;
-    volatile u32 *c_state = l_state0 + cur * N, *n_state = l_state0 + (cur ^ 1) * N;
-    volatile double *c_cost = l_cost0 + cur * N, *n_cost = l_cost0 + (cur ^ 1) * N;
+    if (row_cached) {
+#pragma unroll
+      for (int r = 0; r < kPre; r++) if (lane + 64 * r < P) ll_row[lane + 64 * r] = pre[r];
+      if (t + 1 < T) {
+        const float *nx_row = llt + P;
+#pragma unroll
+        for (int r = 0; r < kPre; r++) if (lane + 64 * r < P) pre[r] = nx_row[lane + 64 * r];
+      }
+      WSYNC();
+    }
+    auto score = [&](int col) -> float { return row_cached ? ll_row[col] : llt[col]; };
+    u32 *c_state = l_state0 + cur * N, *n_state = l_state0 + (cur ^ 1) * N;
+    u32 *c_an = l_an0 + cur * N, *n_an = l_an0 + (cur ^ 1) * N;
+    double *c_cost = l_cost0 + cur * N, *n_cost = l_cost0 + (cur ^ 1) * N;
     // ---------------- GetCutoff: best cost (first index on ties), count
     double best = INFINITY; u32 best_i = kEmpty;
     for (int c0 = 0; c0 < n; c0 += 64) {
@@ -220,12 +258,19 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
       else {
         // sorted[min_active] (> beam_cut) = the smallest cost that has at least min_active+1 costs ≤ it
         double v = INFINITY;
-        for (int c0 = 0; c0 < n; c0 += 64) {
-          int i = c0 + lane;
-          double cst = i < n ? c_cost[i] : INFINITY;
+        if (n <= 64) {  // costs are in registers: broadcast each with v_readlane, no LDS traffic
+          const double cst = lane < n ? c_cost[lane] : INFINITY;
           u32 le = 0;
-          for (int j = 0; j < n; j++) le += (c_cost[j] <= cst) ? 1u : 0u;  // LDS broadcast reads
-          if (i < n && le > (u32)kMinActive) v = fmin(v, cst);
+          for (int j = 0; j < n; j++) le += (readlane_f64(cst, j) <= cst) ? 1u : 0u;
+          if (lane < n && le > (u32)kMinActive) v = cst;
+        } else {
+          for (int c0 = 0; c0 < n; c0 += 64) {
+            int i = c0 + lane;
+            double cst = i < n ? c_cost[i] : INFINITY;
+            u32 le = 0;
+            for (int j = 0; j < n; j++) le += (c_cost[j] <= cst) ? 1u : 0u;  // LDS broadcast reads
+            if (i < n && le > (u32)kMinActive) v = fmin(v, cst);
+          }
         }
         v = wave_min_f64(v);
         wcut = v;
@@ -240,108 +285,119 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
     const bool single = n <= 64;
     double run = INFINITY;  // min over candidate costs seen so far (seed + earlier candidates)
     if (!single && best_i != kEmpty) {
-      const u32 bs = c_state[best_i];
-      const int a0 = arc_off[bs], a1 = arc_off[bs + 1];
+      const u32 ban = c_an[best_i];
+      const int a0 = (int)(ban >> 7), a1 = a0 + (int)(ban & 127u);
       double m = INFINITY;
-      for (int a = a0 + lane; a < a1; a += 64) m = fmin(m, cand_cost(a_w[a], best, llt[a_col[a]], p.scale));
+      for (int a = a0 + lane; a < a1; a += 64) m = fmin(m, cand_cost(a_w[a], best, score(a_col[a]), p.scale));
       run = wave_min_f64(m);
     }
 
     // ---------------- expand tokens in list order
     u32 cand_base = 0;
     bool bad_degree = false;
+    bool used_stash = !single;
     for (int c0 = 0; c0 < n; c0 += 64) {
       const int i = c0 + lane;
-      const u32 st = i < n ? c_state[i] : 0u;
       const double cst = i < n ? c_cost[i] : INFINITY;
       const bool act = i < n && cst < wcut;
       int a0 = 0, narc = 0;
-      if (act) { a0 = arc_off[st]; narc = arc_off[st + 1] - a0; }
+      if (act) { const u32 an = c_an[i]; a0 = (int)(an >> 7); narc = (int)(an & 127u); }
       if (narc > kMaxArcsPerState) bad_degree = true;
       const int maxarc = (int)wave_max_u32((u32)narc);
+      if (maxarc > kArcCache) used_stash = true;
       const u32 narc_incl = incl_scan_sum((u32)narc);
       const u32 cb = cand_base + narc_incl - (u32)narc;
       if (i < n) t_cbase[i] = cb;
       cand_base += (u32)__builtin_amdgcn_readlane((int)narc_incl, 63);
       // arcs → registers (independent loads, one round trip), then their scores (second round trip)
-      float w[kArcCache]; int col[kArcCache]; u32 nx[kArcCache]; double nw[kArcCache]; u32 sl[kArcCache];
+      float w[kArcCache]; int col[kArcCache]; u32 nx[kArcCache]; u32 nan_[kArcCache]; double nw[kArcCache]; u32 sl[kArcCache];
 #pragma unroll
       for (int k = 0; k < kArcCache; k++) {
-        w[k] = 0.0f; col[k] = 0; nx[k] = 0;
-        if (k < narc) { w[k] = a_w[a0 + k]; col[k] = a_col[a0 + k]; nx[k] = (u32)a_next[a0 + k]; }
+        w[k] = 0.0f; col[k] = 0; nx[k] = 0; nan_[k] = 0;
+        if (k < narc) { w[k] = a_w[a0 + k]; col[k] = a_col[a0 + k]; nx[k] = (u32)a_next[a0 + k]; nan_[k] = a_an[a0 + k]; }
       }
       double m = INFINITY;
 #pragma unroll
       for (int k = 0; k < kArcCache; k++) {
-        nw[k] = (k < narc) ? cand_cost(w[k], cst, llt[col[k]], p.scale) : INFINITY;
+        nw[k] = (k < narc) ? cand_cost(w[k], cst, score(col[k]), p.scale) : INFINITY;
         m = fmin(m, nw[k]);
         sl[k] = kEmpty;
       }
       for (int k = kArcCache; k < maxarc; k++)
-        if (k < narc) m = fmin(m, cand_cost(a_w[a0 + k], cst, llt[a_col[a0 + k]], p.scale));
+        if (k < narc) m = fmin(m, cand_cost(a_w[a0 + k], cst, score(a_col[a0 + k]), p.scale));
       if (single) run = best_i != kEmpty ? readlane_f64(m, __builtin_amdgcn_readfirstlane((int)best_i)) : INFINITY;  // best token is always expanded
       const double m_incl = incl_scan_min(m);
       double local = fmin(run, shift_in_min(m_incl));
       run = fmin(run, readlane_f64(m_incl, 63));
 
-      // one candidate: find-or-create the destination's slot, lower its cost, remember the first creator
-      auto create = [&](u32 d, double cnw, u32 cidx, bool created) -> u32 {
-        u32 s = kEmpty;
-        if (created) {
-          s = slot_of[d];
-          if (s == kEmpty) {
-            u32 old = atomicCAS((u32 *)&slot_of[d], kEmpty, kClaim);
-            if (old == kEmpty) {
-              u32 my = atomicAdd((u32 *)&ctr[0], 1u);
-              if (my < (u32)N) { s_state[my] = d; s_cost[my] = kKeyInf; s_F[my] = kEmpty; s_W[my] = kEmpty; }
-              slot_of[d] = my;
-            }
-          }
+      // Candidate creation in three wavefront phases (each phase's LDS operations are issued back to back):
+      //   look up the destination's slot → claim missing slots (CAS; the winner allocates, initialises, publishes)
+      //   → re-read the published slot and lower its cost / first-creator with LDS atomics.
+      auto claim = [&](u32 d, u32 dan) {
+        u32 old = atomicCAS(&slot_of[d], kEmpty, kClaim);
+        if (old == kEmpty) {
+          u32 my = atomicAdd(&ctr[0], 1u);
+          if (my < (u32)N) { s_state[my] = d; s_an[my] = dan; s_cost[my] = kKeyInf; s_F[my] = kEmpty; s_W[my] = kEmpty; }
+          slot_of[d] = my;
         }
-        // all lanes reconverge here; claims made above are published (LDS is in-order within a wavefront)
-        if (created) {
-          s = slot_of[d];
-          if (s < (u32)N) {
-            atomicMin((u64 *)&s_cost[s], dkey(cnw));
-            atomicMin((u32 *)&s_F[s], cidx);
-          } else s = kEmpty;
-        }
+      };
+      auto lower = [&](u32 d, double cnw, u32 cidx) -> u32 {
+        u32 s = slot_of[d];
+        if (s >= (u32)N) return kEmpty;
+        atomicMin(&s_cost[s], dkey(cnw));
+        atomicMin(&s_F[s], cidx);
         return s;
       };
+      bool cr[kArcCache]; u32 s0[kArcCache];
+#pragma unroll
+      for (int k = 0; k < kArcCache; k++) {
+        cr[k] = (k < narc) && (nw[k] < local + (double)abeam);
+        if (k < narc) local = fmin(local, nw[k]);
+        s0[k] = cr[k] ? slot_of[nx[k]] : 0u;
+      }
+#pragma unroll
+      for (int k = 0; k < kArcCache; k++)
+        if (k < maxarc && cr[k] && s0[k] == kEmpty) claim(nx[k], nan_[k]);
+      WSYNC();  // claims are published before anybody re-reads the map
 #pragma unroll
       for (int k = 0; k < kArcCache; k++) {
         if (k < maxarc) {  // uniform
-          bool created = (k < narc) && (nw[k] < local + (double)abeam);
-          if (k < narc) local = fmin(local, nw[k]);
-          sl[k] = create(nx[k], nw[k], ((u32)i << kArcBits) | (u32)k, created);
+          sl[k] = cr[k] ? lower(nx[k], nw[k], ((u32)i << kArcBits) | (u32)k) : kEmpty;
           if (!single && sl[k] != kEmpty) {
-            u32 q = atomicAdd((u32 *)&ctr[1], 1u);
+            u32 q = atomicAdd(&ctr[1], 1u);
             if (q < (u32)C) { st_a[q] = sl[k]; st_b[q] = ((u32)i << kArcBits) | (u32)k; st_key[q] = dkey(nw[k]); }
           }
         }
       }
       for (int k = kArcCache; k < maxarc; k++) {  // slow tail: states with more than kArcCache arcs
-        bool created = false; double cnw = 0.0; u32 d = 0;
+        bool created = false; double cnw = 0.0; u32 d = 0, dan = 0;
         if (k < narc) {
-          cnw = cand_cost(a_w[a0 + k], cst, llt[a_col[a0 + k]], p.scale);
+          cnw = cand_cost(a_w[a0 + k], cst, score(a_col[a0 + k]), p.scale);
           created = cnw < local + (double)abeam;
           local = fmin(local, cnw);
           d = (u32)a_next[a0 + k];
+          dan = a_an[a0 + k];
         }
-        u32 s = create(d, cnw, ((u32)i << kArcBits) | (u32)k, created);
+        if (created && slot_of[d] == kEmpty) claim(d, dan);
+        WSYNC();
+        u32 s = created ? lower(d, cnw, ((u32)i << kArcBits) | (u32)k) : kEmpty;
         if (s != kEmpty) {  // tail candidates always go through the stash
-          u32 q = atomicAdd((u32 *)&ctr[1], 1u);
+          u32 q = atomicAdd(&ctr[1], 1u);
           if (q < (u32)C) { st_a[q] = s; st_b[q] = ((u32)i << kArcBits) | (u32)k; st_key[q] = dkey(cnw); }
         }
       }
       if (single) {
+        WSYNC();  // every candidate of the frame has lowered its slot's cost
         // winners straight from registers: earliest candidate among those that reached the slot's final best cost
 #pragma unroll
         for (int k = 0; k < kArcCache; k++)
-          if (sl[k] != kEmpty && dkey(nw[k]) == s_cost[sl[k]]) atomicMin((u32 *)&s_W[sl[k]], ((u32)i << kArcBits) | (u32)k);
+          if (sl[k] != kEmpty && dkey(nw[k]) == s_cost[sl[k]]) atomicMin(&s_W[sl[k]], ((u32)i << kArcBits) | (u32)k);
       }
     }
-    __threadfence_block();
+    // the stash lives in HBM: make its stores visible before other lanes read them back (workgroup-scope fence waits for
+    // them); frames that kept everything in registers/LDS only need the wavefront hand-over
+    if (used_stash) __threadfence_block();
+    WSYNC();
     const u32 nslots = ctr[0], nstash = ctr[1];
     if (__any(bad_degree)) { status = ST_UNSUPPORTED; break; }
     if (nslots > (u32)N || nstash > (u32)C || cand_base > (u32)C) { status = ST_TOKEN_OVERFLOW; break; }
@@ -352,9 +408,10 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
       u32 q = q0 + lane;
       if (q < nstash) {
         u32 s = st_a[q];
-        if (st_key[q] == s_cost[s]) atomicMin((u32 *)&s_W[s], st_b[q]);
+        if (st_key[q] == s_cost[s]) atomicMin(&s_W[s], st_b[q]);
       }
     }
+    WSYNC();  // winners settled
     // ---------------- Kaldi list order of the new tokens
     for (u32 j0 = 0; j0 < nslots; j0 += 64) {
       u32 j = j0 + lane;
@@ -378,6 +435,7 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
         if (Fb == Fj) cntord[ord_b] = nb;
       }
     }
+    WSYNC();
     {
       u32 carry = 0;
       for (u32 o0 = 0; o0 < cand_base; o0 += 64) {
@@ -388,6 +446,7 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
         carry += (u32)__builtin_amdgcn_readlane((int)inc, 63);
       }
     }
+    WSYNC();
     // ---------------- write the new list + back-pointers, reset the tables
     if (bp_used + nslots > bp_cap) { status = ST_BP_OVERFLOW; break; }
     bool broken = false;  // defensive: an inconsistent table must never turn into an out-of-range store
@@ -400,14 +459,16 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
         const u32 ppos = W >> kArcBits, k = W & (kMaxArcsPerState - 1);
         if (pos >= nslots || ppos >= (u32)n || d >= (u32)S) broken = true;
         else {
-          const u32 arc = (u32)arc_off[c_state[ppos]] + k;
+          const u32 arc = (c_an[ppos] >> 7) + k;
           n_state[pos] = d;
+          n_an[pos] = s_an[j];
           n_cost[pos] = dunkey(s_cost[j]);
           bp[bp_used + pos] = ((u64)arc << 32) | (u64)ppos;
         }
       }
     }
     if (__any(broken)) { status = ST_INTERNAL; break; }
+    WSYNC();
     for (u32 j0 = 0; j0 < nslots; j0 += 64) {
       u32 j = j0 + lane;
       if (j < nslots) { slot_of[s_state[j]] = kEmpty; cntord[s_aux[j] & 0xFFFFFFu] = 0; }
@@ -416,11 +477,13 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
     bp_used += nslots;
     n = (int)nslots;
     cur ^= 1;
-    __threadfence_block();
+    if (!kListsInLds) __threadfence_block();  // token lists in HBM: stores must land before the next frame reads them
+    WSYNC();
   }
+  __threadfence_block();  // back-pointer records (HBM) are read back by the traceback below
   if (p.pass == 0 && lane == 0) p.w_hash[utt] = H;
-  volatile u32 *c_state = l_state0 + cur * N;
-  volatile double *c_cost = l_cost0 + cur * N;
+  u32 *c_state = l_state0 + cur * N;
+  double *c_cost = l_cost0 + cur * N;
 
   // ---------------- ReachedFinal / best final token (first in list order on ties)
   int32_t out_status = status;
@@ -466,6 +529,7 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
     }
   }
   __threadfence_block();
+  WSYNC();
   // ---------------- outputs: transition-ids, words (ordered compaction), likelihood (Kaldi's float accumulation)
   const int32_t *a_il = p.g.d_arc_ilabel + ab_, *a_ol = p.g.d_arc_olabel + ab_;
   int32_t *words = p.words + f0;
@@ -475,7 +539,7 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
   const float inv_scale = -1.0f / p.scale;
   for (int c0 = 0; c0 < T; c0 += 64) {
     const int tt = c0 + lane;
-    int arc = tt < T ? ((volatile int32_t *)ali)[tt] : 0;
+    int arc = tt < T ? ali[tt] : 0;
     int il = 0, ol = 0; float w = 0.0f, ac = 0.0f;
     if (tt < T) {
       il = a_il[arc]; ol = a_ol[arc]; w = a_w[arc];
@@ -517,19 +581,35 @@ __global__ void finalize_pending_kernel(int32_t *status, int n_utt) {
   if (i < n_utt && status[i] == ST_PENDING) status[i] = ST_FAILED;
 }
 
+// (first arc << 7 | out-degree) of every arc's destination state: folds the arc_off lookup of the NEXT frame into this
+// frame's arc fetch, so a frame costs one dependent HBM/L2 round trip instead of three.
+__global__ void arcnext_kernel(mfa_graph_batch g, u32 *out) {
+  const int utt = blockIdx.x;
+  const int64_t so = g.d_state_off[utt], ab = g.d_arc_base[utt];
+  const int64_t na = g.d_arc_base[utt + 1] - ab;
+  const int32_t *arc_off = g.d_arc_off + so + utt;
+  for (int64_t a = threadIdx.x; a < na; a += blockDim.x) {
+    const int d = g.d_arc_next[ab + a];
+    out[ab + a] = ((u32)arc_off[d] << 7) | (u32)(arc_off[d + 1] - arc_off[d]);
+  }
+}
+
+constexpr int kLlCap = 512;
 size_t lds_bytes(int S, int N, int C, bool lists_in_lds) {
   int S2 = (S + 1) & ~1;
-  return (size_t)N * 8 + (size_t)S2 * 4 + (size_t)N * 5 * 4 + (size_t)C * 4 + 16 + (lists_in_lds ? (size_t)N * 24 : 0);
+  return (size_t)N * 8 + (size_t)S2 * 4 + (size_t)N * 6 * 4 + (size_t)C * 4 + (size_t)kLlCap * 4 + 16 +
+         (lists_in_lds ? (size_t)N * 32 : 0);
 }
 constexpr size_t kLdsLimit = 160 * 1024;
 
 struct WsLayout {
-  size_t state, cost, sta, stb, stkey, bp, tokoff, hash, list, count, total;
+  size_t arcnext, state, cost, sta, stb, stkey, bp, tokoff, hash, list, count, total;
 };
-WsLayout ws_layout(int n_utt, int64_t total_frames, int N, int C, int bpf) {
+WsLayout ws_layout(int n_utt, int64_t total_frames, int N, int C, int bpf, int64_t total_arcs) {
   WsLayout w; size_t o = 0;
   auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 255) & ~(size_t)255; return at; };
-  w.state = take((size_t)n_utt * 2 * N * 4);
+  w.arcnext = take((size_t)total_arcs * 4);
+  w.state = take((size_t)n_utt * 4 * N * 4);  // token states + their packed arc ranges
   w.cost = take((size_t)n_utt * 2 * N * 8);
   w.sta = take((size_t)n_utt * C * 4);
   w.stb = take((size_t)n_utt * C * 4);
@@ -566,12 +646,13 @@ extern "C" {
 MFA_API size_t mfa_align_workspace_bytes(mfa_ctx *c, int32_t n_utt, int64_t total_frames, const mfa_align_opts *o) {
   (void)c;
   int N = (o->max_tokens > 0 ? o->max_tokens : 1024) * 4, C = 8 * N;
-  return ws_layout(n_utt, total_frames, N, C, o->bp_tokens_per_frame > 0 ? o->bp_tokens_per_frame : 512).total;
+  return ws_layout(n_utt, total_frames, N, C, o->bp_tokens_per_frame > 0 ? o->bp_tokens_per_frame : 512,
+                   (int64_t)n_utt * 8 * N).total;
 }
 
 MFA_API int mfa_align_batch(mfa_ctx *c, const mfa_graph_batch *g, const float *d_loglikes, const int64_t *d_ll_off,
                             const int32_t *d_ll_cols, const int64_t *d_frame_off, int64_t total_frames,
-                            int32_t max_states, int32_t max_arcs, const mfa_align_opts *o, int32_t *d_ali, int32_t *d_words, int32_t *d_n_words,
+                            int64_t total_arcs, int32_t max_states, int32_t max_arcs, const mfa_align_opts *o, int32_t *d_ali, int32_t *d_words, int32_t *d_n_words,
                             float *d_like, float *d_frame_like, int32_t *d_status) {
   hipSetDevice(c->device);
   const int n_utt = g->n_utt;
@@ -579,19 +660,21 @@ MFA_API int mfa_align_batch(mfa_ctx *c, const mfa_graph_batch *g, const float *d
   if (o->beam <= 0.0f || (o->retry_beam != 0.0f && o->retry_beam <= o->beam))
     return c->fail("Beams do not make sense: beam %f, retry-beam %f", o->beam, o->retry_beam);
   if (max_states <= 0 || max_arcs <= 0) return c->fail("max_states and max_arcs must be positive");
-  if (total_frames <= 0) return c->fail("total_frames must be positive");
+  if (total_frames <= 0 || total_arcs <= 0) return c->fail("total_frames and total_arcs must be positive");
+  if (max_arcs >= (1 << 25)) return c->fail("graphs with more than 2^25 arcs are not supported");
   const int bpf = o->bp_tokens_per_frame > 0 ? o->bp_tokens_per_frame : 512;
   const int passes = o->retry_beam != 0.0f ? 2 : 1;
   int N[2], C[2];
   for (int ps = 0; ps < 2; ps++) pick_caps(o, max_states, max_arcs, ps, &N[ps], &C[ps]);
   const int Nw = passes == 2 ? N[1] : N[0], Cw = passes == 2 ? C[1] : C[0];
-  WsLayout w = ws_layout(n_utt, total_frames, Nw, Cw, bpf);
+  WsLayout w = ws_layout(n_utt, total_frames, Nw, Cw, bpf, total_arcs);
   if (c->ws_bytes < w.total) {
     if (c->d_ws) { hipFree(c->d_ws); c->d_ws = nullptr; c->ws_bytes = 0; }
     MFA_HIP_CHECK(c, hipMalloc(&c->d_ws, w.total));
     c->ws_bytes = w.total;
   }
   unsigned char *base = (unsigned char *)c->d_ws;
+  hipLaunchKernelGGL(arcnext_kernel, dim3(n_utt), dim3(256), 0, c->stream, *g, (u32 *)(base + w.arcnext));
   for (int ps = 0; ps < passes; ps++) {
     // token lists in LDS when everything fits comfortably; in HBM for big graphs / the wide retry beam; and if even the
     // atomically updated tables do not fit, shrink the token capacity (an overflow is then reported per utterance)
@@ -608,11 +691,13 @@ MFA_API int mfa_align_batch(mfa_ctx *c, const mfa_graph_batch *g, const float *d
     p.beam = ps == 0 ? o->beam : o->retry_beam; p.scale = o->acoustic_scale;
     p.nmax = N[ps]; p.cmax = C[ps]; p.bpf = bpf; p.pass = ps;
     // workspace strides follow this pass's capacities (lists and stash are per-pass scratch)
-    WsLayout wp = ws_layout(n_utt, total_frames, N[ps], C[ps], bpf);
+    WsLayout wp = ws_layout(n_utt, total_frames, N[ps], C[ps], bpf, total_arcs);
     p.w_state = (u32 *)(base + wp.state); p.w_cost = (double *)(base + wp.cost);
     p.w_stash_a = (u32 *)(base + wp.sta); p.w_stash_b = (u32 *)(base + wp.stb); p.w_stash_key = (u64 *)(base + wp.stkey);
     p.w_bp = (u64 *)(base + wp.bp); p.w_tokoff = (u32 *)(base + wp.tokoff);
     p.w_hash = (u32 *)(base + w.hash);     // fixed location across passes
+    p.w_arcnext = (const u32 *)(base + w.arcnext);
+    p.llcap = kLlCap;
     int32_t *d_list = (int32_t *)(base + w.list), *d_count = (int32_t *)(base + w.count);
     p.utt_list = nullptr; p.n_list = nullptr;
     p.ali = d_ali; p.words = d_words; p.n_words = d_n_words; p.like = d_like; p.frame_like = d_frame_like; p.status = d_status;

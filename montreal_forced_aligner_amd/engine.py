@@ -38,6 +38,7 @@ class PackedGraphs:
     n_utt: int
     max_states: int
     max_arcs: int
+    total_arcs: int
     tensors: Dict[str, torch.Tensor]
     pdf_list: torch.Tensor      # int32 [ΣP_u] (slot-sorted per utterance)
     pdf_off: torch.Tensor       # int64 [n_utt+1]
@@ -235,7 +236,7 @@ class AlignmentEngine:
             arc_col=self._dev(cols), arc_ilabel=self._dev(arcs["ilabel"].astype(np.int32)),
             arc_olabel=self._dev(arcs["olabel"].astype(np.int32)),
         )
-        return PackedGraphs(n, int(S.max()) if n else 0, int(A.max()) if n else 0, t, self._dev(np.concatenate(pdf_lists).astype(np.int32)),
+        return PackedGraphs(n, int(S.max()) if n else 0, int(A.max()) if n else 0, int(A.sum()), t, self._dev(np.concatenate(pdf_lists).astype(np.int32)),
                             self._dev(pdf_off), self._dev(np.stack(counts).astype(np.int32)), pdf_off, pdf_lists)
 
     def align(self, graphs: PackedGraphs, loglikes: torch.Tensor, ll_off: np.ndarray, ll_cols: torch.Tensor,
@@ -255,7 +256,7 @@ class AlignmentEngine:
         gs = graphs.struct()
         d_lo, d_fo = self._dev(ll_off), self._dev(frame_off)
         check(self.ctx, self.lib.mfa_align_batch(self.ctx, C.byref(gs), _ptr(loglikes), _ptr(d_lo), _ptr(ll_cols), _ptr(d_fo),
-                                                 total, graphs.max_states, graphs.max_arcs, C.byref(opts), _ptr(ali), _ptr(words),
+                                                 total, graphs.total_arcs, graphs.max_states, graphs.max_arcs, C.byref(opts), _ptr(ali), _ptr(words),
                                                  _ptr(n_words), _ptr(like), _ptr(flike), _ptr(status)), "mfa_align_batch")
         return dict(ali=ali, words=words, n_words=n_words, like=like, status=status, frame_like=flike)
 
@@ -347,6 +348,36 @@ class Pipeline:
                                        _ptr(g.pdf_list), _ptr(g.pdf_off), _ptr(g.class_counts), _ptr(self.d_ll_off),
                                        _ptr(self.loglikes)), "mfa_gmm_score_batch")
         check(c, L.mfa_align_batch(c, C.byref(self.gstruct), _ptr(self.loglikes), _ptr(self.d_ll_off), _ptr(self.d_ll_cols),
-                                   _ptr(self.d_frame_off), self.total_frames, g.max_states, g.max_arcs, C.byref(self.opts), _ptr(self.ali),
+                                   _ptr(self.d_frame_off), self.total_frames, g.total_arcs, g.max_states, g.max_arcs, C.byref(self.opts), _ptr(self.ali),
                                    _ptr(self.words), _ptr(self.n_words), _ptr(self.like), None, _ptr(self.status)),
               "mfa_align_batch")
+
+
+def fmllr_statistics(engine: "AlignmentEngine", feats: torch.Tensor, frame_off: np.ndarray, ali: torch.Tensor,
+                     tm: TransitionModel, utt2spk: np.ndarray, silence_phones: Sequence[int], silence_weight: float = 0.0):
+    """Per-speaker fMLLR statistics from first-pass alignments (mfa_fmllr_acc_batch).
+
+    ``ali``: int32 [ΣT] transition-ids (0 where an utterance failed: those frames get weight 0).  Returns
+    (speaker ids, beta [S], K [S,D,D+1], G [S,D,D+1,D+1]) as float64 numpy arrays."""
+    dev = engine.device
+    id2pdf = torch.from_numpy(np.maximum(tm.id2pdf, 0).astype(np.int32)).to(dev)
+    sil = np.zeros(tm.id2phone.shape[0], dtype=np.float32)
+    sil[np.isin(tm.id2phone, np.asarray(list(silence_phones), dtype=np.int64))] = 1.0
+    w_of_tid = torch.from_numpy(np.where(sil > 0, np.float32(silence_weight), np.float32(1.0)).astype(np.float32)).to(dev)
+    w_of_tid[0] = 0.0
+    ali64 = ali.to(torch.int64)
+    pdf = id2pdf[ali64].contiguous()
+    weight = w_of_tid[ali64].contiguous()
+    spk_ids, inv = np.unique(np.asarray(utt2spk), return_inverse=True)
+    n_spk = len(spk_ids)
+    order = np.argsort(inv, kind="stable").astype(np.int32)
+    spk_off = np.concatenate([[0], np.cumsum(np.bincount(inv, minlength=n_spk))]).astype(np.int32)
+    D = feats.shape[1]
+    beta = torch.zeros(n_spk, dtype=torch.float64, device=dev)
+    K = torch.zeros((n_spk, D, D + 1), dtype=torch.float64, device=dev)
+    G = torch.zeros((n_spk, D, D + 1, D + 1), dtype=torch.float64, device=dev)
+    d_fo, d_so, d_su = engine._dev(frame_off), engine._dev(spk_off), engine._dev(order)
+    check(engine.ctx, engine.lib.mfa_fmllr_acc_batch(engine.ctx, _ptr(feats), _ptr(d_fo), len(frame_off) - 1, int(frame_off[-1]),
+                                                      _ptr(pdf), _ptr(weight), _ptr(d_so), _ptr(d_su), n_spk, _ptr(beta),
+                                                      _ptr(K), _ptr(G)), "mfa_fmllr_acc_batch")
+    return spk_ids, beta.cpu().numpy(), K.cpu().numpy(), G.cpu().numpy()

@@ -276,3 +276,40 @@ def test_end_to_end_pcm_to_alignment(engine, fx):
         a, b = frame_off[u], frame_off[u + 1]
         assert np.array_equal(res["ali"][a:b], ref["ali"])  # frame-identical boundaries
         assert abs(res["like"][u] - ref["like"]) / (b - a) < 1e-3  # per-frame log-likelihood (what MFA reports) within 1e-3
+
+
+def test_fmllr_statistics_match_oracle(engine, fx):
+    """First-pass alignment → per-speaker fMLLR statistics on the device vs the oracle's accumulation, and the
+    host solve on them vs the oracle's solve."""
+    from montreal_forced_aligner_amd import fmllr as F
+    from montreal_forced_aligner_amd.engine import fmllr_statistics
+
+    am, tm = fx.g2p_am, fx.g2p_tm
+    rng = np.random.default_rng(3)
+    mf = [O.mfcc(s.astype(np.float32), O.default_mfcc_opts(snip_edges=1)) for s in _segments(fx)[:3]]
+    feats = [O.affine(O.splice(O.cmvn_apply(O.cmvn_stats([m]), m)), fx.g2p_lda) for m in mf]
+    frame_off = np.concatenate([[0], np.cumsum([f.shape[0] for f in feats])]).astype(np.int64)
+    # a synthetic "alignment": random transition-ids of the model (what matters here is the statistics, not the path)
+    alis = [rng.integers(1, tm.num_transition_ids + 1, size=f.shape[0]).astype(np.int32) for f in feats]
+    alis[1][:5] = 0  # unaligned frames carry no weight
+    utt2spk = np.array([7, 3, 7])
+    sil_phones = [1, 2]
+    engine.load_gmm(am)
+    spk_ids, beta, K, G = fmllr_statistics(engine, _dev(engine, np.concatenate(feats)), frame_off, _dev(engine, np.concatenate(alis)),
+                                           tm, utt2spk, sil_phones)
+    assert spk_ids.tolist() == [3, 7]
+    for k, spk in enumerate(spk_ids):
+        stats = None
+        for u in range(3):
+            if utt2spk[u] != spk:
+                continue
+            ali = alis[u]
+            w = np.where((ali == 0) | np.isin(tm.id2phone[ali], sil_phones), 0.0, 1.0).astype(np.float32)
+            stats = O.fmllr_acc(feats[u], np.maximum(tm.id2pdf[ali], 0), w, am.gconsts, am.means_invvars, am.inv_vars,
+                                am.pdf_offsets, stats)
+        rb, rK, rG = stats[0][0], stats[1], stats[2]
+        assert abs(beta[k] - rb) < 1e-3 * max(1.0, rb)
+        assert np.allclose(K[k], rK, rtol=1e-4, atol=1e-2) and np.allclose(G[k], rG, rtol=1e-4, atol=1e-2)
+        Wd, impr_d = F.compute_fmllr(beta[k], K[k], G[k], min_count=50.0)
+        Wo, impr_o = O.fmllr_solve(rb, rK, rG, min_count=50.0)
+        assert abs(impr_d - impr_o) < 1e-3 * max(1.0, abs(impr_o)) and np.abs(Wd - Wo).max() < 1e-3
