@@ -38,6 +38,8 @@ struct GmmParams {
   float *out;
   float min_log_diff;  // logf(FLT_EPSILON), computed on the host so device and oracle use the same constant
   int skip_single;     // >0: that many leading single-block 32-row pdfs are handled by gmm_sp_kernel
+  int n_utt, tiles;    // generic kernel: 1-D grid of 8·ceil(n_utt/8)·tiles workgroups
+  int prio;            // MFA_GMM_PRIO: s_setprio level for the second half of a 512-thread workgroup (0 = none)
 };
 
 __device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
@@ -146,32 +148,31 @@ __device__ __forceinline__ float reg_max(const f32x16 &v) {
   for (int r = R0 + 1; r < R1; r++) m = fmaxf(m, v[r]);
   return m;
 }
-// exp(x) for x in [ln(eps), 0]: 2^(x·log2 e) with the product's rounding error folded back in (≈1.5 ulp, six VALU
-// instructions instead of the ≈20 of the library expf — the epilogue shares the SIMD with the other wavefront's MFMAs).
-__device__ __forceinline__ float exp_neg(float x) {
-  const float kL2E = 1.44269504088896341f, kL2E_lo = 1.92596299112661746e-8f, kLn2 = 0.693147180559945309f;
-  float t = x * kL2E;
-  float e = fmaf(x, kL2E, -t);
-  e = fmaf(x, kL2E_lo, e);
-  float r = __builtin_amdgcn_exp2f(t);
-  return fmaf(r, e * kLn2, r);
-}
+// Σ_r exp(v[r] − mx) over the rows r ∈ [R0, R1) that pass Kaldi's cutoff (v[r] ≥ max + ln ε).
+// exp(x) = 2^(x·log2 e) on the hardware exp2 (≈1 ulp); the rounding of the product x·log2 e adds |x|·6e-8 relative
+// error to a term, which only matters for terms that are themselves ≤ e^x of the sum — below 1e-7 of the total.
+// The ≤16 terms per lane are added in float32 as a balanced tree (error ≲ 4 ulp of the sum, i.e. ≲ 2.5e-7 absolute on
+// the log-likelihood — an order of magnitude below half an ulp of a float32 score of magnitude ≥ 16).  Round 1 summed
+// in float64 after a 6-instruction exponential: measured, that epilogue cost as much VALU time as the MFMAs it follows.
 template <int R0, int R1>
-__device__ __forceinline__ double reg_expsum(const f32x16 &v, float mx, float cutoff) {
-  double s = 0.0;
+__device__ __forceinline__ float reg_expsum(const f32x16 &v, float mx, float cutoff) {
+  constexpr int n = R1 - R0;
+  float e[n];
 #pragma unroll
-  for (int r = R0; r < R1; r++) {
-    float e = exp_neg(v[r] - mx);
-    s += (double)(v[r] >= cutoff ? e : 0.0f);
+  for (int r = 0; r < n; r++) {
+    const float t = __builtin_amdgcn_exp2f((v[R0 + r] - mx) * 1.44269504088896341f);
+    e[r] = v[R0 + r] >= cutoff ? t : 0.0f;
   }
-  return s;
+#pragma unroll
+  for (int w = 1; w < n; w <<= 1)
+#pragma unroll
+    for (int r = 0; r + w < n; r += 2 * w) e[r] += e[r + w];
+  return e[0];
 }
-// LL = max + ln(sum).  sum ∈ [1, #Gaussians] is exact in float64; the logarithm is taken with the hardware log2
-// (1 ulp on a value ≤ 5–7, i.e. ≲4e-7 absolute — well inside half an ulp of a float32 log-likelihood of magnitude ≥ 16).
-__device__ __forceinline__ float finish(float mx, double sum) {
-  return fmaf(__builtin_amdgcn_logf((float)sum), 0.693147180559945309f, mx);
+// LL = max + ln(sum) with the hardware log2 (1 ulp on a value ≤ 7, i.e. ≲4e-7 absolute).
+__device__ __forceinline__ float finish(float mx, float sum) {
+  return fmaf(__builtin_amdgcn_logf(sum), 0.693147180559945309f, mx);
 }
-__device__ __forceinline__ float finish_exact(float mx, double sum) { return (float)((double)mx + log(sum)); }
 
 template <int M8, int kNT, int kMinWaves, int kWaves>
 __global__ __launch_bounds__(64 * kWaves, kMinWaves) void gmm_kernel(GmmParams p) {
@@ -180,12 +181,18 @@ __global__ __launch_bounds__(64 * kWaves, kMinWaves) void gmm_kernel(GmmParams p
   // phase, then both in their log-sum-exp epilogue, matrix pipe idle).  A static priority for the second half lets that
   // wavefront own the matrix pipe while the other fills the pipe during the first one's epilogue
   // (cdna_hip_programming.md T5, static form).
-  if (kWaves == 8 && (threadIdx.x >> 8)) __builtin_amdgcn_s_setprio(2);
-  const int utt = blockIdx.y;
+  if (kWaves == 8 && p.prio && (threadIdx.x >> 8)) __builtin_amdgcn_s_setprio(2);
+  // XCD-aware block→(utterance, frame tile) map (cdna_hip_programming.md T1): workgroups are dealt round-robin over the
+  // 8 XCDs, each with a private L2.  All frame tiles of one utterance stream the same model rows, so they are given
+  // consecutive slots on ONE XCD: the rows are then fetched from HBM/Infinity Cache once per utterance, not once per tile.
+  const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+  const int utt = (seq / p.tiles) * 8 + xcd;
+  const int tile_x = seq % p.tiles;
+  if (utt >= p.n_utt) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t f0 = p.frame_off[utt];
   const int T = (int)(p.frame_off[utt + 1] - f0);
-  const int t_base = (blockIdx.x * kWaves + wave) * kFramesPerWave;
+  const int t_base = (tile_x * kWaves + wave) * kFramesPerWave;
   if (t_base >= T) return;  // wavefronts are independent (no barriers in this kernel)
   const int col = lane & 31, h = lane >> 5;
   const int64_t l0 = p.pdf_off[utt];
@@ -204,7 +211,7 @@ __global__ __launch_bounds__(64 * kWaves, kMinWaves) void gmm_kernel(GmmParams p
   f32x16 acc[kNT];
   // per-wavefront output staging tile (volatile: written lane-per-frame, read row-wise by the same wavefront)
   __shared__ float stage_all[kWaves][64 * 33];
-  volatile float *stage = stage_all[wave];
+  float *stage = stage_all[wave];
   const int n_single = cc6[0];
 
   // ---- slot 32 (one pdf per block; pdfs with more than 32 Gaussians take several blocks, two passes).
@@ -226,7 +233,7 @@ __global__ __launch_bounds__(64 * kWaves, kMinWaves) void gmm_kernel(GmmParams p
   if (n32 > first32) request(first32);
   for (int j = first32; j < n32; j++) {
     const int r0 = r0_next, nb = nb_next;
-    float mx[kNT]; double sum[kNT];
+    float mx[kNT]; float sum[kNT];
     if (nb == 1) {
       tile.run32(a_next, gc_next, acc);
       if (j + 1 < n32) request(j + 1);
@@ -234,13 +241,13 @@ __global__ __launch_bounds__(64 * kWaves, kMinWaves) void gmm_kernel(GmmParams p
       for (int n = 0; n < kNT; n++) {
         float m = reg_max<0, 16>(acc[n]);
         m = fmaxf(m, swap32(m, h));
-        double s = reg_expsum<0, 16>(acc[n], m, m + p.min_log_diff);
-        s += swap32_f64(s, h);
+        float s = reg_expsum<0, 16>(acc[n], m, m + p.min_log_diff);
+        s += swap32(s, h);
         mx[n] = m; sum[n] = s;
       }
     } else {
 #pragma unroll
-      for (int n = 0; n < kNT; n++) { mx[n] = -INFINITY; sum[n] = 0.0; }
+      for (int n = 0; n < kNT; n++) { mx[n] = -INFINITY; sum[n] = 0.0f; }
       for (int blk = 0; blk < nb; blk++) {
         const int rr = r0 + 32 * blk + col;
         tile.block(p.w + (size_t)rr * p.kpad + 4 * h, p.gc[rr], lane, acc);
@@ -256,8 +263,8 @@ __global__ __launch_bounds__(64 * kWaves, kMinWaves) void gmm_kernel(GmmParams p
         tile.block(p.w + (size_t)rr * p.kpad + 4 * h, p.gc[rr], lane, acc);
 #pragma unroll
         for (int n = 0; n < kNT; n++) {
-          double s = reg_expsum<0, 16>(acc[n], mx[n], mx[n] + p.min_log_diff);
-          s += shfl_xor_f64(s, 32);
+          float s = reg_expsum<0, 16>(acc[n], mx[n], mx[n] + p.min_log_diff);
+          s += swap32(s, h);
           sum[n] += s;
         }
       }
@@ -266,7 +273,7 @@ __global__ __launch_bounds__(64 * kWaves, kMinWaves) void gmm_kernel(GmmParams p
     // both halves hold every tile's (max, sum): with two tiles half h finishes tile h (one log per lane)
     if constexpr (kNT == 2) {
       const float mxs = h ? mx[1] : mx[0];
-      const double sums = h ? sum[1] : sum[0];
+      const float sums = h ? sum[1] : sum[0];
       const float v = finish(mxs, sums);
       if (j < n_single) {
         // Stage [64 frames][32 pdfs] in LDS and flush whole 128-byte row segments: a lane-per-frame store would touch 64
@@ -274,13 +281,20 @@ __global__ __launch_bounds__(64 * kWaves, kMinWaves) void gmm_kernel(GmmParams p
         const int jj = (j - first32) & 31;
         stage[(32 * h + col) * 33 + jj] = v;
         if (jj == 31 || j + 1 == n_single) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
           const int j0 = j - jj, cnt = jj + 1;
           const int c = lane & 31;
 #pragma unroll 4
           for (int i = 0; i < 32; i++) {
             const int r = (lane >> 5) + 2 * i, t = t_base + r;
-            if (c < cnt && t < T) out[(size_t)t * P + j0 + c] = stage[r * 33 + c];
+            // streaming store: the scores are written once and read once by the decoder; keeping them out of the
+            // Infinity Cache leaves room for the 51 MB of model rows every workgroup keeps re-reading
+            if (c < cnt && t < T) __builtin_nontemporal_store(stage[r * 33 + c], &out[(size_t)t * P + j0 + c]);
           }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
         }
       } else {
         const int t = t_base + 32 * h + col;
@@ -308,8 +322,8 @@ __global__ __launch_bounds__(64 * kWaves, kMinWaves) void gmm_kernel(GmmParams p
       int t = t_base + 32 * n + col;
       float m0 = reg_max<0, 8>(acc[n]), m1 = reg_max<8, 16>(acc[n]);
       m0 = fmaxf(m0, __shfl_xor(m0, 32)); m1 = fmaxf(m1, __shfl_xor(m1, 32));
-      double s0 = reg_expsum<0, 8>(acc[n], m0, m0 + p.min_log_diff), s1 = reg_expsum<8, 16>(acc[n], m1, m1 + p.min_log_diff);
-      s0 += shfl_xor_f64(s0, 32); s1 += shfl_xor_f64(s1, 32);
+      float s0 = reg_expsum<0, 8>(acc[n], m0, m0 + p.min_log_diff), s1 = reg_expsum<8, 16>(acc[n], m1, m1 + p.min_log_diff);
+      s0 += __shfl_xor(s0, 32); s1 += __shfl_xor(s1, 32);
       if (h == 0 && t < T) {
         out[(size_t)t * P + base + j] = finish(m0, s0);
         if (j + 1 < cc[1]) out[(size_t)t * P + base + j + 1] = finish(m1, s1);
@@ -326,14 +340,14 @@ __global__ __launch_bounds__(64 * kWaves, kMinWaves) void gmm_kernel(GmmParams p
 #pragma unroll
     for (int n = 0; n < kNT; n++) {
       int t = t_base + 32 * n + col;
-      float m[4]; double s[4];
+      float m[4]; float s[4];
       m[0] = reg_max<0, 4>(acc[n]); m[1] = reg_max<4, 8>(acc[n]); m[2] = reg_max<8, 12>(acc[n]); m[3] = reg_max<12, 16>(acc[n]);
 #pragma unroll
       for (int q = 0; q < 4; q++) m[q] = fmaxf(m[q], __shfl_xor(m[q], 32));
       s[0] = reg_expsum<0, 4>(acc[n], m[0], m[0] + p.min_log_diff); s[1] = reg_expsum<4, 8>(acc[n], m[1], m[1] + p.min_log_diff);
       s[2] = reg_expsum<8, 12>(acc[n], m[2], m[2] + p.min_log_diff); s[3] = reg_expsum<12, 16>(acc[n], m[3], m[3] + p.min_log_diff);
 #pragma unroll
-      for (int q = 0; q < 4; q++) s[q] += shfl_xor_f64(s[q], 32);
+      for (int q = 0; q < 4; q++) s[q] += __shfl_xor(s[q], 32);
       if (h == 0 && t < T) {
 #pragma unroll
         for (int q = 0; q < 4; q++)
@@ -351,7 +365,7 @@ __global__ __launch_bounds__(64 * kWaves, kMinWaves) void gmm_kernel(GmmParams p
 #pragma unroll
     for (int n = 0; n < kNT; n++) {
       int t = t_base + 32 * n + col;
-      float m[4]; double s[4];
+      float m[4]; float s[4];
       m[0] = reg_max<0, 4>(acc[n]); m[1] = reg_max<4, 8>(acc[n]); m[2] = reg_max<8, 12>(acc[n]); m[3] = reg_max<12, 16>(acc[n]);
       s[0] = reg_expsum<0, 4>(acc[n], m[0], m[0] + p.min_log_diff); s[1] = reg_expsum<4, 8>(acc[n], m[1], m[1] + p.min_log_diff);
       s[2] = reg_expsum<8, 12>(acc[n], m[2], m[2] + p.min_log_diff); s[3] = reg_expsum<12, 16>(acc[n], m[3], m[3] + p.min_log_diff);
@@ -427,20 +441,20 @@ __global__ __launch_bounds__(256, 1) void gmm_sp_kernel(GmmParams p) {
     Tile<M8, NT>::load_gc32(p.gc + r0, h, g);
   };
   auto epilogue = [&](const f32x16 (&acc)[NT], int j) {
-    float mx[NT]; double sum[NT];
+    float mx[NT]; float sum[NT];
 #pragma unroll
     for (int n = 0; n < NT; n++) {
       float m = reg_max<0, 16>(acc[n]);
       m = fmaxf(m, swap32(m, h));
-      double s = reg_expsum<0, 16>(acc[n], m, m + p.min_log_diff);
-      s += swap32_f64(s, h);
+      float s = reg_expsum<0, 16>(acc[n], m, m + p.min_log_diff);
+      s += swap32(s, h);
       mx[n] = m; sum[n] = s;
     }
     // half h finishes tiles 2i+h
 #pragma unroll
     for (int i = 0; i < NT / 2; i++) {
       const float mxs = h ? mx[2 * i + 1] : mx[2 * i];
-      const double sums = h ? sum[2 * i + 1] : sum[2 * i];
+      const float sums = h ? sum[2 * i + 1] : sum[2 * i];
       const int t = t_base + 32 * (2 * i + h) + col;
       if (t < T) out[(size_t)t * P + j] = finish(mxs, sums);
     }
@@ -606,6 +620,7 @@ MFA_API int mfa_gmm_score_batch(mfa_ctx *c, const float *d_feats, const int64_t 
   p.class_counts = d_class_counts; p.ll_off = d_ll_off; p.out = d_loglikes;
   p.min_log_diff = logf(1.1920928955078125e-07f);
   p.skip_single = 0;
+  { const char *pr = getenv("MFA_GMM_PRIO"); p.prio = pr ? atoi(pr) : 0; }
   const char *naive = getenv("MFA_GMM_NAIVE");
   const int m8 = c->kpad / 8;
   KernelTimer kt(c, MFA_K_GMM);
@@ -633,7 +648,9 @@ MFA_API int mfa_gmm_score_batch(mfa_ctx *c, const float *d_feats, const int64_t 
     const int wg = wg_env ? atoi(wg_env) : 256;
     const int fpw = 32 * (nt == 2 ? 2 : 1);
     const int waves_per_wg = (nt == 2 && wg == 512) ? 8 : 4;
-    dim3 grid((max_frames + waves_per_wg * fpw - 1) / (waves_per_wg * fpw), n_utt);
+    p.n_utt = n_utt;
+    p.tiles = (max_frames + waves_per_wg * fpw - 1) / (waves_per_wg * fpw);
+    dim3 grid((unsigned)(((n_utt + 7) / 8) * 8 * p.tiles));
     if (nt == 2 && wg == 512) {
       if (m8 <= 10) hipLaunchKernelGGL((gmm_kernel<10, 2, 2, 8>), grid, dim3(512), 0, c->stream, p);
       else hipLaunchKernelGGL((gmm_kernel<12, 2, 2, 8>), grid, dim3(512), 0, c->stream, p);

@@ -280,118 +280,167 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
     // PossiblyResizeHash
     { u32 want = (u32)((float)n * kHashRatio); if (want > H) H = want; }
 
-    // ---------------- seed of the running cutoff: the best token's cheapest candidate.  With a single chunk it is
-    // taken from the expansion's registers below; otherwise computed here.
-    const bool single = n <= 64;
-    double run = INFINITY;  // min over candidate costs seen so far (seed + earlier candidates)
-    if (!single && best_i != kEmpty) {
-      const u32 ban = c_an[best_i];
-      const int a0 = (int)(ban >> 7), a1 = a0 + (int)(ban & 127u);
-      double m = INFINITY;
-      for (int a = a0 + lane; a < a1; a += 64) m = fmin(m, cand_cost(a_w[a], best, score(a_col[a]), p.scale));
-      run = wave_min_f64(m);
-    }
-
-    // ---------------- expand tokens in list order
+    // Candidate creation in three wavefront phases (each phase's LDS operations are issued back to back):
+    //   look up the destination's slot → claim missing slots (CAS; the winner allocates, initialises, publishes)
+    //   → re-read the published slot and lower its cost / first-creator with LDS atomics.
+    auto claim = [&](u32 d, u32 dan) {
+      u32 old = atomicCAS(&slot_of[d], kEmpty, kClaim);
+      if (old == kEmpty) {
+        u32 my = atomicAdd(&ctr[0], 1u);
+        if (my < (u32)N) { s_state[my] = d; s_an[my] = dan; s_cost[my] = kKeyInf; s_F[my] = kEmpty; s_W[my] = kEmpty; }
+        slot_of[d] = my;
+      }
+    };
+    auto lower = [&](u32 d, double cnw, u32 cidx) -> u32 {
+      u32 s = slot_of[d];
+      if (s >= (u32)N) return kEmpty;
+      atomicMin(&s_cost[s], dkey(cnw));
+      atomicMin(&s_F[s], cidx);
+      return s;
+    };
     u32 cand_base = 0;
     bool bad_degree = false;
-    bool used_stash = !single;
-    for (int c0 = 0; c0 < n; c0 += 64) {
-      const int i = c0 + lane;
-      const double cst = i < n ? c_cost[i] : INFINITY;
-      const bool act = i < n && cst < wcut;
-      int a0 = 0, narc = 0;
-      if (act) { const u32 an = c_an[i]; a0 = (int)(an >> 7); narc = (int)(an & 127u); }
-      if (narc > kMaxArcsPerState) bad_degree = true;
-      const int maxarc = (int)wave_max_u32((u32)narc);
-      if (maxarc > kArcCache) used_stash = true;
-      const u32 narc_incl = incl_scan_sum((u32)narc);
-      const u32 cb = cand_base + narc_incl - (u32)narc;
-      if (i < n) t_cbase[i] = cb;
-      cand_base += (u32)__builtin_amdgcn_readlane((int)narc_incl, 63);
-      // arcs → registers (independent loads, one round trip), then their scores (second round trip)
-      float w[kArcCache]; int col[kArcCache]; u32 nx[kArcCache]; u32 nan_[kArcCache]; double nw[kArcCache]; u32 sl[kArcCache];
-#pragma unroll
-      for (int k = 0; k < kArcCache; k++) {
-        w[k] = 0.0f; col[k] = 0; nx[k] = 0; nan_[k] = 0;
-        if (k < narc) { w[k] = a_w[a0 + k]; col[k] = a_col[a0 + k]; nx[k] = (u32)a_next[a0 + k]; nan_[k] = a_an[a0 + k]; }
+    bool used_stash = false;
+    bool fast = false;
+    // ---------------- fast path (the common case): at most 64 tokens and at most 64 candidates this frame → ONE
+    // candidate per lane.  The running cutoff is then a plain exclusive prefix-min across lanes, every candidate does one
+    // arc fetch, one slot lookup, one claim/lower, and the winner check comes straight from its registers.
+    if (n <= 64) {
+      const double cst = lane < n ? c_cost[lane] : INFINITY;
+      const u32 an = lane < n ? c_an[lane] : 0u;
+      const bool act = lane < n && cst < wcut;
+      const u32 narc = act ? (an & 127u) : 0u;
+      const u32 narc_incl = incl_scan_sum(narc);
+      const u32 cb = narc_incl - narc;
+      const u32 ctot = (u32)__builtin_amdgcn_readlane((int)narc_incl, 63);
+      if (ctot <= 64u) {
+        fast = true;
+        cand_base = ctot;
+        if (lane < n) t_cbase[lane] = cb;
+        s_aux[lane] = 0u;                       // s_aux is free until the ordering pass: owner map of the 64 ordinals
+        WSYNC();
+        if (narc > 0u) s_aux[cb] = (u32)lane + 1u;  // head of each token's candidate run
+        WSYNC();
+        const u32 tok1 = incl_scan_max(s_aux[lane]);
+        const bool valid = (u32)lane < ctot;
+        const u32 tok = valid ? tok1 - 1u : 0u;
+        const double tcost = c_cost[tok];
+        const u32 tan = c_an[tok];
+        const u32 k = valid ? (u32)lane - t_cbase[tok] : 0u;
+        const u32 a = (tan >> 7) + k;
+        float w = 0.0f; int col = 0; u32 nx = 0u, nan_ = 0u;
+        if (valid) { w = a_w[a]; col = a_col[a]; nx = (u32)a_next[a]; nan_ = a_an[a]; }
+        const double nw = valid ? cand_cost(w, tcost, score(col), p.scale) : INFINITY;
+        const double seed = wave_min_f64((valid && tok == best_i) ? nw : INFINITY);  // the best token's candidates
+        const double m_incl = incl_scan_min(nw);
+        const double local = fmin(seed, shift_in_min(m_incl));
+        const bool created = valid && nw < local + (double)abeam;
+        const u32 cidx = (tok << kArcBits) | k;
+        const u32 s0 = created ? slot_of[nx] : 0u;
+        if (created && s0 == kEmpty) claim(nx, nan_);
+        WSYNC();  // claims are published before anybody re-reads the map
+        const u32 sl = created ? lower(nx, nw, cidx) : kEmpty;
+        WSYNC();  // every candidate of the frame has lowered its slot's cost
+        if (sl != kEmpty && dkey(nw) == s_cost[sl]) atomicMin(&s_W[sl], cidx);
       }
-      double m = INFINITY;
-#pragma unroll
-      for (int k = 0; k < kArcCache; k++) {
-        nw[k] = (k < narc) ? cand_cost(w[k], cst, score(col[k]), p.scale) : INFINITY;
-        m = fmin(m, nw[k]);
-        sl[k] = kEmpty;
+    }
+    if (!fast) {
+      // ---------------- seed of the running cutoff: the best token's cheapest candidate.  With a single chunk it is
+      // taken from the expansion's registers below; otherwise computed here.
+      const bool single = n <= 64;
+      double run = INFINITY;  // min over candidate costs seen so far (seed + earlier candidates)
+      if (!single && best_i != kEmpty) {
+        const u32 ban = c_an[best_i];
+        const int a0 = (int)(ban >> 7), a1 = a0 + (int)(ban & 127u);
+        double m = INFINITY;
+        for (int a = a0 + lane; a < a1; a += 64) m = fmin(m, cand_cost(a_w[a], best, score(a_col[a]), p.scale));
+        run = wave_min_f64(m);
       }
-      for (int k = kArcCache; k < maxarc; k++)
-        if (k < narc) m = fmin(m, cand_cost(a_w[a0 + k], cst, score(a_col[a0 + k]), p.scale));
-      if (single) run = best_i != kEmpty ? readlane_f64(m, __builtin_amdgcn_readfirstlane((int)best_i)) : INFINITY;  // best token is always expanded
-      const double m_incl = incl_scan_min(m);
-      double local = fmin(run, shift_in_min(m_incl));
-      run = fmin(run, readlane_f64(m_incl, 63));
 
-      // Candidate creation in three wavefront phases (each phase's LDS operations are issued back to back):
-      //   look up the destination's slot → claim missing slots (CAS; the winner allocates, initialises, publishes)
-      //   → re-read the published slot and lower its cost / first-creator with LDS atomics.
-      auto claim = [&](u32 d, u32 dan) {
-        u32 old = atomicCAS(&slot_of[d], kEmpty, kClaim);
-        if (old == kEmpty) {
-          u32 my = atomicAdd(&ctr[0], 1u);
-          if (my < (u32)N) { s_state[my] = d; s_an[my] = dan; s_cost[my] = kKeyInf; s_F[my] = kEmpty; s_W[my] = kEmpty; }
-          slot_of[d] = my;
+      // ---------------- expand tokens in list order (general path: token per lane, arcs in a per-lane loop)
+      used_stash = !single;
+      for (int c0 = 0; c0 < n; c0 += 64) {
+        const int i = c0 + lane;
+        const double cst = i < n ? c_cost[i] : INFINITY;
+        const bool act = i < n && cst < wcut;
+        int a0 = 0, narc = 0;
+        if (act) { const u32 an = c_an[i]; a0 = (int)(an >> 7); narc = (int)(an & 127u); }
+        if (narc > kMaxArcsPerState) bad_degree = true;
+        const int maxarc = (int)wave_max_u32((u32)narc);
+        if (maxarc > kArcCache) used_stash = true;
+        const u32 narc_incl = incl_scan_sum((u32)narc);
+        const u32 cb = cand_base + narc_incl - (u32)narc;
+        if (i < n) t_cbase[i] = cb;
+        cand_base += (u32)__builtin_amdgcn_readlane((int)narc_incl, 63);
+        // arcs → registers (independent loads, one round trip), then their scores (second round trip)
+        float w[kArcCache]; int col[kArcCache]; u32 nx[kArcCache]; u32 nan_[kArcCache]; double nw[kArcCache]; u32 sl[kArcCache];
+  #pragma unroll
+        for (int k = 0; k < kArcCache; k++) {
+          w[k] = 0.0f; col[k] = 0; nx[k] = 0; nan_[k] = 0;
+          if (k < narc) { w[k] = a_w[a0 + k]; col[k] = a_col[a0 + k]; nx[k] = (u32)a_next[a0 + k]; nan_[k] = a_an[a0 + k]; }
         }
-      };
-      auto lower = [&](u32 d, double cnw, u32 cidx) -> u32 {
-        u32 s = slot_of[d];
-        if (s >= (u32)N) return kEmpty;
-        atomicMin(&s_cost[s], dkey(cnw));
-        atomicMin(&s_F[s], cidx);
-        return s;
-      };
-      bool cr[kArcCache]; u32 s0[kArcCache];
-#pragma unroll
-      for (int k = 0; k < kArcCache; k++) {
-        cr[k] = (k < narc) && (nw[k] < local + (double)abeam);
-        if (k < narc) local = fmin(local, nw[k]);
-        s0[k] = cr[k] ? slot_of[nx[k]] : 0u;
-      }
-#pragma unroll
-      for (int k = 0; k < kArcCache; k++)
-        if (k < maxarc && cr[k] && s0[k] == kEmpty) claim(nx[k], nan_[k]);
-      WSYNC();  // claims are published before anybody re-reads the map
-#pragma unroll
-      for (int k = 0; k < kArcCache; k++) {
-        if (k < maxarc) {  // uniform
-          sl[k] = cr[k] ? lower(nx[k], nw[k], ((u32)i << kArcBits) | (u32)k) : kEmpty;
-          if (!single && sl[k] != kEmpty) {
-            u32 q = atomicAdd(&ctr[1], 1u);
-            if (q < (u32)C) { st_a[q] = sl[k]; st_b[q] = ((u32)i << kArcBits) | (u32)k; st_key[q] = dkey(nw[k]); }
+        double m = INFINITY;
+  #pragma unroll
+        for (int k = 0; k < kArcCache; k++) {
+          nw[k] = (k < narc) ? cand_cost(w[k], cst, score(col[k]), p.scale) : INFINITY;
+          m = fmin(m, nw[k]);
+          sl[k] = kEmpty;
+        }
+        for (int k = kArcCache; k < maxarc; k++)
+          if (k < narc) m = fmin(m, cand_cost(a_w[a0 + k], cst, score(a_col[a0 + k]), p.scale));
+        if (single) run = best_i != kEmpty ? readlane_f64(m, __builtin_amdgcn_readfirstlane((int)best_i)) : INFINITY;  // best token is always expanded
+        const double m_incl = incl_scan_min(m);
+        double local = fmin(run, shift_in_min(m_incl));
+        run = fmin(run, readlane_f64(m_incl, 63));
+
+        // Candidate creation in three wavefront phases (each phase's LDS operations are issued back to back):
+        //   look up the destination's slot → claim missing slots (CAS; the winner allocates, initialises, publishes)
+        //   → re-read the published slot and lower its cost / first-creator with LDS atomics.
+        bool cr[kArcCache]; u32 s0[kArcCache];
+  #pragma unroll
+        for (int k = 0; k < kArcCache; k++) {
+          cr[k] = (k < narc) && (nw[k] < local + (double)abeam);
+          if (k < narc) local = fmin(local, nw[k]);
+          s0[k] = cr[k] ? slot_of[nx[k]] : 0u;
+        }
+  #pragma unroll
+        for (int k = 0; k < kArcCache; k++)
+          if (k < maxarc && cr[k] && s0[k] == kEmpty) claim(nx[k], nan_[k]);
+        WSYNC();  // claims are published before anybody re-reads the map
+  #pragma unroll
+        for (int k = 0; k < kArcCache; k++) {
+          if (k < maxarc) {  // uniform
+            sl[k] = cr[k] ? lower(nx[k], nw[k], ((u32)i << kArcBits) | (u32)k) : kEmpty;
+            if (!single && sl[k] != kEmpty) {
+              u32 q = atomicAdd(&ctr[1], 1u);
+              if (q < (u32)C) { st_a[q] = sl[k]; st_b[q] = ((u32)i << kArcBits) | (u32)k; st_key[q] = dkey(nw[k]); }
+            }
           }
         }
-      }
-      for (int k = kArcCache; k < maxarc; k++) {  // slow tail: states with more than kArcCache arcs
-        bool created = false; double cnw = 0.0; u32 d = 0, dan = 0;
-        if (k < narc) {
-          cnw = cand_cost(a_w[a0 + k], cst, score(a_col[a0 + k]), p.scale);
-          created = cnw < local + (double)abeam;
-          local = fmin(local, cnw);
-          d = (u32)a_next[a0 + k];
-          dan = a_an[a0 + k];
+        for (int k = kArcCache; k < maxarc; k++) {  // slow tail: states with more than kArcCache arcs
+          bool created = false; double cnw = 0.0; u32 d = 0, dan = 0;
+          if (k < narc) {
+            cnw = cand_cost(a_w[a0 + k], cst, score(a_col[a0 + k]), p.scale);
+            created = cnw < local + (double)abeam;
+            local = fmin(local, cnw);
+            d = (u32)a_next[a0 + k];
+            dan = a_an[a0 + k];
+          }
+          if (created && slot_of[d] == kEmpty) claim(d, dan);
+          WSYNC();
+          u32 s = created ? lower(d, cnw, ((u32)i << kArcBits) | (u32)k) : kEmpty;
+          if (s != kEmpty) {  // tail candidates always go through the stash
+            u32 q = atomicAdd(&ctr[1], 1u);
+            if (q < (u32)C) { st_a[q] = s; st_b[q] = ((u32)i << kArcBits) | (u32)k; st_key[q] = dkey(cnw); }
+          }
         }
-        if (created && slot_of[d] == kEmpty) claim(d, dan);
-        WSYNC();
-        u32 s = created ? lower(d, cnw, ((u32)i << kArcBits) | (u32)k) : kEmpty;
-        if (s != kEmpty) {  // tail candidates always go through the stash
-          u32 q = atomicAdd(&ctr[1], 1u);
-          if (q < (u32)C) { st_a[q] = s; st_b[q] = ((u32)i << kArcBits) | (u32)k; st_key[q] = dkey(cnw); }
+        if (single) {
+          WSYNC();  // every candidate of the frame has lowered its slot's cost
+          // winners straight from registers: earliest candidate among those that reached the slot's final best cost
+  #pragma unroll
+          for (int k = 0; k < kArcCache; k++)
+            if (sl[k] != kEmpty && dkey(nw[k]) == s_cost[sl[k]]) atomicMin(&s_W[sl[k]], ((u32)i << kArcBits) | (u32)k);
         }
-      }
-      if (single) {
-        WSYNC();  // every candidate of the frame has lowered its slot's cost
-        // winners straight from registers: earliest candidate among those that reached the slot's final best cost
-#pragma unroll
-        for (int k = 0; k < kArcCache; k++)
-          if (sl[k] != kEmpty && dkey(nw[k]) == s_cost[sl[k]]) atomicMin(&s_W[sl[k]], ((u32)i << kArcBits) | (u32)k);
       }
     }
     // the stash lives in HBM: make its stores visible before other lanes read them back (workgroup-scope fence waits for

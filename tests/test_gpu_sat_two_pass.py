@@ -61,29 +61,31 @@ def test_two_pass_fmllr_recovers_speaker_distortion(engine):
         res = engine.align(graphs, ll, ll_off, ll_cols, frame_off, beam=10.0, retry_beam=40.0, max_tokens=512)
         return feats, frame_off, res
 
-    # pass 1: speaker-independent alignment of the distorted features
-    feats1, frame_off, res1 = align_with(distort)
-    st1 = res1["status"].cpu().numpy()
-    assert np.all((st1 == 0) | (st1 == 1)), st1
-    like1 = res1["like"].cpu().numpy() / 1000.0
     sil = [world.lexicon.phone_table.find("sil"), world.lexicon.phone_table.find("spn")]
-    spk_ids, beta, K, Gm = fmllr_statistics(engine, feats1, frame_off, res1["ali"], model.tm, u2s, sil)
-    assert spk_ids.tolist() == list(range(n_spk)) and np.all(beta > 1500)  # silence frames carry no weight
-    solved = [F.compute_fmllr(beta[s], K[s], Gm[s]) for s in range(n_spk)]
-    assert all(impr > 0.0 for _, impr in solved)  # the auxiliary function (which carries the log-det term) rises
-    est = np.stack([w for w, _ in solved])
-    total = np.stack([_compose(est[s], distort[s]) for s in range(n_spk)])
-    # pass 2 with the adapted features
-    _feats2, _fo, res2 = align_with(total)
-    st2 = res2["status"].cpu().numpy()
-    assert np.all((st2 == 0) | (st2 == 1))
-    like2 = res2["like"].cpu().numpy() / 1000.0
-    # the decoder's likelihood has no Jacobian term, so it need not rise by much — but it must not get worse
-    assert like2.mean() > like1.mean() - 0.25, (like1.mean(), like2.mean())
-    # the adapted features sit closer to the undistorted ones (variance-normalised squared distance per frame/dim)
-    clean, _ = lda_feats([u[0] for u in utts])
-    clean = clean.cpu().numpy()
-    var = clean.var(axis=0)
-    d_before = (((feats1.cpu().numpy() - clean) ** 2) / var).mean()
-    d_after = (((_feats2.cpu().numpy() - clean) ** 2) / var).mean()
-    assert d_after < 0.6 * d_before, (d_before, d_after)
+    identity = np.stack([np.concatenate([np.eye(40), np.zeros((40, 1))], axis=1)] * n_spk).astype(np.float32)
+
+    def two_pass(pre):
+        """pass 1 on features pre-transformed by `pre` → statistics → solve → pass 2 with (estimate ∘ pre)."""
+        feats1, frame_off, res1 = align_with(pre)
+        st1 = res1["status"].cpu().numpy()
+        assert np.all((st1 == 0) | (st1 == 1)), st1
+        spk_ids, beta, K, Gm = fmllr_statistics(engine, feats1, frame_off, res1["ali"], model.tm, u2s, sil)
+        assert spk_ids.tolist() == list(range(n_spk)) and np.all(beta > 1500)  # silence frames carry no weight
+        solved = [F.compute_fmllr(beta[s], K[s], Gm[s]) for s in range(n_spk)]
+        assert all(impr > 0.0 for _, impr in solved)  # the auxiliary function (it carries the log-det term) rises
+        total = np.stack([_compose(solved[s][0], pre[s]) for s in range(n_spk)])
+        feats2, _fo, res2 = align_with(total)
+        st2 = res2["status"].cpu().numpy()
+        assert np.all((st2 == 0) | (st2 == 1))
+        # (the decoder's likelihood carries no Jacobian term, so it may move either way: the objective that must rise
+        #  is the auxiliary function checked above)
+        return feats1.cpu().numpy(), feats2.cpu().numpy()
+
+    # fMLLR moves every speaker towards the speaker-independent model's space, so the adapted features must come out
+    # (nearly) the same whether or not the input was distorted: adapt(D·x) ≈ adapt(x), although D·x is far from x.
+    clean1, clean2 = two_pass(identity)
+    dist1, dist2 = two_pass(distort)
+    var = clean2.var(axis=0)
+    d_in = (((dist1 - clean1) ** 2) / var).mean()
+    d_out = (((dist2 - clean2) ** 2) / var).mean()
+    assert d_out < 0.5 * d_in, (d_in, d_out)
