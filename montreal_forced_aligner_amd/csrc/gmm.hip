@@ -214,73 +214,76 @@ __global__ __launch_bounds__(64 * kWaves, kMinWaves) void gmm_kernel(GmmParams p
   float *stage = stage_all[wave];
   const int n_single = cc6[0];
 
-  // ---- slot 32 (one pdf per block; pdfs with more than 32 Gaussians take several blocks, two passes).
-  // Software pipeline: the A rows of block j+1 are requested right after block j's last MFMA has been issued (its
-  // operand registers are dead by then), so their L2 latency hides under block j's log-sum-exp epilogue.
-  const int n32 = cc[0];
-  f32x4 a_next[M8];
-  f32x4 gc_next[4];
-  int nb_next = 0, r0_next = 0;
-  auto request = [&](int jj) {
-    const int pdf = list[jj];
-    r0_next = p.row0[pdf];
-    nb_next = p.nblk[pdf];
-    if (nb_next == 1) {
-      Tile<M8, kNT>::load_a(p.w + (size_t)(r0_next + col) * p.kpad + 4 * h, a_next);
-      Tile<M8, kNT>::load_gc32(p.gc + r0_next, h, gc_next);
+  // ---- single-block 32-row pdfs (the bulk of a context-dependent model): one pdf per MFMA block.
+  // Software pipeline, no extra registers: as soon as the MFMAs that read operand group a[m] of block j have been issued,
+  // the same registers are re-loaded with block j+1's rows, so every load has a whole block period (≈5k cycles of MFMA
+  // issue plus the epilogue) to come back from L2 / Infinity Cache.  The packed-row lookups (pdf id → first row) run
+  // two and three blocks ahead, so they never sit on the critical path.
+  // (Round-1 measurements, tools/mfma_f32_microbench2.hip: operands requested just in time 116 TFLOP/s, one block
+  // ahead 143 TFLOP/s.)
+  if (n_single > first32) {
+    const int last = n_single - 1;
+    auto pdf_at = [&](int jj) { return __builtin_amdgcn_readfirstlane(list[min(jj, last)]); };
+    auto row_of = [&](int pdf) { return __builtin_amdgcn_readfirstlane(p.row0[pdf]); };
+    const float *wl = p.w + (size_t)col * p.kpad + 4 * h;  // this lane's row within a block, k offset of its half
+    f32x4 a[M8], g[4];
+    int r1 = row_of(pdf_at(first32 + 1));
+    int pdf2 = pdf_at(first32 + 2);
+    {
+      const int r0 = row_of(pdf_at(first32));
+      // same issue order as inside the loop (gconst rows, then operand groups): the compiler's vmcnt bookkeeping at the
+      // loop head is the merge of both paths, and a different order here makes it wait for every outstanding load
+      Tile<M8, kNT>::load_gc32(p.gc + r0, h, g);
+      __builtin_amdgcn_sched_barrier(0);
+      Tile<M8, kNT>::load_a(wl + (size_t)r0 * p.kpad, a);
+      __builtin_amdgcn_sched_barrier(0);
     }
-  };
-  if (n32 > first32) request(first32);
-  for (int j = first32; j < n32; j++) {
-    const int r0 = r0_next, nb = nb_next;
-    float mx[kNT]; float sum[kNT];
-    if (nb == 1) {
-      tile.run32(a_next, gc_next, acc);
-      if (j + 1 < n32) request(j + 1);
+    for (int j = first32; j < n_single; j++) {
+      {
+        f32x16 init;
+#pragma unroll
+        for (int r = 0; r < 16; r++) init[r] = g[r >> 2][r & 3];
+#pragma unroll
+        for (int n = 0; n < kNT; n++) acc[n] = init;
+      }
+      // The lookups are vector loads (the compiler cannot prove the lists are not aliased by `out`), issued first so that
+      // they are the oldest entries of the in-order vmcnt queue: reading them back after the MFMA phase then waits for
+      // nothing younger.
+      const int x_r2 = p.row0[pdf2];
+      const int x_pdf3 = list[min(j + 3, last)];
+      __builtin_amdgcn_sched_barrier(0);
+      const float *wn = wl + (size_t)r1 * p.kpad;
+      Tile<M8, kNT>::load_gc32(p.gc + r1, h, g);
+#pragma unroll
+      for (int m = 0; m < M8; m++) {
+#pragma unroll
+        for (int cc4 = 0; cc4 < 4; cc4++) {
+#pragma unroll
+          for (int n = 0; n < kNT; n++)
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][cc4], tile.b[n][4 * m + cc4], acc[n], 0, 0, 0);
+        }
+        a[m] = *reinterpret_cast<const f32x4 *>(wn + 8 * m);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      r1 = __builtin_amdgcn_readfirstlane(x_r2);
+      pdf2 = __builtin_amdgcn_readfirstlane(x_pdf3);
+      float mx[kNT], sum[kNT];
 #pragma unroll
       for (int n = 0; n < kNT; n++) {
         float m = reg_max<0, 16>(acc[n]);
         m = fmaxf(m, swap32(m, h));
-        float s = reg_expsum<0, 16>(acc[n], m, m + p.min_log_diff);
-        s += swap32(s, h);
-        mx[n] = m; sum[n] = s;
+        float sv = reg_expsum<0, 16>(acc[n], m, m + p.min_log_diff);
+        sv += swap32(sv, h);
+        mx[n] = m; sum[n] = sv;
       }
-    } else {
-#pragma unroll
-      for (int n = 0; n < kNT; n++) { mx[n] = -INFINITY; sum[n] = 0.0f; }
-      for (int blk = 0; blk < nb; blk++) {
-        const int rr = r0 + 32 * blk + col;
-        tile.block(p.w + (size_t)rr * p.kpad + 4 * h, p.gc[rr], lane, acc);
-#pragma unroll
-        for (int n = 0; n < kNT; n++) {
-          float m = reg_max<0, 16>(acc[n]);
-          m = fmaxf(m, __shfl_xor(m, 32));
-          mx[n] = fmaxf(mx[n], m);
-        }
-      }
-      for (int blk = 0; blk < nb; blk++) {
-        const int rr = r0 + 32 * blk + col;
-        tile.block(p.w + (size_t)rr * p.kpad + 4 * h, p.gc[rr], lane, acc);
-#pragma unroll
-        for (int n = 0; n < kNT; n++) {
-          float s = reg_expsum<0, 16>(acc[n], mx[n], mx[n] + p.min_log_diff);
-          s += swap32(s, h);
-          sum[n] += s;
-        }
-      }
-      if (j + 1 < n32) request(j + 1);
-    }
-    // both halves hold every tile's (max, sum): with two tiles half h finishes tile h (one log per lane)
-    if constexpr (kNT == 2) {
-      const float mxs = h ? mx[1] : mx[0];
-      const float sums = h ? sum[1] : sum[0];
-      const float v = finish(mxs, sums);
-      if (j < n_single) {
+      if constexpr (kNT == 2) {
+        // both halves hold every tile's (max, sum): half h finishes tile h (one log per lane).
         // Stage [64 frames][32 pdfs] in LDS and flush whole 128-byte row segments: a lane-per-frame store would touch 64
         // different lines per instruction and (measured, round 1) inflate HBM write traffic 11x with partial lines.
+        const float v = finish(h ? mx[1] : mx[0], h ? sum[1] : sum[0]);
         const int jj = (j - first32) & 31;
         stage[(32 * h + col) * 33 + jj] = v;
-        if (jj == 31 || j + 1 == n_single) {
+        if (jj == 31 || j == last) {
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -297,15 +300,47 @@ __global__ __launch_bounds__(64 * kWaves, kMinWaves) void gmm_kernel(GmmParams p
           __builtin_amdgcn_wave_barrier();
         }
       } else {
-        const int t = t_base + 32 * h + col;
-        if (t < T) out[(size_t)t * P + j] = v;
+#pragma unroll
+        for (int n = 0; n < kNT; n++) {
+          const int t = t_base + 32 * n + col;
+          if (h == (n & 1) && t < T) out[(size_t)t * P + j] = finish(mx[n], sum[n]);
+        }
       }
-    } else {
+    }
+  }
+
+  // ---- 32-row pdfs with more than 32 Gaussians: several blocks, two passes (max, then the sum against that max)
+  const int n32 = cc[0];
+  for (int j = max(first32, n_single); j < n32; j++) {
+    const int pdf = list[j];
+    const int r0 = p.row0[pdf], nb = p.nblk[pdf];
+    float mx[kNT], sum[kNT];
+#pragma unroll
+    for (int n = 0; n < kNT; n++) { mx[n] = -INFINITY; sum[n] = 0.0f; }
+    for (int blk = 0; blk < nb; blk++) {
+      const int rr = r0 + 32 * blk + col;
+      tile.block(p.w + (size_t)rr * p.kpad + 4 * h, p.gc[rr], lane, acc);
 #pragma unroll
       for (int n = 0; n < kNT; n++) {
-        const int t = t_base + 32 * n + col;
-        if (h == (n & 1) && t < T) out[(size_t)t * P + j] = finish(mx[n], sum[n]);
+        float m = reg_max<0, 16>(acc[n]);
+        m = fmaxf(m, __shfl_xor(m, 32));
+        mx[n] = fmaxf(mx[n], m);
       }
+    }
+    for (int blk = 0; blk < nb; blk++) {
+      const int rr = r0 + 32 * blk + col;
+      tile.block(p.w + (size_t)rr * p.kpad + 4 * h, p.gc[rr], lane, acc);
+#pragma unroll
+      for (int n = 0; n < kNT; n++) {
+        float sv = reg_expsum<0, 16>(acc[n], mx[n], mx[n] + p.min_log_diff);
+        sv += swap32(sv, h);
+        sum[n] += sv;
+      }
+    }
+#pragma unroll
+    for (int n = 0; n < kNT; n++) {
+      const int t = t_base + 32 * n + col;
+      if (h == (n & 1) && t < T) out[(size_t)t * P + j] = finish(mx[n], sum[n]);
     }
   }
 
