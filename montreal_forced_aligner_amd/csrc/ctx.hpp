@@ -34,7 +34,8 @@ struct mfa_ctx {
   float *d_window = nullptr;   // [win]
   float *d_twiddle = nullptr;  // [nfft/2][2] cos,sin of -2*pi*k/nfft ... see mfcc.hip
   float *d_melw = nullptr;     // [nbins][2] packed sparse: see mfcc.hip
-  int32_t *d_melidx = nullptr;
+  int32_t *d_melidx = nullptr;  // [64][4] per-lane filterbank plan, see mfcc.hip
+  int n_melw = 0;
   float *d_dct = nullptr;      // [nceps][nbins] with lifter folded separately
   float *d_lifter = nullptr;   // [nceps]
 

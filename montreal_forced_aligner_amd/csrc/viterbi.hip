@@ -20,6 +20,9 @@
 #include <cmath>
 #include <cstdint>
 
+#include <algorithm>
+#include <vector>
+
 #include "ctx.hpp"
 
 namespace {
@@ -36,7 +39,7 @@ constexpr float kHashRatio = 2.0f;
 constexpr int kArcBits = 6;               // at most 64 arcs per state
 constexpr int kMaxArcsPerState = 1 << kArcBits;
 
-enum { ST_OK = 0, ST_RETRIED = 1, ST_FAILED = 2, ST_TOKEN_OVERFLOW = 3, ST_BP_OVERFLOW = 4, ST_UNSUPPORTED = 5, ST_INTERNAL = 6, ST_PENDING = -1 };
+enum { ST_OK = 0, ST_RETRIED = 1, ST_FAILED = 2, ST_TOKEN_OVERFLOW = 3, ST_BP_OVERFLOW = 4, ST_UNSUPPORTED = 5, ST_INTERNAL = 6, ST_PENDING = -1, ST_GROW = -2 };
 
 struct VitParams {
   mfa_graph_batch g;
@@ -46,6 +49,7 @@ struct VitParams {
   const int32_t *utt_list;    // utterances to decode (NULL: identity)
   const int32_t *n_list;      // number of entries in utt_list (device scalar) or NULL
   int pass;                   // 0 first beam, 1 retry
+  int grow;                   // 1: a token/candidate overflow is not final — the utterance is re-run with larger tables
   // workspace
   u32 *w_state; double *w_cost;        // [n_utt][2][nmax]
   u32 *w_stash_a; u64 *w_stash_key;    // [n_utt][cmax]: (slot<<32|cidx) packed in stash_a pair → two arrays
@@ -560,7 +564,8 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
   if (out_status != ST_OK) {
     if (lane == 0) {
       // a first-pass failure stays pending for the retry pass; other codes are final
-      p.status[utt] = (p.pass == 0 && out_status == ST_FAILED) ? ST_PENDING : out_status;
+      p.status[utt] = (p.pass == 0 && out_status == ST_FAILED) ? ST_PENDING
+                      : (p.grow && out_status == ST_TOKEN_OVERFLOW) ? ST_GROW : out_status;
       p.n_words[utt] = 0; p.like[utt] = 0.0f;
     }
     return;
@@ -621,9 +626,9 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
 }
 
 // Build the retry list: utterances left pending by the first pass.
-__global__ void collect_pending_kernel(const int32_t *status, int n_utt, int32_t *list, int32_t *count) {
+__global__ void collect_pending_kernel(const int32_t *status, int n_utt, int code, int32_t *list, int32_t *count) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n_utt && status[i] == ST_PENDING) list[atomicAdd(count, 1)] = i;
+  if (i < n_utt && status[i] == code) list[atomicAdd(count, 1)] = i;
 }
 __global__ void finalize_pending_kernel(int32_t *status, int n_utt) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -724,35 +729,52 @@ MFA_API int mfa_align_batch(mfa_ctx *c, const mfa_graph_batch *g, const float *d
   }
   unsigned char *base = (unsigned char *)c->d_ws;
   hipLaunchKernelGGL(arcnext_kernel, dim3(n_utt), dim3(256), 0, c->stream, *g, (u32 *)(base + w.arcnext));
-  for (int ps = 0; ps < passes; ps++) {
+  // Launch plan.  The decoder is latency-bound (one wavefront walks one utterance frame by frame), so throughput is the
+  // number of wavefronts a CU can keep resident, and that is set by the LDS tables, which scale with the token capacity.
+  // With the normal beam a frame rarely holds more than a few dozen tokens, so every utterance is first decoded with
+  // small tables (kSmallTokens); the few that overflow them are marked ST_GROW and decoded again, from scratch and with
+  // the same beam, at the caller's full capacity.  Then the retry-beam pass for utterances that did not reach a final state.
+  struct Launch { int pass, N, C, code, grow; };
+  std::vector<Launch> plan;
+  constexpr int kSmallTokens = 128;
+  if (N[0] > kSmallTokens) {
+    int cs = std::min(C[0], 4 * kSmallTokens);
+    plan.push_back({0, kSmallTokens, cs, 0, 1});
+    plan.push_back({0, N[0], C[0], ST_GROW, 0});
+  } else {
+    plan.push_back({0, N[0], C[0], 0, 0});
+  }
+  if (passes == 2) plan.push_back({1, N[1], C[1], ST_PENDING, 0});
+  for (Launch &L : plan) {
+    const int ps = L.pass;
     // token lists in LDS when everything fits comfortably; in HBM for big graphs / the wide retry beam; and if even the
     // atomically updated tables do not fit, shrink the token capacity (an overflow is then reported per utterance)
-    bool lists_in_lds = lds_bytes(max_states, N[ps], C[ps], true) <= kLdsLimit / 2 ||
-                        (ps == 0 && lds_bytes(max_states, N[ps], C[ps], true) <= kLdsLimit);
-    while (lds_bytes(max_states, N[ps], C[ps], lists_in_lds) > kLdsLimit && N[ps] > 64) {
-      N[ps] = (N[ps] / 2 + 63) & ~63;
-      if (C[ps] > 8 * N[ps]) C[ps] = 8 * N[ps];
+    bool lists_in_lds = lds_bytes(max_states, L.N, L.C, true) <= kLdsLimit / 2 ||
+                        (ps == 0 && lds_bytes(max_states, L.N, L.C, true) <= kLdsLimit);
+    while (lds_bytes(max_states, L.N, L.C, lists_in_lds) > kLdsLimit && L.N > 64) {
+      L.N = (L.N / 2 + 63) & ~63;
+      if (L.C > 8 * L.N) L.C = 8 * L.N;
     }
-    size_t lds = lds_bytes(max_states, N[ps], C[ps], lists_in_lds);
-    if (lds > kLdsLimit) return c->fail("Viterbi tables need %zu bytes of LDS (> 160 KiB): %d states, %d tokens", lds, max_states, N[ps]);
+    size_t lds = lds_bytes(max_states, L.N, L.C, lists_in_lds);
+    if (lds > kLdsLimit) return c->fail("Viterbi tables need %zu bytes of LDS (> 160 KiB): %d states, %d tokens", lds, max_states, L.N);
     VitParams p;
     p.g = *g; p.ll = d_loglikes; p.ll_off = d_ll_off; p.ll_cols = d_ll_cols; p.frame_off = d_frame_off;
     p.beam = ps == 0 ? o->beam : o->retry_beam; p.scale = o->acoustic_scale;
-    p.nmax = N[ps]; p.cmax = C[ps]; p.bpf = bpf; p.pass = ps;
-    // workspace strides follow this pass's capacities (lists and stash are per-pass scratch)
-    WsLayout wp = ws_layout(n_utt, total_frames, N[ps], C[ps], bpf, total_arcs);
+    p.nmax = L.N; p.cmax = L.C; p.bpf = bpf; p.pass = ps; p.grow = L.grow;
+    // workspace strides follow this launch's capacities (lists and stash are per-launch scratch)
+    WsLayout wp = ws_layout(n_utt, total_frames, L.N, L.C, bpf, total_arcs);
     p.w_state = (u32 *)(base + wp.state); p.w_cost = (double *)(base + wp.cost);
     p.w_stash_a = (u32 *)(base + wp.sta); p.w_stash_b = (u32 *)(base + wp.stb); p.w_stash_key = (u64 *)(base + wp.stkey);
     p.w_bp = (u64 *)(base + wp.bp); p.w_tokoff = (u32 *)(base + wp.tokoff);
-    p.w_hash = (u32 *)(base + w.hash);     // fixed location across passes
+    p.w_hash = (u32 *)(base + w.hash);     // fixed location across launches
     p.w_arcnext = (const u32 *)(base + w.arcnext);
     p.llcap = kLlCap;
     int32_t *d_list = (int32_t *)(base + w.list), *d_count = (int32_t *)(base + w.count);
     p.utt_list = nullptr; p.n_list = nullptr;
     p.ali = d_ali; p.words = d_words; p.n_words = d_n_words; p.like = d_like; p.frame_like = d_frame_like; p.status = d_status;
-    if (ps == 1) {
+    if (L.code != 0) {
       MFA_HIP_CHECK(c, hipMemsetAsync(d_count, 0, sizeof(int32_t), c->stream));
-      hipLaunchKernelGGL(collect_pending_kernel, dim3((n_utt + 255) / 256), dim3(256), 0, c->stream, d_status, n_utt, d_list, d_count);
+      hipLaunchKernelGGL(collect_pending_kernel, dim3((n_utt + 255) / 256), dim3(256), 0, c->stream, d_status, n_utt, L.code, d_list, d_count);
       p.utt_list = d_list; p.n_list = d_count;
     }
     {
