@@ -45,6 +45,8 @@ def parse_args():
     ap.add_argument("--cpu-sample", type=int, default=0, help="utterances for the CPU baseline (0 = 2 per core)")
     ap.add_argument("--max-tokens", type=int, default=256)
     ap.add_argument("--bp-tokens", type=int, default=128)
+    ap.add_argument("--reachability", type=int, default=1,
+                    help="1: score a pdf only from the first frame the decoder can ask for it (default); 0: dense matrix")
     ap.add_argument("--streams", type=int, default=1, help="split the batch over this many HIP streams (stage overlap)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo to rehearse "
                                                            "several ranks on one GPU)")
@@ -205,7 +207,8 @@ def main():
             ids_k, inv_k = np.unique(utt_spk[lo:hi], return_inverse=True)
             fm_k = None if mono else torch.from_numpy(fm_np[ids_k % n_spk_total]).to(dev)
             pipes.append(Pipeline(engines[k], pcm_k, so_k, inv_k.astype(np.int32), g_k, lda=d_lda, fmllr=fm_k,
-                                  max_tokens=args.max_tokens, bp_tokens_per_frame=args.bp_tokens))
+                                  max_tokens=args.max_tokens, bp_tokens_per_frame=args.bp_tokens,
+                                  reachability=bool(args.reachability)))
     torch.cuda.synchronize()
 
     class _Multi:
@@ -230,6 +233,26 @@ def main():
         if world > 1:
             dist.barrier()
 
+    if os.environ.get("MFA_BENCH_FILL"):  # diagnostic: how much of the score matrix does one step write?
+        for p_ in pipes:
+            p_.loglikes.zero_()
+        pipe.step()
+        torch.cuda.synchronize()
+        for p_ in pipes:
+            nz = int((p_.loglikes != 0).sum().item())
+            log(rank, f"score cells written: {nz}/{p_.loglikes.numel()} = {nz / p_.loglikes.numel():.4f}")
+    if os.environ.get("MFA_GMM_TRACE"):  # diagnostic: per-wavefront timeline of one scoring launch → .npy
+        import ctypes as C
+        p_ = pipes[0]
+        tiles = (p_.max_frames + 255) // 256
+        trace = torch.zeros(p_.n_utt * tiles * 4 * 4, dtype=torch.int64, device=dev)
+        pipe.step()
+        torch.cuda.synchronize()
+        eng.lib.mfa_debug_gmm_trace(eng.ctx, C.c_void_p(trace.data_ptr()))
+        pipe.step()
+        torch.cuda.synchronize()
+        eng.lib.mfa_debug_gmm_trace(eng.ctx, None)
+        np.save(os.environ["MFA_GMM_TRACE"], trace.cpu().numpy().reshape(p_.n_utt, tiles * 4, 4))
     for _ in range(args.warmup):
         pipe.step()
     torch.cuda.synchronize()
@@ -283,6 +306,7 @@ def main():
             "batch_per_gpu": B, "utterances_total": total_utts, "distinct_utterances_per_gpu": args.pool,
             "frames_per_utt": int(pipe.max_frames), "parallelism": f"utterance-sharded x{world}, no collective",
             "streams_per_gpu": n_streams,
+            "scores": "reachable cells only (pdf j from its first possible frame on)" if args.reachability else "dense T x P",
         },
         "real_time_factor": dt / (pipe.audio_seconds * args.steps * world),
         "aligned_fraction": n_ok / B, **({"diagnostic_variant": os.environ["MFA_GMM_DIAG"]} if diagnostic else {}),
@@ -359,8 +383,10 @@ def tile_graphs(eng, packed_pool, fsts, idx):
     lists = [packed_pool.pdf_lists_host[i] for i in idx]
     pdf_off = np.concatenate([[0], np.cumsum([len(p) for p in lists])]).astype(np.int64)
     cc = packed_pool.class_counts.cpu().numpy()[idx]
+    ffs = [packed_pool.pdf_first_frame_host[i] for i in idx]
     return PackedGraphs(n, int(S.max()), int(A.max()), int(A.sum()), tensors, eng._dev(np.concatenate(lists).astype(np.int32)),
-                        eng._dev(pdf_off), eng._dev(cc.astype(np.int32)), pdf_off, lists)
+                        eng._dev(pdf_off), eng._dev(cc.astype(np.int32)), pdf_off, lists,
+                        eng._dev(np.concatenate(ffs).astype(np.int32)), ffs)
 
 
 if __name__ == "__main__":

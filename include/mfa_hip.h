@@ -106,14 +106,37 @@ MFA_API int32_t mfa_gmm_slot(mfa_ctx *ctx, int32_t pdf);
 /* Sort h_pdfs[n] in place into the order the scoring kernels require; h_class_counts[6] receives how many pdfs fall in
  * the classes {32 rows single block, 32 rows multi-block (>32 Gaussians), 16, 8, 4, 1}. */
 MFA_API int mfa_gmm_sort_pdf_list(mfa_ctx *ctx, int32_t *h_pdfs, int32_t n, int32_t *h_class_counts);
+/* Same, with a per-pdf key (h_first_frame[n], permuted along): inside each class the pdfs are ordered by ascending key.
+ * With key = first frame at which the decoder can ask for the pdf (mfa_fst_first_frames + a min over the arcs that emit
+ * it), the pdfs a given frame range needs form a PREFIX of every class, which is what mfa_gmm_score_batch's
+ * d_pdf_first_frame argument relies on. */
+MFA_API int mfa_gmm_sort_pdf_list_keyed(mfa_ctx *ctx, int32_t *h_pdfs, int32_t *h_first_frame, int32_t n,
+                                        int32_t *h_class_counts);
+/* Host helper: h_depth[s] = the smallest number of arcs on a path from `start` to state s of an epsilon-free graph in
+ * CSR form (arc_off[n_states+1], arc_next[n_arcs]); INT32_MAX for unreachable states.  A decoder token can sit on s at
+ * frame t only if h_depth[s] <= t (FasterDecoder consumes one frame per arc; kaldi decoder/faster-decoder.cc
+ * ProcessEmitting), so an arc leaving s is never scored before frame h_depth[s]. */
+MFA_API int mfa_fst_first_frames(int32_t n_states, const int32_t *h_arc_off, const int32_t *h_arc_next, int32_t start,
+                                 int32_t *h_depth);
 
 /* ---- Acoustic scoring: replaces DecodableAmDiagGmmScaled::LogLikelihood inside GmmAligner.align_utterance and
  *      gmm_compute_likes (MFA/alignment/multiprocessing.py:846-853, :1415).
  * Per utterance u: pdf list d_pdf_list[pdf_off[u]..pdf_off[u+1]) (sorted as above) with d_class_counts[u][6];
  * output d_loglikes + ll_off[u]: float32 [T_u][P_u] row-major (UNSCALED log-likelihoods). */
+/* d_pdf_first_frame (may be NULL): int32 parallel to d_pdf_list, ascending inside every class of every utterance
+ * (mfa_gmm_sort_pdf_list_keyed).  When given, cell (t, j) is only guaranteed to be written if
+ * d_pdf_first_frame[j] <= t rounded up to the end of its 64-frame tile: Kaldi's decodable is evaluated lazily, for the
+ * arcs leaving live tokens only, and no token can ask for pdf j before that frame — the skipped cells are never read by
+ * mfa_align_batch.  NULL scores every cell (what gmm_compute_likes-style callers want). */
 MFA_API int mfa_gmm_score_batch(mfa_ctx *ctx, const float *d_feats, const int64_t *d_frame_off, int32_t n_utt,
                                 int32_t max_frames, const int32_t *d_pdf_list, const int64_t *d_pdf_off,
-                                const int32_t *d_class_counts, const int64_t *d_ll_off, float *d_loglikes);
+                                const int32_t *d_class_counts, const int32_t *d_pdf_first_frame, const int64_t *d_ll_off,
+                                float *d_loglikes);
+
+/* Debug/profiling aid: when d_trace is non-NULL the scoring kernel records, for every (utterance u, 64-frame sub-tile r)
+ * it scores, four uint64 words {start, end (100 MHz wall clock), hardware id (HW_ID | XCC_ID << 32), 32-row blocks
+ * walked} at d_trace[((u * tiles) * 4 + r) * 4], tiles = ceil(max_frames / 256).  NULL turns it off. */
+MFA_API int mfa_debug_gmm_trace(mfa_ctx *ctx, void *d_trace);
 
 /* ---- Alignment: replaces GmmAligner.align_utterance(fst, feats) / .export_alignments
  *      (MFA/alignment/multiprocessing.py:846-853, :1311-1315; MFA/online/alignment.py:107) = Kaldi AddTransitionProbs

@@ -55,7 +55,7 @@ def build_native(force: bool = False, verbose: bool = False) -> Path:
         return _SO
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
-           "-fvisibility=hidden", "-o", str(_SO)] + [str(s) for s in srcs]
+           "-fvisibility=hidden"] + os.environ.get("MFA_HIPCC_FLAGS", "").split() + ["-o", str(_SO)] + [str(s) for s in srcs]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
@@ -88,7 +88,10 @@ SIGNATURES = {
     "mfa_load_gmm": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp]),
     "mfa_gmm_slot": (_i32, [_vp, _i32]),
     "mfa_gmm_sort_pdf_list": (C.c_int, [_vp, _vp, _i32, _vp]),
-    "mfa_gmm_score_batch": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "mfa_gmm_sort_pdf_list_keyed": (C.c_int, [_vp, _vp, _vp, _i32, _vp]),
+    "mfa_fst_first_frames": (C.c_int, [_i32, _vp, _vp, _i32, _vp]),
+    "mfa_debug_gmm_trace": (C.c_int, [_vp, _vp]),
+    "mfa_gmm_score_batch": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mfa_align_batch": (C.c_int, [_vp, C.POINTER(GraphBatch), _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, C.POINTER(AlignOpts),
                                   _vp, _vp, _vp, _vp, _vp, _vp]),
     "mfa_fmllr_acc_batch": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),

@@ -49,6 +49,9 @@ struct mfa_ctx {
   int32_t *d_slot = nullptr;   // [num_pdfs] slot class rows (1,4,8,16,32)
   std::vector<int32_t> h_slot, h_nblk;
   int32_t *d_nrows = nullptr;  // [num_pdfs] packed rows per pdf (fmllr.hip)
+  int *d_gmm_queue = nullptr;  // [8] per-XCD work-item counters of the persistent scoring kernel
+  int num_cus = 0;
+  void *gmm_trace = nullptr;   // debug: per-wavefront timeline records of the scoring kernel (mfa_debug_gmm_trace)
 
   // Viterbi workspace
   void *d_ws = nullptr;

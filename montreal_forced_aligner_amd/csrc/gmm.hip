@@ -4,7 +4,8 @@
 //
 // Per Gaussian:  ll = gconst + Σ_d means_invvars[d]·x[d] + Σ_d (−½ inv_vars[d])·x[d]²   — a [rows × 2D]·[2D × frames]
 // contraction.  The MFMA accumulates a k-ordered fmaf chain starting from C = gconst, i.e. bit for bit the oracle's chain.
-// Per pdf:       LL = max + log Σ_{ll ≥ max+ln ε} exp(ll − max)  (exp in f32, sum and log in f64, as Kaldi).
+// Per pdf:       LL = max + log Σ_{ll ≥ max+ln ε} exp(ll − max)  (Kaldi: expf, double sum, log; here: hardware exp2/log2
+//                and a float32 tree sum — within 1 ulp of the Kaldi value at score magnitudes ≥ 16, see reg_expsum).
 //
 // Packed model (built once in mfa_load_gmm): every pdf owns `slot` consecutive rows of W[rows][kpad]
 // (slot ∈ {1,4,8,16,32·n}; pad rows have zero weights and gconst −1e30 so they fall under the cutoff).  Within each group
@@ -13,11 +14,17 @@
 // One 32-row MFMA block then serves 32/slot pdfs of the utterance's (slot-sorted) pdf list; rows ↔ accumulator registers:
 // row = (r&3) + 8(r>>2) + 4(l>>5), so 4-row slots reduce inside a lane and 8/16/32-row slots add one cross-half shuffle.
 //
-// Work decomposition: grid (frame tiles of 256, utterances); a wavefront owns NT×32 frames, keeps their x̃ = [x, x²]
-// operands in registers (the B side) and streams the utterance's model rows (the A side, L2/MALL-resident).
+// Work decomposition: 1-D grid of (utterance, 256-frame tile) workgroups dealt XCD-aware; a wavefront owns NT×32 frames,
+// keeps their x̃ = [x, x²] operands in registers (the B side) and streams the utterance's model rows (the A side,
+// L2/MALL-resident).  With reachability information (first_frame) a wavefront only walks the prefix of each class that
+// its frames can be asked for.
 // Output: [T][P_u] row-major, the layout the Viterbi kernel gathers from.
+#include <algorithm>
+#include <climits>
 #include <cmath>
+#include <cstdint>
 #include <cstdlib>
+#include <utility>
 #include <vector>
 
 #include "ctx.hpp"
@@ -35,18 +42,14 @@ struct GmmParams {
   const float *w; const float *gc; const int32_t *row0; const int32_t *nblk; const int32_t *slot;
   const float *feats; const int64_t *frame_off;
   const int32_t *pdf_list; const int64_t *pdf_off; const int32_t *class_counts; const int64_t *ll_off;
+  unsigned long long *trace;   // debug (mfa_debug_gmm_trace): per workgroup {start, end, hw id, blocks} or NULL
+  int ff_bias;                 // debug (MFA_GMM_FF_BIAS): added to the tile's last frame before the reachability test
+  const int32_t *first_frame;  // parallel to pdf_list (ascending inside each class) or NULL: see mfa_gmm_score_batch
   float *out;
   float min_log_diff;  // logf(FLT_EPSILON), computed on the host so device and oracle use the same constant
-  int skip_single;     // >0: that many leading single-block 32-row pdfs are handled by gmm_sp_kernel
-  int n_utt, tiles;    // generic kernel: 1-D grid of 8·ceil(n_utt/8)·tiles workgroups
-  int prio;            // MFA_GMM_PRIO: s_setprio level for the second half of a 512-thread workgroup (0 = none)
+  int n_utt, tiles;    // tiles = 256-frame tiles per utterance (ceil(max_frames / 256)); items = (utterance, tile)
+  int *queue;          // [0..8) phase-1 and [8..16) phase-2 per-XCD item counters, [16] max first frame; zeroed per launch
 };
-
-__device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __shfl_xor(lo, mask); hi = __shfl_xor(hi, mask);
-  return __hiloint2double(hi, lo);
-}
 
 // row index (within a 32-row MFMA block) held by accumulator register r of a lane in half h
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
@@ -62,17 +65,6 @@ __device__ __forceinline__ float swap32(float v, int h) {
   return __shfl_xor(v, 32);
 #endif
 }
-__device__ __forceinline__ double swap32_f64(double v, int h) {
-#if __has_builtin(__builtin_amdgcn_permlane32_swap)
-  unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
-  auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-  auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-  return __hiloint2double((int)(h ? b[0] : b[1]), (int)(h ? a[0] : a[1]));
-#else
-  return shfl_xor_f64(v, 32);
-#endif
-}
-
 template <int M8, int kNT>
 struct Tile {
   // One wavefront: B operands for kNT frame tiles, generic block evaluation.
@@ -174,45 +166,52 @@ __device__ __forceinline__ float finish(float mx, float sum) {
   return fmaf(__builtin_amdgcn_logf(sum), 0.693147180559945309f, mx);
 }
 
-template <int M8, int kNT, int kMinWaves, int kWaves>
-__global__ __launch_bounds__(64 * kWaves, kMinWaves) void gmm_kernel(GmmParams p) {
+// One work item = (utterance, 64-frame tile): score_tile walks the utterance's pdf list for those frames.
+template <int M8, int kNT>
+__device__ __forceinline__ void score_tile(const GmmParams &p, int utt, int t_base, int lane, float *stage, int rec_index) {
   constexpr int kFramesPerWave = 32 * kNT;
-  // 512-thread workgroups put two wavefronts on every SIMD.  Left alone they fall into lockstep (both in their MFMA
-  // phase, then both in their log-sum-exp epilogue, matrix pipe idle).  A static priority for the second half lets that
-  // wavefront own the matrix pipe while the other fills the pipe during the first one's epilogue
-  // (cdna_hip_programming.md T5, static form).
-  if (kWaves == 8 && p.prio && (threadIdx.x >> 8)) __builtin_amdgcn_s_setprio(2);
-  // XCD-aware block→(utterance, frame tile) map (cdna_hip_programming.md T1): workgroups are dealt round-robin over the
-  // 8 XCDs, each with a private L2.  All frame tiles of one utterance stream the same model rows, so they are given
-  // consecutive slots on ONE XCD: the rows are then fetched from HBM/Infinity Cache once per utterance, not once per tile.
-  const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
-  const int utt = (seq / p.tiles) * 8 + xcd;
-  const int tile_x = seq % p.tiles;
-  if (utt >= p.n_utt) return;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned long long t_start = 0;
+  if (p.trace) t_start = wall_clock64();
   const int64_t f0 = p.frame_off[utt];
   const int T = (int)(p.frame_off[utt + 1] - f0);
-  const int t_base = (tile_x * kWaves + wave) * kFramesPerWave;
-  if (t_base >= T) return;  // wavefronts are independent (no barriers in this kernel)
+  if (t_base >= T) return;
   const int col = lane & 31, h = lane >> 5;
   const int64_t l0 = p.pdf_off[utt];
   const int P = (int)(p.pdf_off[utt + 1] - l0);
   const int32_t *list = p.pdf_list + l0;
   const int32_t *cc6 = p.class_counts + (size_t)utt * 6;
-  // class_counts[u] = {32-row single-block, 32-row multi-block, 16, 8, 4, 1}; with p.skip_single the single-block pdfs
-  // are scored by gmm_sp_kernel and this kernel starts after them
-  const int first32 = p.skip_single ? min(cc6[0], p.skip_single) : 0;
+  // class_counts[u] = {32-row single-block, 32-row multi-block, 16, 8, 4, 1}
+  constexpr int first32 = 0;
   const int32_t cc[5] = {cc6[0] + cc6[1], cc6[2], cc6[3], cc6[4], cc6[5]};
-  if (first32 == cc[0] && cc[1] + cc[2] + cc[3] + cc[4] == 0) return;  // nothing left for this kernel
+  // need[c]: how many pdfs of class c this wavefront's frames can be asked for.  Without reachability information that
+  // is all of them; with it, the pdfs whose first possible frame lies at or before the tile's last frame — a prefix of
+  // the class, because the host ordered each class by that frame.
+  int need[6];
+  {
+    const int t_last = min(T, t_base + kFramesPerWave) - 1 + p.ff_bias;
+    int off = 0;
+#pragma unroll
+    for (int cls = 0; cls < 6; cls++) {
+      const int cnt = cc6[cls];
+      int nd = cnt;
+      if (p.first_frame) {
+        nd = 0;
+        for (int i0 = 0; i0 < cnt; i0 += 64) {
+          const int i = i0 + lane;
+          const bool ok = i < cnt && p.first_frame[l0 + off + i] <= t_last;
+          nd += __popcll(__ballot(ok));
+        }
+      }
+      need[cls] = nd;
+      off += cnt;
+    }
+  }
   float *out = p.out + p.ll_off[utt];
 
   Tile<M8, kNT> tile;
   tile.load_b(p, f0, T, t_base, lane);
   f32x16 acc[kNT];
-  // per-wavefront output staging tile (volatile: written lane-per-frame, read row-wise by the same wavefront)
-  __shared__ float stage_all[kWaves][64 * 33];
-  float *stage = stage_all[wave];
-  const int n_single = cc6[0];
+  const int n_single = need[0];
 
   // ---- single-block 32-row pdfs (the bulk of a context-dependent model): one pdf per MFMA block.
   // Software pipeline, no extra registers: as soon as the MFMAs that read operand group a[m] of block j have been issued,
@@ -311,7 +310,7 @@ __global__ __launch_bounds__(64 * kWaves, kMinWaves) void gmm_kernel(GmmParams p
 
   // ---- 32-row pdfs with more than 32 Gaussians: several blocks, two passes (max, then the sum against that max)
   const int n32 = cc[0];
-  for (int j = max(first32, n_single); j < n32; j++) {
+  for (int j = max(first32, cc6[0]); j < cc6[0] + need[1]; j++) {
     const int pdf = list[j];
     const int r0 = p.row0[pdf], nb = p.nblk[pdf];
     float mx[kNT], sum[kNT];
@@ -347,7 +346,7 @@ __global__ __launch_bounds__(64 * kWaves, kMinWaves) void gmm_kernel(GmmParams p
   // ---- smaller slots: 32/slot pdfs share one MFMA block
   int base = n32;
   // slot 16
-  for (int j = 0; j < cc[1]; j += 2) {
+  for (int j = 0; j < need[2]; j += 2) {
     const int which = col >> 4, within = col & 15;
     const int idx = j + which;
     const int row = idx < cc[1] ? p.row0[list[base + idx]] + within : p.num_rows;
@@ -367,7 +366,7 @@ __global__ __launch_bounds__(64 * kWaves, kMinWaves) void gmm_kernel(GmmParams p
   }
   base += cc[1];
   // slot 8
-  for (int j = 0; j < cc[2]; j += 4) {
+  for (int j = 0; j < need[3]; j += 4) {
     const int which = col >> 3, within = col & 7;
     const int idx = j + which;
     const int row = idx < cc[2] ? p.row0[list[base + idx]] + within : p.num_rows;
@@ -392,7 +391,7 @@ __global__ __launch_bounds__(64 * kWaves, kMinWaves) void gmm_kernel(GmmParams p
   }
   base += cc[2];
   // slot 4: rows 8q+4h..8q+4h+3 live in registers 4q..4q+3 of one lane → pdf index 2q+h, no shuffle
-  for (int j = 0; j < cc[3]; j += 8) {
+  for (int j = 0; j < need[4]; j += 8) {
     const int which = col >> 2, within = col & 3;
     const int idx = j + which;
     const int row = idx < cc[3] ? p.row0[list[base + idx]] + within : p.num_rows;
@@ -415,7 +414,7 @@ __global__ __launch_bounds__(64 * kWaves, kMinWaves) void gmm_kernel(GmmParams p
   }
   base += cc[3];
   // slot 1: every row is its own single-Gaussian pdf: LL = ll (max + log(1) exactly)
-  for (int j = 0; j < cc[4]; j += 32) {
+  for (int j = 0; j < need[5]; j += 32) {
     const int idx = j + col;
     const int row = idx < cc[4] ? p.row0[list[base + idx]] : p.num_rows;
     tile.block(p.w + (size_t)row * p.kpad + 4 * h, p.gc[row], lane, acc);
@@ -431,98 +430,94 @@ __global__ __launch_bounds__(64 * kWaves, kMinWaves) void gmm_kernel(GmmParams p
       }
     }
   }
+  if (p.trace && lane == 0) {
+    unsigned long long *rec = p.trace + (size_t)rec_index * 4;
+    rec[0] = t_start; rec[1] = wall_clock64();
+    rec[2] = ((unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11))) | ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (3 << 11)) << 32);
+    rec[3] = (unsigned long long)(need[0] + need[1]);
+  }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Software-pipelined scoring of the single-block 32-row pdfs (the bulk of a context-dependent model).
-// One wavefront per SIMD (whole 512-register file): it owns 4 frame tiles (128 frames, x̃ in 160 VGPRs) and two
-// accumulator sets.  While the matrix pipe works through block j's 160 MFMAs, the same wavefront's VALU stream runs the
-// log-sum-exp epilogue of block j-1 from the other accumulator set, and block j+1's model rows are already in flight —
-// the pipe never waits for an epilogue phase (two co-resident wavefronts running [MFMA phase | epilogue phase] fall
-// into lockstep and leave it idle ≈40 % of the time).
-constexpr int kSpMaxBlocks = 2048;
-template <int M8>
-__global__ __launch_bounds__(256, 1) void gmm_sp_kernel(GmmParams p) {
-  constexpr int NT = 4;
-  const int utt = blockIdx.y;
+// Persistent scoring kernel.  Round-1 timeline of the one-workgroup-per-tile version (tools/gmm_timeline.py): the hardware
+// deals workgroups to CUs in a fixed round-robin order — every CU received exactly 32 of the 8192 workgroups and, the
+// tile index being periodic in the grid, always the SAME tile type — so CUs with cheap tiles idled (slot occupancy 82 %)
+// and skipping unreachable cells bought no time at all.  Here the grid is just enough workgroups to fill the chip
+// (2 per CU) and work is pulled from queues (atomic counters) until they run dry, in two phases:
+//   phase 1, workgroup items (utterance, 256-frame tile) for the tiles whose four 64-frame sub-tiles all need the whole
+//     pdf list: the four wavefronts take one sub-tile each and walk the list at the same pace, so the model rows they
+//     stream come through the CU's L1 once, not four times (measured: 5.3 µs per 32-row block against 5.9 µs when every
+//     wavefront streams its own rows);
+//   phase 2, wavefront items (utterance, 64-frame tile) for the leading tiles, where reachability makes the sub-tiles
+//     unequal (a workgroup item would idle three wavefronts behind the fourth); being short, they also fill the tail.
+// One queue per XCD and phase, holding the utterances u ≡ xcd (mod 8): all tiles of an utterance stream the same rows
+// through that XCD's private L2 (cdna_hip_programming.md T1); the XCD a workgroup runs on is read from XCC_ID.  Items go
+// utterance by utterance, last frames first.  A workgroup whose queue is empty takes items from the other XCDs' queues,
+// so a phase ends within one item.  Every wavefront leaves a loop once all eight counters have passed their item counts:
+// the grid always drains.
+template <int M8, int kNT, int kMinWaves, int kWaves>
+__global__ __launch_bounds__(64 * kWaves, kMinWaves) void gmm_kernel(GmmParams p) {
+  constexpr int kFramesPerWave = 32 * kNT, kFramesPerTile = kFramesPerWave * kWaves;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t f0 = p.frame_off[utt];
-  const int T = (int)(p.frame_off[utt + 1] - f0);
-  const int t_base = (blockIdx.x * 4 + wave) * (32 * NT);
-  const int32_t *cc = p.class_counts + (size_t)utt * 6;
-  const int n1 = min(cc[0], kSpMaxBlocks);  // the generic kernel takes whatever exceeds the row cache
-  const int64_t l0 = p.pdf_off[utt];
-  const int P = (int)(p.pdf_off[utt + 1] - l0);
-  const int32_t *list = p.pdf_list + l0;
-  // first packed row of every block, staged in LDS once per workgroup: the per-block lookups then ride on lgkmcnt and
-  // never serialise with the model-row prefetch on vmcnt
-  __shared__ int rows_lds[kSpMaxBlocks];
-  for (int i = threadIdx.x; i < n1; i += blockDim.x) rows_lds[i] = p.row0[list[i]];
-  __syncthreads();
-  if (t_base >= T || n1 == 0) return;
-  const int col = lane & 31, h = lane >> 5;
-  float *out = p.out + p.ll_off[utt];
-
-  Tile<M8, NT> tile;
-  tile.load_b(p, f0, T, t_base, lane);
-
-  f32x4 aA[M8], aB[M8], gA[4], gB[4];
-  f32x16 accA[NT], accB[NT];
-  // first packed row of block jj; fetched two blocks ahead of its use (two dependent loads that must not stall the pipe)
-  auto row_of = [&](int jj) { return jj < n1 ? rows_lds[jj] : 0; };
-  auto request = [&](int r0, f32x4 (&a)[M8], f32x4 (&g)[4]) {
-    r0 = __builtin_amdgcn_readfirstlane(r0);
-    Tile<M8, NT>::load_a(p.w + (size_t)(r0 + col) * p.kpad + 4 * h, a);
-    Tile<M8, NT>::load_gc32(p.gc + r0, h, g);
-  };
-  auto epilogue = [&](const f32x16 (&acc)[NT], int j) {
-    float mx[NT]; float sum[NT];
-#pragma unroll
-    for (int n = 0; n < NT; n++) {
-      float m = reg_max<0, 16>(acc[n]);
-      m = fmaxf(m, swap32(m, h));
-      float s = reg_expsum<0, 16>(acc[n], m, m + p.min_log_diff);
-      s += swap32(s, h);
-      mx[n] = m; sum[n] = s;
-    }
-    // half h finishes tiles 2i+h
-#pragma unroll
-    for (int i = 0; i < NT / 2; i++) {
-      const float mxs = h ? mx[2 * i + 1] : mx[2 * i];
-      const float sums = h ? sum[2 * i + 1] : sum[2 * i];
-      const int t = t_base + 32 * (2 * i + h) + col;
-      if (t < T) out[(size_t)t * P + j] = finish(mxs, sums);
-    }
-  };
-
-  // Operand sets are requested one whole block (160 MFMAs) before their first use; the sched_barrier keeps the compiler
-  // from sinking the loads down to that use.
-  request(row_of(0), aA, gA);
-  if (n1 > 1) request(row_of(1), aB, gB);
-  int r_next = row_of(2);   // row of block j+1 at the top of each half-trip below
-  __builtin_amdgcn_sched_barrier(0);
-  tile.run32(aA, gA, accA);  // block 0
-  int j = 1;
-  // two blocks per trip so the accumulator/operand sets alternate by name (no register copies)
-  for (; j + 1 < n1; j += 2) {
-    request(r_next, aA, gA);    // block j+1, for the second half of this trip (aA is free: block j-1's MFMAs are issued)
-    r_next = row_of(j + 2);
-    __builtin_amdgcn_sched_barrier(0);
-    tile.run32(aB, gB, accB);   // block j      → accB   ┐ independent MFMA and VALU streams:
-    epilogue(accA, j - 1);      // block j-1 from accA   ┘ the scheduler interleaves them
-    if (j + 2 < n1) request(r_next, aB, gB);
-    r_next = row_of(j + 3);
-    __builtin_amdgcn_sched_barrier(0);
-    tile.run32(aA, gA, accA);   // block j+1    → accA
-    epilogue(accB, j);
+  // per-wavefront output staging tile (written lane-per-frame, read row-wise by the same wavefront)
+  __shared__ float stage_all[kWaves][64 * 33];
+  __shared__ int s_item;
+  const int my_xcd = (int)(__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u);
+  // leading tiles whose first sub-tile cannot yet see every pdf (first possible frame beyond that sub-tile's last frame)
+  int light = 0;
+  if (p.first_frame) {
+    const int mff = __builtin_amdgcn_readfirstlane(p.queue[16]);
+    light = mff >= kFramesPerWave ? min(p.tiles, (mff - (kFramesPerWave - 1) + kFramesPerTile - 1) / kFramesPerTile) : 0;
   }
-  if (j < n1) {
-    tile.run32(aB, gB, accB);
-    epilogue(accA, j - 1);
-    epilogue(accB, j);
-  } else {
-    epilogue(accA, j - 1);
+  const int heavy = p.tiles - light;
+  // Opaque copies inside the loops: without them the compiler hoists every lane-dependent address out of the item loop
+  // and keeps it in registers for the kernel's lifetime (measured: 256 VGPRs + 240 bytes of scratch instead of 217 VGPRs).
+  if (heavy > 0) {
+    for (int hop = 0; hop < 8; hop++) {
+      const int q = (my_xcd + hop) & 7;
+      const int n_items = ((p.n_utt - q + 7) >> 3) * heavy;   // utterances q, q+8, q+16, ...
+      for (;;) {
+        __syncthreads();                             // every wavefront is done with the previous item (and has read s_item)
+        if (threadIdx.x == 0) s_item = atomicAdd(&p.queue[q], 1);
+        __syncthreads();
+        const int item = s_item;
+        if (item >= n_items) break;                  // uniform over the workgroup
+        int lane_i = lane, wave_i = wave;
+        asm volatile("" : "+v"(lane_i), "+v"(wave_i));
+        wave_i = __builtin_amdgcn_readfirstlane(wave_i);
+        const int v = item / heavy, tl = p.tiles - 1 - item % heavy;
+        score_tile<M8, kNT>(p, v * 8 + q, (tl * kWaves + wave_i) * kFramesPerWave, lane_i, stage_all[wave_i],
+                            ((v * 8 + q) * p.tiles + tl) * kWaves + wave_i);
+      }
+    }
   }
+  if (light > 0) {
+    const int per_utt = light * kWaves;
+    for (int hop = 0; hop < 8; hop++) {
+      const int q = (my_xcd + hop) & 7;
+      const int n_items = ((p.n_utt - q + 7) >> 3) * per_utt;
+      for (;;) {
+        int item = 0;
+        if (lane == 0) item = atomicAdd(&p.queue[8 + q], 1);
+        item = __builtin_amdgcn_readfirstlane(item);
+        if (item >= n_items) break;                  // uniform over the wavefront
+        int lane_i = lane, wave_i = wave;
+        asm volatile("" : "+v"(lane_i), "+v"(wave_i));
+        wave_i = __builtin_amdgcn_readfirstlane(wave_i);
+        const int v = item / per_utt, r = per_utt - 1 - item % per_utt;
+        score_tile<M8, kNT>(p, v * 8 + q, r * kFramesPerWave, lane_i, stage_all[wave_i], (v * 8 + q) * p.tiles * kWaves + r);
+      }
+    }
+  }
+}
+
+// max over the batch of the pdfs' first possible frames → queue[16] (the persistent kernel derives its phase split from it)
+__global__ void gmm_max_first_frame_kernel(const int32_t *first_frame, const int64_t *pdf_off, int n_utt, int *out) {
+  const int64_t n = pdf_off[n_utt];
+  int m = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    m = max(m, first_frame[i]);
+  for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(out, m);
 }
 
 // Straightforward one-thread-per-(frame,pdf) kernel: used for feature dims the MFMA kernel is not instantiated for and,
@@ -642,9 +637,54 @@ MFA_API int mfa_gmm_sort_pdf_list(mfa_ctx *c, int32_t *h_pdfs, int32_t n, int32_
   return 0;
 }
 
+MFA_API int mfa_gmm_sort_pdf_list_keyed(mfa_ctx *c, int32_t *h_pdfs, int32_t *h_first_frame, int32_t n,
+                                        int32_t *h_class_counts) {
+  if (!c->gmm_ready) return c->fail("mfa_load_gmm has not been called");
+  std::vector<std::pair<int32_t, int32_t>> bucket[6];  // (key, pdf)
+  for (int i = 0; i < n; i++) {
+    int p = h_pdfs[i];
+    if (p < 0 || p >= c->num_pdfs) return c->fail("pdf id %d out of range [0,%d)", p, c->num_pdfs);
+    int ci = class_index(c->h_slot[p]);
+    bucket[ci == 0 ? (c->h_nblk[p] == 1 ? 0 : 1) : ci + 1].push_back({h_first_frame[i], p});
+  }
+  int k = 0;
+  for (int b = 0; b < 6; b++) {
+    std::stable_sort(bucket[b].begin(), bucket[b].end(),
+                     [](const std::pair<int32_t, int32_t> &x, const std::pair<int32_t, int32_t> &y) { return x.first < y.first; });
+    h_class_counts[b] = (int32_t)bucket[b].size();
+    for (auto &e : bucket[b]) { h_first_frame[k] = e.first; h_pdfs[k++] = e.second; }
+  }
+  return 0;
+}
+
+MFA_API int mfa_fst_first_frames(int32_t n_states, const int32_t *h_arc_off, const int32_t *h_arc_next, int32_t start,
+                                 int32_t *h_depth) {
+  if (n_states <= 0 || start < 0 || start >= n_states) return -1;
+  for (int s = 0; s < n_states; s++) h_depth[s] = INT32_MAX;
+  std::vector<int32_t> queue;
+  queue.reserve(n_states);
+  queue.push_back(start);
+  h_depth[start] = 0;
+  for (size_t q = 0; q < queue.size(); q++) {  // breadth-first: unit arc lengths
+    const int s = queue[q];
+    for (int a = h_arc_off[s]; a < h_arc_off[s + 1]; a++) {
+      const int d = h_arc_next[a];
+      if (d < 0 || d >= n_states) return -1;
+      if (h_depth[d] == INT32_MAX) { h_depth[d] = h_depth[s] + 1; queue.push_back(d); }
+    }
+  }
+  return 0;
+}
+
+MFA_API int mfa_debug_gmm_trace(mfa_ctx *c, void *d_trace) {
+  c->gmm_trace = d_trace;
+  return 0;
+}
+
 MFA_API int mfa_gmm_score_batch(mfa_ctx *c, const float *d_feats, const int64_t *d_frame_off, int32_t n_utt,
                                 int32_t max_frames, const int32_t *d_pdf_list, const int64_t *d_pdf_off,
-                                const int32_t *d_class_counts, const int64_t *d_ll_off, float *d_loglikes) {
+                                const int32_t *d_class_counts, const int32_t *d_pdf_first_frame, const int64_t *d_ll_off,
+                                float *d_loglikes) {
   if (!c->gmm_ready) return c->fail("mfa_load_gmm has not been called");
   if (n_utt <= 0 || max_frames <= 0) return 0;
   if (n_utt > 65535) return c->fail("at most 65535 utterances per scoring launch (got %d)", n_utt);
@@ -654,8 +694,9 @@ MFA_API int mfa_gmm_score_batch(mfa_ctx *c, const float *d_feats, const int64_t 
   p.feats = d_feats; p.frame_off = d_frame_off; p.pdf_list = d_pdf_list; p.pdf_off = d_pdf_off;
   p.class_counts = d_class_counts; p.ll_off = d_ll_off; p.out = d_loglikes;
   p.min_log_diff = logf(1.1920928955078125e-07f);
-  p.skip_single = 0;
-  { const char *pr = getenv("MFA_GMM_PRIO"); p.prio = pr ? atoi(pr) : 0; }
+  p.first_frame = d_pdf_first_frame;
+  p.trace = (unsigned long long *)c->gmm_trace;
+  { const char *fb = getenv("MFA_GMM_FF_BIAS"); p.ff_bias = fb ? atoi(fb) : 0; }
   const char *naive = getenv("MFA_GMM_NAIVE");
   const int m8 = c->kpad / 8;
   KernelTimer kt(c, MFA_K_GMM);
@@ -665,37 +706,29 @@ MFA_API int mfa_gmm_score_batch(mfa_ctx *c, const float *d_feats, const int64_t 
     dim3 grid((unsigned)((per_utt + 255) / 256), n_utt);
     hipLaunchKernelGGL(gmm_naive_kernel, grid, dim3(256), 0, c->stream, p);
   } else {
-    // frame tiles per wavefront: 1 → more resident wavefronts (≤128 VGPRs, 4 per SIMD) to interleave MFMA and epilogue
-    // phases; 2 → half the model-row traffic.  MFA_GMM_NT overrides for experiments.
-    const char *nt_env = getenv("MFA_GMM_NT");
-    const int nt = nt_env ? atoi(nt_env) : 2;
-    // single-block 32-row pdfs can go through the software-pipelined one-wavefront-per-SIMD kernel (MFA_GMM_SP=1).
-    // Measured on MI355X (round 1): 88.6 TFLOP/s vs 94.8 for the generic two-wavefront kernel, so it is off by default.
-    const char *sp_env = getenv("MFA_GMM_SP");
-    const bool use_sp = sp_env && sp_env[0] == '1';
-    p.skip_single = use_sp ? kSpMaxBlocks : 0;
-    if (use_sp) {
-      dim3 gsp((max_frames + 511) / 512, n_utt);
-      if (m8 <= 10) hipLaunchKernelGGL((gmm_sp_kernel<10>), gsp, dim3(256), 0, c->stream, p);
-      else hipLaunchKernelGGL((gmm_sp_kernel<12>), gsp, dim3(256), 0, c->stream, p);
-    }
-    const char *wg_env = getenv("MFA_GMM_WG");
-    const int wg = wg_env ? atoi(wg_env) : 256;
-    const int fpw = 32 * (nt == 2 ? 2 : 1);
-    const int waves_per_wg = (nt == 2 && wg == 512) ? 8 : 4;
+    // 4 wavefronts per workgroup, 2 frame tiles (64 frames) per wavefront, two workgroups resident per CU (206 VGPRs).
+    // Variants measured and dropped in round 1: 1 tile per wavefront (3 per SIMD: 30 TFLOP/s, spills), 8-wavefront
+    // workgroups with or without a static s_setprio split (103 TFLOP/s), one wavefront per SIMD with 4 tiles and an
+    // in-wavefront MFMA/epilogue software pipeline (97 TFLOP/s).
+    constexpr int kFramesPerItem = 256;
     p.n_utt = n_utt;
-    p.tiles = (max_frames + waves_per_wg * fpw - 1) / (waves_per_wg * fpw);
-    dim3 grid((unsigned)(((n_utt + 7) / 8) * 8 * p.tiles));
-    if (nt == 2 && wg == 512) {
-      if (m8 <= 10) hipLaunchKernelGGL((gmm_kernel<10, 2, 2, 8>), grid, dim3(512), 0, c->stream, p);
-      else hipLaunchKernelGGL((gmm_kernel<12, 2, 2, 8>), grid, dim3(512), 0, c->stream, p);
-    } else if (nt == 2) {
-      if (m8 <= 10) hipLaunchKernelGGL((gmm_kernel<10, 2, 2, 4>), grid, dim3(256), 0, c->stream, p);
-      else hipLaunchKernelGGL((gmm_kernel<12, 2, 2, 4>), grid, dim3(256), 0, c->stream, p);
-    } else {
-      if (m8 <= 10) hipLaunchKernelGGL((gmm_kernel<10, 1, 3, 4>), grid, dim3(256), 0, c->stream, p);
-      else hipLaunchKernelGGL((gmm_kernel<12, 1, 3, 4>), grid, dim3(256), 0, c->stream, p);
+    p.tiles = (max_frames + kFramesPerItem - 1) / kFramesPerItem;
+    if (!c->d_gmm_queue) MFA_HIP_CHECK(c, hipMalloc((void **)&c->d_gmm_queue, 32 * sizeof(int)));
+    MFA_HIP_CHECK(c, hipMemsetAsync(c->d_gmm_queue, 0, 32 * sizeof(int), c->stream));
+    p.queue = c->d_gmm_queue;
+    if (d_pdf_first_frame)
+      hipLaunchKernelGGL(gmm_max_first_frame_kernel, dim3(64), dim3(256), 0, c->stream, d_pdf_first_frame, d_pdf_off, n_utt,
+                         c->d_gmm_queue + 16);
+    if (c->num_cus <= 0) {
+      hipDeviceProp_t prop;
+      MFA_HIP_CHECK(c, hipGetDeviceProperties(&prop, c->device));
+      c->num_cus = prop.multiProcessorCount;
     }
+    const int64_t items = (int64_t)n_utt * p.tiles;
+    const int64_t wgs = std::min<int64_t>((int64_t)c->num_cus * 2, items);
+    dim3 grid((unsigned)std::max<int64_t>(wgs, 1));
+    if (m8 <= 10) hipLaunchKernelGGL((gmm_kernel<10, 2, 2, 4>), grid, dim3(256), 0, c->stream, p);
+    else hipLaunchKernelGGL((gmm_kernel<12, 2, 2, 4>), grid, dim3(256), 0, c->stream, p);
   }
   MFA_HIP_CHECK(c, hipGetLastError());
   return 0;

@@ -45,6 +45,8 @@ class PackedGraphs:
     class_counts: torch.Tensor  # int32 [n_utt,6]
     pdf_off_host: np.ndarray
     pdf_lists_host: List[np.ndarray]
+    pdf_first_frame: Optional[torch.Tensor] = None        # int32 [ΣP_u]: first frame a pdf can be asked for
+    pdf_first_frame_host: Optional[List[np.ndarray]] = None
 
     def struct(self) -> GraphBatch:
         t = self.tensors
@@ -84,8 +86,8 @@ class AlignmentEngine:
             pass
 
     def use_torch_stream(self) -> None:
-        stream = torch.cuda.current_stream(self.device).cuda_stream
-        check(self.ctx, self.lib.mfa_set_stream(self.ctx, C.c_void_p(stream), 0), "mfa_set_stream")
+        self.stream = torch.cuda.current_stream(self.device)
+        check(self.ctx, self.lib.mfa_set_stream(self.ctx, C.c_void_p(self.stream.cuda_stream), 0), "mfa_set_stream")
 
     # ------------------------------------------------------------------ configuration
     def configure_mfcc(self, **kw) -> None:
@@ -179,26 +181,46 @@ class AlignmentEngine:
         check(self.ctx, rc, "mfa_feats_batch")
         return out
 
-    def sort_pdf_list(self, pdfs: np.ndarray):
-        """Order a pdf list by slot class as the scoring kernels require; returns (sorted, counts[6])."""
-        pdfs = np.asarray(pdfs, dtype=np.int32)
-        cls = self.slot_class[pdfs]
-        order = np.argsort(cls, kind="stable")
-        return pdfs[order], np.bincount(cls, minlength=6).astype(np.int32)
+    def sort_pdf_list(self, pdfs: np.ndarray, first_frame: Optional[np.ndarray] = None):
+        """Order a pdf list by slot class as the scoring kernels require; returns (sorted, counts[6]) or, with
+        ``first_frame`` keys, (sorted, counts[6], sorted keys) with ascending keys inside each class
+        (mfa_gmm_sort_pdf_list / mfa_gmm_sort_pdf_list_keyed)."""
+        pdfs = np.ascontiguousarray(pdfs, dtype=np.int32).copy()
+        counts = np.zeros(6, dtype=np.int32)
+        if first_frame is None:
+            check(self.ctx, self.lib.mfa_gmm_sort_pdf_list(self.ctx, pdfs.ctypes.data, len(pdfs), counts.ctypes.data),
+                  "mfa_gmm_sort_pdf_list")
+            return pdfs, counts
+        keys = np.ascontiguousarray(first_frame, dtype=np.int32).copy()
+        check(self.ctx, self.lib.mfa_gmm_sort_pdf_list_keyed(self.ctx, pdfs.ctypes.data, keys.ctypes.data, len(pdfs),
+                                                             counts.ctypes.data), "mfa_gmm_sort_pdf_list_keyed")
+        return pdfs, counts, keys
+
+    def state_first_frames(self, fst: Fst) -> np.ndarray:
+        """depth[s] = fewest arcs from the start state to s = first frame a token can sit on s (mfa_fst_first_frames)."""
+        arc_off = np.ascontiguousarray(fst.arc_offsets, dtype=np.int32)
+        nxt = np.ascontiguousarray(fst.arcs["nextstate"], dtype=np.int32)
+        depth = np.empty(fst.num_states, dtype=np.int32)
+        if self.lib.mfa_fst_first_frames(fst.num_states, arc_off.ctypes.data, nxt.ctypes.data, int(fst.start),
+                                         depth.ctypes.data) != 0:
+            raise _lib.MfaHipError("mfa_fst_first_frames: malformed graph")
+        return depth
 
     def score(self, feats: torch.Tensor, frame_off: np.ndarray, pdf_list: torch.Tensor, pdf_off_host: np.ndarray,
-              class_counts: torch.Tensor):
-        """Returns (loglikes float32 flat, ll_off host int64 [n+1], ll_cols int32 tensor)."""
+              class_counts: torch.Tensor, pdf_first_frame: Optional[torch.Tensor] = None):
+        """Returns (loglikes float32 flat, ll_off host int64 [n+1], ll_cols int32 tensor).  With ``pdf_first_frame``
+        (PackedGraphs.pdf_first_frame) cells no decoder token can ask for are left unwritten (zero here)."""
         n_utt = len(frame_off) - 1
         T = np.diff(frame_off)
         P = np.diff(pdf_off_host)
         ll_off = np.concatenate([[0], np.cumsum(T * P)]).astype(np.int64)
-        out = torch.empty(int(ll_off[-1]), dtype=torch.float32, device=self.device)
+        alloc = torch.empty if pdf_first_frame is None else torch.zeros
+        out = alloc(int(ll_off[-1]), dtype=torch.float32, device=self.device)
         d_fo, d_po, d_lo = self._dev(frame_off), self._dev(pdf_off_host.astype(np.int64)), self._dev(ll_off)
         max_frames = int(T.max()) if n_utt else 0
         check(self.ctx, self.lib.mfa_gmm_score_batch(self.ctx, _ptr(feats), _ptr(d_fo), n_utt, max_frames, _ptr(pdf_list),
-                                                     _ptr(d_po), _ptr(class_counts), _ptr(d_lo), _ptr(out)),
-              "mfa_gmm_score_batch")
+                                                     _ptr(d_po), _ptr(class_counts), _ptr(pdf_first_frame), _ptr(d_lo),
+                                                     _ptr(out)), "mfa_gmm_score_batch")
         return out, ll_off, self._dev(P.astype(np.int32))
 
     def pack_graphs(self, fsts: Sequence[Fst], tm: TransitionModel) -> PackedGraphs:
@@ -218,15 +240,23 @@ class AlignmentEngine:
             raise _lib.MfaHipError(f"a graph state has {max_deg} arcs; the device decoder supports at most 64")
         pdf_of_arc = tm.id2pdf[arcs["ilabel"]]
         cols = np.empty(arcs.shape[0], dtype=np.int32)
-        pdf_lists, counts = [], []
+        pdf_lists, counts, first_frames = [], [], []
         lut = np.full(tm.num_pdfs, -1, dtype=np.int32)
         for u in range(n):
             a0, a1 = int(arc_base[u]), int(arc_base[u + 1])
-            pl, cc = self.sort_pdf_list(np.unique(pdf_of_arc[a0:a1]))
+            f = fsts[u]
+            # first frame each pdf can be asked for = fewest arcs from the start state to the source of an arc emitting it
+            depth = self.state_first_frames(f)
+            src = np.repeat(np.arange(f.num_states, dtype=np.int64), np.diff(f.arc_offsets))
+            upl, inv = np.unique(pdf_of_arc[a0:a1], return_inverse=True)
+            ff = np.full(upl.shape[0], np.iinfo(np.int32).max, dtype=np.int32)
+            np.minimum.at(ff, inv, depth[src])
+            pl, cc, ff = self.sort_pdf_list(upl, ff)
             lut[pl] = np.arange(pl.shape[0], dtype=np.int32)
             cols[a0:a1] = lut[pdf_of_arc[a0:a1]]
             pdf_lists.append(pl)
             counts.append(cc)
+            first_frames.append(ff)
         pdf_off = np.concatenate([[0], np.cumsum([len(p) for p in pdf_lists])]).astype(np.int64)
         t = dict(
             state_off=self._dev(state_off), arc_base=self._dev(arc_base),
@@ -237,7 +267,8 @@ class AlignmentEngine:
             arc_olabel=self._dev(arcs["olabel"].astype(np.int32)),
         )
         return PackedGraphs(n, int(S.max()) if n else 0, int(A.max()) if n else 0, int(A.sum()), t, self._dev(np.concatenate(pdf_lists).astype(np.int32)),
-                            self._dev(pdf_off), self._dev(np.stack(counts).astype(np.int32)), pdf_off, pdf_lists)
+                            self._dev(pdf_off), self._dev(np.stack(counts).astype(np.int32)), pdf_off, pdf_lists,
+                            self._dev(np.concatenate(first_frames).astype(np.int32)), first_frames)
 
     def align(self, graphs: PackedGraphs, loglikes: torch.Tensor, ll_off: np.ndarray, ll_cols: torch.Tensor,
               frame_off: np.ndarray, beam: float = 10.0, retry_beam: float = 40.0, acoustic_scale: float = 0.1,
@@ -287,8 +318,11 @@ class Pipeline:
     def __init__(self, engine: AlignmentEngine, pcm: torch.Tensor, sample_off: np.ndarray, utt2spk: np.ndarray,
                  graphs: PackedGraphs, lda: Optional[torch.Tensor] = None, fmllr: Optional[torch.Tensor] = None,
                  splice_context: int = 3, beam: float = 10.0, retry_beam: float = 40.0, acoustic_scale: float = 0.1,
-                 max_tokens: int = 1024, bp_tokens_per_frame: int = 256):
+                 max_tokens: int = 1024, bp_tokens_per_frame: int = 256, reachability: bool = True):
         e = self.e = engine
+        # reachability: score a pdf only from the first frame a decoder token can ask for it (Kaldi evaluates its
+        # decodable lazily; the dense score matrix here skips the cells that provably are never read)
+        self.reachability = bool(reachability) and graphs.pdf_first_frame is not None
         dev = e.device
         self.pcm = pcm
         self.n_utt = len(sample_off) - 1
@@ -324,9 +358,16 @@ class Pipeline:
         self.opts = AlignOpts(beam, retry_beam, acoustic_scale, max_tokens, bp_tokens_per_frame)
         self.gstruct = graphs.struct()
         # algorithmic work of one step: GMM flops 4·D·g·P·T summed over utterances
-        g_of_pdf = np.diff(e.gmm.pdf_offsets)
-        gauss = np.array([int(g_of_pdf[pl].sum()) for pl in graphs.pdf_lists_host], dtype=np.float64)
-        self.gmm_flops = float((4.0 * e.gmm.dim * gauss * T).sum())
+        # With reachability a (frame, pdf) cell is algorithmically needed only from the pdf's first possible frame on.
+        g_of_pdf = np.diff(e.gmm.pdf_offsets).astype(np.float64)
+        cells = 0.0
+        for u, pl in enumerate(graphs.pdf_lists_host):
+            if self.reachability and graphs.pdf_first_frame_host is not None:
+                live = np.clip(float(T[u]) - graphs.pdf_first_frame_host[u].astype(np.float64), 0.0, None)
+            else:
+                live = np.full(len(pl), float(T[u]))
+            cells += float((g_of_pdf[pl] * live).sum())
+        self.gmm_flops = 4.0 * e.gmm.dim * cells
         self.audio_seconds = float(np.diff(sample_off).sum() / e.mfcc_opts.sample_frequency)
 
     def step(self) -> None:
@@ -345,7 +386,8 @@ class Pipeline:
         check(c, rc, "mfa_feats_batch")
         g = self.graphs
         check(c, L.mfa_gmm_score_batch(c, _ptr(self.feats), _ptr(self.d_frame_off), self.n_utt, self.max_frames,
-                                       _ptr(g.pdf_list), _ptr(g.pdf_off), _ptr(g.class_counts), _ptr(self.d_ll_off),
+                                       _ptr(g.pdf_list), _ptr(g.pdf_off), _ptr(g.class_counts),
+                                       _ptr(g.pdf_first_frame) if self.reachability else None, _ptr(self.d_ll_off),
                                        _ptr(self.loglikes)), "mfa_gmm_score_batch")
         check(c, L.mfa_align_batch(c, C.byref(self.gstruct), _ptr(self.loglikes), _ptr(self.d_ll_off), _ptr(self.d_ll_cols),
                                    _ptr(self.d_frame_off), self.total_frames, g.total_arcs, g.max_states, g.max_arcs, C.byref(self.opts), _ptr(self.ali),

@@ -231,7 +231,9 @@ class GmmAligner:
         graphs = eng.pack_graphs([_graph.add_transition_probs(f, self._scaled) for f in fsts], self.transition_model)
         frame_off = np.concatenate([[0], np.cumsum([x.shape[0] for x in feats])]).astype(np.int64)
         d_feats = torch.from_numpy(np.concatenate(feats).astype(np.float32)).to(eng.device)
-        ll, ll_off, ll_cols = eng.score(d_feats, frame_off, graphs.pdf_list, graphs.pdf_off_host, graphs.class_counts)
+        # score only what a decoder token can ask for (Kaldi's decodable is lazy); unreachable cells stay unwritten
+        ll, ll_off, ll_cols = eng.score(d_feats, frame_off, graphs.pdf_list, graphs.pdf_off_host, graphs.class_counts,
+                                        pdf_first_frame=graphs.pdf_first_frame)
         res = eng.align(graphs, ll, ll_off, ll_cols, frame_off, beam=self.beam, retry_beam=self.retry_beam,
                         acoustic_scale=self.acoustic_scale, want_frame_likes=True)
         res = {k: v.cpu().numpy() for k, v in res.items() if v is not None}

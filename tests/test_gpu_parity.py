@@ -278,6 +278,62 @@ def test_end_to_end_pcm_to_alignment(engine, fx):
         assert abs(res["like"][u] - ref["like"]) / (b - a) < 1e-3  # per-frame log-likelihood (what MFA reports) within 1e-3
 
 
+def test_reachability_bounded_scoring_changes_nothing(engine, fx):
+    """Scoring with pdf_first_frame skips (frame, pdf) cells no decoder token can ask for: every cell it does write is
+    bit-identical to the dense matrix, every cell at or after the pdf's first frame is written, and the alignment that
+    comes out of the sparse matrix is identical to the one from the dense matrix."""
+    tm, am = fx.mono_tm, fx.mono_am
+    sr = 16000
+    cuts = [(0.0, 4.2), (4.0, 6.5), (23.5, 26.72)]
+    texts = ["this is the acoustic corpus i'm talking pretty fast here", "there's nothing going else going on",
+             "um and that should be all thanks"]
+    segs = [fx.pcm[int(a * sr): int(b * sr)] for a, b in cuts]
+    engine.configure_mfcc()
+    engine.load_gmm(am)
+    sample_off = np.concatenate([[0], np.cumsum([len(s) for s in segs])]).astype(np.int64)
+    mfcc, frame_off = engine.mfcc(_dev(engine, np.concatenate(segs)), sample_off)
+    utt2spk = np.arange(3, dtype=np.int32)
+    feats = engine.features(mfcc, frame_off, utt2spk, engine.cmvn_stats(mfcc, frame_off, utt2spk, 3))
+    fsts = [fx.mono_graph(t) for t in texts]
+    graphs = engine.pack_graphs(fsts, tm)
+    dense, ll_off, ll_cols = engine.score(feats, frame_off, graphs.pdf_list, graphs.pdf_off_host, graphs.class_counts)
+    sparse, _, _ = engine.score(feats, frame_off, graphs.pdf_list, graphs.pdf_off_host, graphs.class_counts,
+                                pdf_first_frame=graphs.pdf_first_frame)
+    d, s = dense.cpu().numpy(), sparse.cpu().numpy()
+    skipped = 0
+    for u in range(3):
+        T, P = int(frame_off[u + 1] - frame_off[u]), len(graphs.pdf_lists_host[u])
+        du, su = d[ll_off[u]: ll_off[u + 1]].reshape(T, P), s[ll_off[u]: ll_off[u + 1]].reshape(T, P)
+        ff = graphs.pdf_first_frame_host[u]
+        # host-side check of the keys themselves: state depths by a plain numpy relaxation
+        f = fsts[u]
+        depth = np.full(f.num_states, 1 << 30, dtype=np.int64)
+        depth[f.start] = 0
+        src = np.repeat(np.arange(f.num_states), np.diff(f.arc_offsets))
+        for _ in range(f.num_states):
+            nd = depth.copy()
+            np.minimum.at(nd, f.arcs["nextstate"], depth[src] + 1)
+            if np.array_equal(nd, depth):
+                break
+            depth = nd
+        col_of_arc = {int(p): i for i, p in enumerate(graphs.pdf_lists_host[u])}
+        want = np.full(P, 1 << 30, dtype=np.int64)
+        for a in range(f.num_arcs):
+            c = col_of_arc[int(tm.id2pdf[f.arcs["ilabel"][a]])]
+            want[c] = min(want[c], depth[src[a]])
+        assert np.array_equal(want, ff)
+        needed = np.arange(T)[:, None] >= ff[None, :]
+        assert np.array_equal(du[needed], su[needed])          # written cells are the dense values, bit for bit
+        written = su != 0.0
+        assert np.array_equal(du[written], su[written])
+        skipped += int((~written).sum())
+    assert skipped > 0  # the bound actually removes work on these graphs
+    ra = engine.align(graphs, dense, ll_off, ll_cols, frame_off, beam=100.0, retry_beam=400.0, want_frame_likes=True)
+    rb = engine.align(graphs, sparse, ll_off, ll_cols, frame_off, beam=100.0, retry_beam=400.0, want_frame_likes=True)
+    for k in ("ali", "words", "n_words", "like", "status", "frame_like"):
+        assert torch.equal(ra[k], rb[k]), k
+
+
 def test_fmllr_statistics_match_oracle(engine, fx):
     """First-pass alignment → per-speaker fMLLR statistics on the device vs the oracle's accumulation, and the
     host solve on them vs the oracle's solve."""

@@ -29,6 +29,34 @@ def test_c_abi_exports_every_declared_symbol():
     assert declared <= exported
 
 
+def test_fst_first_frames_host_helper(fx):
+    """mfa_fst_first_frames is pure host code (a breadth-first search): state depth = first frame a token can reach it."""
+    import ctypes as C
+
+    from montreal_forced_aligner_amd import _lib
+
+    lib = _lib.lib()
+    f = fx.mono_graph("this is the acoustic corpus")
+    arc_off = np.ascontiguousarray(f.arc_offsets, dtype=np.int32)
+    nxt = np.ascontiguousarray(f.arcs["nextstate"], dtype=np.int32)
+    depth = np.empty(f.num_states, dtype=np.int32)
+    assert lib.mfa_fst_first_frames(f.num_states, arc_off.ctypes.data, nxt.ctypes.data, int(f.start), depth.ctypes.data) == 0
+    ref = np.full(f.num_states, np.iinfo(np.int32).max, dtype=np.int64)
+    ref[f.start] = 0
+    src = np.repeat(np.arange(f.num_states), np.diff(f.arc_offsets))
+    for _ in range(f.num_states):
+        nd = ref.copy()
+        ok = ref[src] < np.iinfo(np.int32).max
+        np.minimum.at(nd, nxt[ok], ref[src][ok] + 1)
+        if np.array_equal(nd, ref):
+            break
+        ref = nd
+    assert np.array_equal(depth.astype(np.int64), ref)
+    assert depth[f.start] == 0 and depth.max() < f.num_states  # trimmed graph: everything reachable
+    # malformed input is rejected, not walked
+    assert lib.mfa_fst_first_frames(f.num_states, arc_off.ctypes.data, nxt.ctypes.data, f.num_states, depth.ctypes.data) != 0
+
+
 def test_engine_fails_loudly_without_gpu():
     import torch
 
