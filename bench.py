@@ -291,6 +291,20 @@ def main():
     gmm_ms = ktimes["gmm"]["ms"] / max(1, ktimes["gmm"]["launches"])
     flops_per_launch = pipe.gmm_flops / n_streams  # one scoring launch per stream per step
     achieved = flops_per_launch / (gmm_ms * 1e-3) / 1e12 if gmm_ms > 0 else 0.0
+    # fabric-side bytes of one scoring launch: PMC counters cannot be collected from inside this process, so the figure
+    # is the one measured by tools/profile_round.sh (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this very
+    # command) and committed under profiles/; it applies to the default triphone workload at batch 2048 only
+    traffic, traffic_src = None, None
+    prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_profile_summary_triphone_b2048.json")
+    if not mono and B == 2048 and n_streams == 1 and args.reachability and os.path.exists(prof):
+        try:
+            with open(prof) as fh:
+                d_ = json.load(fh)["kernels"]["gmm_kernel"]["derived"]
+            traffic = float(d_["fetch_bytes_per_dispatch_raw"] + d_["write_bytes_per_dispatch"])
+            traffic_src = ("profiles/r01_profile_summary_triphone_b2048.json: (FETCH_SIZE + WRITE_SIZE) KiB x 1024 per "
+                           "launch, FETCH_SIZE uncorrected (gfx950 may tally 128-B reads at 64 B: up to 2x more)")
+        except (KeyError, ValueError):
+            pass
     out = {
         "metric": "aligned utterances/sec (whole node), 10 s utts, 5k-state triphone" if not mono
         else "aligned utterances/sec (whole node), 10 s utts, monophone",
@@ -314,8 +328,9 @@ def main():
         "roofline": {
             "kernel": "gmm_kernel (diagonal-GMM scoring, v_mfma_f32_32x32x2_f32)", "bound": "mfma",
             "achieved": round(achieved, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
             "algorithmic_flops_per_launch": flops_per_launch, "avg_launch_ms": round(gmm_ms, 4),
+            **({"traffic_source": traffic_src} if traffic is not None else {}),
         },
     }
 
