@@ -252,7 +252,9 @@ __device__ __forceinline__ void score_tile(const GmmParams &p, int utt, int t_ba
       const int x_pdf3 = list[min(j + 3, last)];
       __builtin_amdgcn_sched_barrier(0);
       const float *wn = wl + (size_t)r1 * p.kpad;
+#ifndef GMM_DIAG_NO_LOADS
       Tile<M8, kNT>::load_gc32(p.gc + r1, h, g);
+#endif
 #pragma unroll
       for (int m = 0; m < M8; m++) {
 #pragma unroll
@@ -261,7 +263,9 @@ __device__ __forceinline__ void score_tile(const GmmParams &p, int utt, int t_ba
           for (int n = 0; n < kNT; n++)
             acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][cc4], tile.b[n][4 * m + cc4], acc[n], 0, 0, 0);
         }
+#ifndef GMM_DIAG_NO_LOADS   // timing-only builds (tools/: -DGMM_DIAG_*): results are wrong by construction
         a[m] = *reinterpret_cast<const f32x4 *>(wn + 8 * m);
+#endif
         __builtin_amdgcn_sched_barrier(0);
       }
       r1 = __builtin_amdgcn_readfirstlane(x_r2);
@@ -269,11 +273,15 @@ __device__ __forceinline__ void score_tile(const GmmParams &p, int utt, int t_ba
       float mx[kNT], sum[kNT];
 #pragma unroll
       for (int n = 0; n < kNT; n++) {
+#ifdef GMM_DIAG_NO_EPILOGUE
+        mx[n] = acc[n][0] + acc[n][15]; sum[n] = 1.0f;
+#else
         float m = reg_max<0, 16>(acc[n]);
         m = fmaxf(m, swap32(m, h));
         float sv = reg_expsum<0, 16>(acc[n], m, m + p.min_log_diff);
         sv += swap32(sv, h);
         mx[n] = m; sum[n] = sv;
+#endif
       }
       if constexpr (kNT == 2) {
         // both halves hold every tile's (max, sum): half h finishes tile h (one log per lane).
@@ -282,7 +290,11 @@ __device__ __forceinline__ void score_tile(const GmmParams &p, int utt, int t_ba
         const float v = finish(h ? mx[1] : mx[0], h ? sum[1] : sum[0]);
         const int jj = (j - first32) & 31;
         stage[(32 * h + col) * 33 + jj] = v;
+#ifdef GMM_DIAG_NO_FLUSH
+        if (v == 12345.678f) {   // never true, but keeps the scores alive
+#else
         if (jj == 31 || j == last) {
+#endif
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

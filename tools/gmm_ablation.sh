@@ -1,0 +1,17 @@
+#!/bin/bash
+# Timing-only ablations of the scoring kernel (cdna_hip_programming.md §7 "Ablate"): rebuild libmfa_hip.so on the GPU box
+# with one phase removed, time the bench's scoring launch, restore the real build.  Scores are wrong in these builds;
+# only stage_ms_per_step.gmm matters.    bash tools/gmm_ablation.sh  (through gpurun, from the repo root)
+set -eo pipefail
+run() {
+  MFA_GMM_DIAG=1 python bench.py --no-cpu-baseline --steps 3 2>>gpurun_out/ablation.err | python -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', d['stage_ms_per_step']['gmm'])"
+}
+build() { MFA_HIPCC_FLAGS="$1" python -c "
+import sys; sys.path.insert(0, '.')
+from montreal_forced_aligner_amd import _lib; _lib.build_native(force=True)" 2>/dev/null; }
+run full
+for f in -DGMM_DIAG_NO_EPILOGUE -DGMM_DIAG_NO_LOADS -DGMM_DIAG_NO_FLUSH "-DGMM_DIAG_NO_EPILOGUE -DGMM_DIAG_NO_LOADS -DGMM_DIAG_NO_FLUSH"; do
+  build "$f"; run "$f"
+done
+build ""
