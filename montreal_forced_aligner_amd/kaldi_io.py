@@ -145,6 +145,55 @@ def write_matrix(f: BinaryIO, m: np.ndarray) -> None:
     f.write(m.tobytes())
 
 
+def write_compressed_matrix(f: BinaryIO, m: np.ndarray) -> None:
+    """Kaldi CompressedMatrix, method kOneByteWithColHeaders ("CM"): what ``compute_mfccs_for_export(seg, compress=True)``
+    and FinalFeatureFunction write into feats.*.ark (MFA/corpus/features.py:235, :364; Kaldi matrix/compressed-matrix.cc:
+    ComputeGlobalHeader, ComputeColHeader, FloatToChar).  Columns are stored one after another, one
+    byte per value, quantised piecewise-linearly between the column's 0/25/75/100-th percentiles (uint16 on a global range).
+    Columns shorter than five rows use Kaldi's small-matrix rule (percentiles from the sorted values directly)."""
+    m = np.ascontiguousarray(m, dtype=np.float32)
+    rows, cols = m.shape
+    if rows == 0 or cols == 0:
+        raise ValueError("cannot compress an empty matrix")
+    mn, mx = float(m.min()), float(m.max())
+    if mx == mn:
+        mx = mn + (1.0 + abs(mn))
+    mn32, rng32 = np.float32(mn), np.float32(np.float32(mx) - np.float32(mn))
+    _w_token(f, "CM")
+    f.write(struct.pack("<ffii", float(mn32), float(rng32), rows, cols))
+
+    def to_u16(v):
+        fr = (np.float32(v) - mn32) / rng32
+        fr = min(max(float(fr), 0.0), 1.0)
+        return int(fr * 65535 + 0.499)
+
+    hdr = np.zeros((cols, 4), dtype=np.uint16)
+    data = np.zeros((cols, rows), dtype=np.uint8)
+    inc = np.float32(rng32 * np.float32(1.0 / 65535.0))
+    for c in range(cols):
+        col = m[:, c]
+        sd = np.sort(col)
+        if rows >= 5:
+            q = rows // 4
+            p0 = min(to_u16(sd[0]), 65532)
+            p25 = min(max(to_u16(sd[q]), p0 + 1), 65533)
+            p75 = min(max(to_u16(sd[3 * q]), p25 + 1), 65534)
+            p100 = max(to_u16(sd[rows - 1]), p75 + 1)
+        else:
+            p0 = min(to_u16(sd[0]), 65532)
+            p25 = min(max(to_u16(sd[1]) if rows > 1 else p0 + 1, p0 + 1), 65533)
+            p75 = min(max(to_u16(sd[2]) if rows > 2 else p25 + 1, p25 + 1), 65534)
+            p100 = max(to_u16(sd[3]) if rows > 3 else p75 + 1, p75 + 1)
+        hdr[c] = (p0, p25, p75, p100)
+        f0, f25, f75, f100 = (np.float32(mn32 + inc * np.float32(x)) for x in (p0, p25, p75, p100))
+        lo = np.clip(((col - f0) / (f25 - f0) * 64 + 0.5).astype(np.int64), 0, 64)
+        mid = np.clip(64 + ((col - f25) / (f75 - f25) * 128 + 0.5).astype(np.int64), 64, 192)
+        hi = np.clip(192 + ((col - f75) / (f100 - f75) * 63 + 0.5).astype(np.int64), 192, 255)
+        data[c] = np.where(col < f25, lo, np.where(col < f75, mid, hi)).astype(np.uint8)
+    f.write(hdr.astype("<u2").tobytes())
+    f.write(data.tobytes())
+
+
 def write_vector(f: BinaryIO, v: np.ndarray) -> None:
     v = np.ascontiguousarray(v)
     if v.dtype == np.float64:
@@ -532,6 +581,8 @@ def write_ark_entry(f: BinaryIO, key: str, obj, kind: str) -> int:
     f.write(b"\0B")
     if kind == "matrix":
         write_matrix(f, obj)
+    elif kind == "compressed_matrix":
+        write_compressed_matrix(f, obj)
     elif kind == "vector":
         write_vector(f, obj)
     elif kind == "int_vector":
@@ -539,6 +590,43 @@ def write_ark_entry(f: BinaryIO, key: str, obj, kind: str) -> int:
     else:
         raise ValueError(kind)
     return off
+
+
+def write_table(ark_path, entries, kind: str, scp_path=None) -> None:
+    """Write a binary ark (and its scp: ``key path:offset``) from (key, object) pairs — Kaldi ``ark,scp:`` wspecifier."""
+    ark_path = Path(ark_path)
+    lines = []
+    with open(ark_path, "wb") as f:
+        for key, obj in entries:
+            off = write_ark_entry(f, key, obj, kind)
+            lines.append(f"{key} {ark_path}:{off}\n")
+    if scp_path is not None:
+        Path(scp_path).write_text("".join(lines), encoding="utf8")
+
+
+def read_scp(scp_path) -> List[Tuple[str, str, int]]:
+    """(key, ark path, byte offset) per line of a Kaldi scp."""
+    out = []
+    for line in Path(scp_path).read_text(encoding="utf8").splitlines():
+        line = line.strip()
+        if not line:
+            continue
+        key, rest = line.split(None, 1)
+        path, _, off = rest.rpartition(":")
+        out.append((key, path, int(off)))
+    return out
+
+
+def read_scp_object(ark_cache: Dict[str, bytes], path: str, offset: int, kind: str):
+    """Object an scp line points at (``offset`` = first byte after the key's space)."""
+    if path not in ark_cache:
+        ark_cache[path] = Path(path).read_bytes()
+    r = BinaryReader(ark_cache[path])
+    r.p = offset
+    if kind == "fst":
+        return read_fst(r)
+    r.expect_binary_header()
+    return {"matrix": r.matrix, "vector": r.vector, "int_vector": r.int_vector}[kind]()
 
 
 def load_acoustic_model_archive(path) -> Dict[str, bytes]:

@@ -19,7 +19,7 @@ from __future__ import annotations
 import os
 from dataclasses import dataclass
 from pathlib import Path
-from typing import Dict, Iterable, List, Optional, Sequence, Tuple, Union
+from typing import Dict, Iterable, Iterator, List, Optional, Sequence, Tuple, Union
 
 import numpy as np
 
@@ -91,9 +91,50 @@ class MfccComputer:
         out, _ = eng.mfcc(torch.from_numpy(pcm.copy()).to(eng.device), np.array([0, pcm.shape[0]], dtype=np.int64))
         return out.cpu().numpy()
 
-    def compute_mfccs_for_export(self, segment, compress: bool = True) -> np.ndarray:
-        """The corpus path writes these 8-bit compressed; this engine keeps float32."""
-        return self.compute_mfccs(segment)
+    def compute_mfccs_for_export(self, segment, compress: bool = True):
+        """``compress=True``: the matrix wrapped so that ``kaldi_io.write_ark_entry`` stores it as a Kaldi CompressedMatrix
+        (what MfccFunction writes, MFA/corpus/features.py:235); ``compress=False``: the float32 matrix (FineTuneFunction)."""
+        m = self.compute_mfccs(segment)
+        return CompressedFeatures(m) if compress else m
+
+    def export_feats(self, file_name, segments: Iterable[Tuple[str, Union["Segment", np.ndarray]]], write_scp: bool = True,
+                     compress: bool = True, batch_size: int = 256) -> None:
+        """``feats.*.ark`` (+ ``.scp``) for (key, segment) pairs, MFCCs computed in device batches (MfccFunction._run)."""
+        import torch
+
+        eng = self._configure()
+        ark = Path(file_name)
+        scp = ark.with_suffix(".scp") if write_scp else None
+        lines = []
+        with open(ark, "wb") as f:
+            batch: List[Tuple[str, np.ndarray]] = []
+
+            def flush():
+                if not batch:
+                    return
+                so = np.concatenate([[0], np.cumsum([len(x) for _, x in batch])]).astype(np.int64)
+                out, fo = eng.mfcc(torch.from_numpy(np.concatenate([x for _, x in batch])).to(eng.device), so)
+                out = out.cpu().numpy()
+                for i, (key, _) in enumerate(batch):
+                    off = kaldi_io.write_ark_entry(f, key, out[fo[i]: fo[i + 1]], "compressed_matrix" if compress else "matrix")
+                    lines.append(f"{key} {ark}:{off}\n")
+                batch.clear()
+
+            for key, seg in segments:
+                pcm = seg.load_audio() if isinstance(seg, Segment) else np.asarray(seg, dtype=np.int16)
+                batch.append((key, np.ascontiguousarray(pcm, dtype=np.int16)))
+                if len(batch) >= batch_size:
+                    flush()
+            flush()
+        if scp is not None:
+            scp.write_text("".join(lines), encoding="utf8")
+
+
+class CompressedFeatures(np.ndarray):
+    """A float32 matrix tagged for 8-bit storage: ``FeatureArchive``/``write_features`` write it as Kaldi "CM"."""
+
+    def __new__(cls, m):
+        return np.asarray(m, dtype=np.float32).view(cls)
 
 
 class CmvnComputer:
@@ -105,6 +146,147 @@ class CmvnComputer:
         frame_off = np.concatenate([[0], np.cumsum([f.shape[0] for f in feats])]).astype(np.int64)
         d = torch.from_numpy(np.concatenate(feats).astype(np.float32)).to(eng.device)
         return eng.cmvn_stats(d, frame_off, np.zeros(len(feats), dtype=np.int32), 1).cpu().numpy()[0]
+
+
+    def export_cmvn(self, file_name, feature_archive, spk2utt: Dict[str, Sequence[str]], write_scp: bool = True) -> None:
+        """Per-speaker statistics → ``cmvn.ark`` (+ ``.scp``) of float64 [2, dim+1] matrices keyed by speaker
+        (calc_cmvn, MFA/corpus/acoustic_corpus.py:1315-1367).  ``feature_archive``: (utt key, matrix) pairs or a dict."""
+        feats = dict(feature_archive) if not isinstance(feature_archive, dict) else feature_archive
+        entries = []
+        for spk in sorted(spk2utt):
+            mats = [np.asarray(feats[u]) for u in spk2utt[spk] if u in feats]
+            if mats:
+                entries.append((str(spk), self.compute_cmvn_from_features(mats)))
+        ark = Path(file_name)
+        kaldi_io.write_table(ark, entries, "matrix", ark.with_suffix(".scp") if write_scp else None)
+
+
+class FeatureArchive:
+    """``FeatureArchive(scp, utt2spk=, cmvn_file_name=, lda_mat_file_name=, transform_file_name=, deltas=, …)``: iterable of
+    (utt_id, final feature matrix) — Job.construct_feature_archive's chain (MFA/db.py:2101-2136): base features from the
+    scp (compressed or not) → per-speaker CMVN → Δ+ΔΔ or splice(±3)+LDA → per-speaker fMLLR.  Utterances are pushed
+    through the device in batches of ``batch_size``; ``utt2spk`` is a dict or a Kaldi utt2spk file."""
+
+    def __init__(self, file_name, utt2spk=None, cmvn_file_name=None, lda_mat_file_name=None, transform_file_name=None,
+                 vad_file_name=None, deltas: bool = False, splices: bool = False, splice_frames: int = 3, subsample_n: int = 0,
+                 use_sliding_cmvn: bool = False, batch_size: int = 256):
+        if vad_file_name is not None or subsample_n or use_sliding_cmvn:
+            raise NotImplementedError("vad / subsampling / sliding CMVN are not part of the alignment path")
+        self.file_name = Path(file_name)
+        self.utt2spk = self._read_map(utt2spk)
+        self.cmvn_read_specifier = cmvn_file_name
+        self.lda_mat_file_name = lda_mat_file_name
+        self.transform_read_specifier = transform_file_name
+        self.use_splices = bool(splices or lda_mat_file_name)
+        self.use_deltas = bool(deltas) and not self.use_splices
+        self.splice_frames = splice_frames
+        self.batch_size = batch_size
+        self._entries = kaldi_io.read_scp(self.file_name) if self.file_name.suffix == ".scp" else None
+        self._cache: Dict[str, bytes] = {}
+        self._cmvn = self._read_table(cmvn_file_name)
+        self._trans = self._read_table(transform_file_name)
+        self._lda = None if lda_mat_file_name is None else kaldi_io.read_matrix_file(Path(lda_mat_file_name).read_bytes())
+
+    @staticmethod
+    def _read_map(m):
+        if m is None or isinstance(m, dict):
+            return m
+        return dict(line.split()[:2] for line in Path(m).read_text(encoding="utf8").splitlines() if line.strip())
+
+    def _read_table(self, name) -> Optional[Dict[str, np.ndarray]]:
+        if name is None:
+            return None
+        name = Path(name)
+        if name.suffix == ".scp":
+            return {k: kaldi_io.read_scp_object(self._cache, p, o, "matrix") for k, p, o in kaldi_io.read_scp(name)}
+        return dict(kaldi_io.read_ark(name.read_bytes(), "matrix"))
+
+    def _base(self) -> Iterator[Tuple[str, np.ndarray]]:
+        if self._entries is not None:
+            for key, path, off in self._entries:
+                yield key, kaldi_io.read_scp_object(self._cache, path, off, "matrix")
+        else:
+            yield from kaldi_io.read_ark(self.file_name.read_bytes(), "matrix")
+
+    def __iter__(self) -> Iterator[Tuple[str, np.ndarray]]:
+        import torch
+
+        eng = get_engine()
+        batch: List[Tuple[str, np.ndarray]] = []
+
+        def flush():
+            spk_names = [self.utt2spk.get(k, k) if self.utt2spk else k for k, _ in batch]
+            ids = {s: i for i, s in enumerate(dict.fromkeys(spk_names))}
+            u2s = np.array([ids[s] for s in spk_names], dtype=np.int32)
+            dim = batch[0][1].shape[1]
+            cm = None
+            if self._cmvn is not None:
+                st = np.zeros((len(ids), 2, dim + 1), dtype=np.float64)
+                st[:, 0, dim] = 1.0   # a speaker without statistics keeps its features (mean 0 over count 1)
+                for s, i in ids.items():
+                    if s in self._cmvn:
+                        st[i] = self._cmvn[s]
+                cm = torch.from_numpy(st).to(eng.device)
+            lda = None if self._lda is None else torch.from_numpy(self._lda.astype(np.float32)).to(eng.device)
+            fm = None
+            if self._trans is not None and lda is not None:
+                R = lda.shape[0]
+                ft = np.tile(np.eye(R, R + 1, dtype=np.float32), (len(ids), 1, 1))
+                for s, i in ids.items():
+                    if s in self._trans:
+                        ft[i] = self._trans[s]
+                fm = torch.from_numpy(ft).to(eng.device)
+            fo = np.concatenate([[0], np.cumsum([m.shape[0] for _, m in batch])]).astype(np.int64)
+            d = torch.from_numpy(np.concatenate([m for _, m in batch]).astype(np.float32)).to(eng.device)
+            if self.use_splices and lda is None:
+                raise NotImplementedError("spliced features without an LDA matrix")
+            if not self.use_deltas and lda is None:
+                out = d if cm is None else None
+                if out is None:   # CMVN only (FinalFeatureFunction's output): Δ kernel's first block is the CMVN-applied base
+                    out = eng.features(d, fo, u2s, cm)[:, :dim]
+                out = out.cpu().numpy()
+            else:
+                out = eng.features(d, fo, u2s, cm, lda=lda, fmllr=fm, splice_context=self.splice_frames).cpu().numpy()
+            res = [(k, out[fo[i]: fo[i + 1]].copy()) for i, (k, _) in enumerate(batch)]
+            batch.clear()
+            return res
+
+        for key, m in self._base():
+            batch.append((key, m))
+            if len(batch) >= self.batch_size:
+                yield from flush()
+        if batch:
+            yield from flush()
+
+    def close(self) -> None:
+        self._cache.clear()
+
+
+class AlignmentArchive:
+    """``AlignmentArchive(ali, words_file_name=, likelihood_file_name=)``: iterable of Alignment and ``archive[utt_id]``
+    (KeyError when absent) over the arks ``GmmAligner.export_alignments`` writes (MFA/alignment/multiprocessing.py:1856)."""
+
+    def __init__(self, file_name, words_file_name=None, likelihood_file_name=None):
+        self._ali = dict(kaldi_io.read_ark(Path(file_name).read_bytes(), "int_vector"))
+        self._words = dict(kaldi_io.read_ark(Path(words_file_name).read_bytes(), "int_vector")) if words_file_name else {}
+        self._likes = dict(kaldi_io.read_ark(Path(likelihood_file_name).read_bytes(), "vector")) if likelihood_file_name else {}
+
+    def _make(self, key) -> "Alignment":
+        pf = self._likes.get(key)
+        like = float(np.sum(pf)) if pf is not None else float("nan")
+        return Alignment(key, self._ali[key].tolist(), self._words.get(key, np.zeros(0, np.int32)).tolist(), like, pf)
+
+    def __getitem__(self, key) -> "Alignment":
+        if key not in self._ali:
+            raise KeyError(key)
+        return self._make(key)
+
+    def __iter__(self):
+        for key in self._ali:
+            yield self._make(key)
+
+    def close(self) -> None:
+        pass
 
 
 class Utterance:

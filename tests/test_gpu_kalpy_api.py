@@ -66,3 +66,58 @@ def test_align_utterance_online_sequence(fx, tmp_path):
     assert ref["status"] in (0, 1)
     assert np.array_equal(np.asarray(alignment.alignment), ref["ali"])
     assert abs(alignment.likelihood - ref["like"]) / 420 < 1e-3
+
+
+def test_archives_follow_the_corpus_file_flow(fx, tmp_path):
+    """feats.ark/scp (compressed) → cmvn.ark → FeatureArchive (CMVN + deltas) → export_alignments → AlignmentArchive:
+    the table files the corpus path passes between MfccFunction, calc_cmvn, AlignFunction and the extraction step
+    (SURVEY §8b "on-disk formats at the boundary")."""
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from montreal_forced_aligner_amd import kaldi_io as K
+    from montreal_forced_aligner_amd import kalpy_api as KA
+
+    ar = K.load_acoustic_model_archive(helpers.REF / "mono_model.zip")
+    (tmp_path / "final.mdl").write_bytes(ar["final.mdl"])
+    (tmp_path / "tree").write_bytes(ar["tree"])
+    cuts = {"1-1": (0.0, 4.2, "this is the acoustic corpus i'm talking pretty fast here"),
+            "1-2": (4.0, 6.5, "there's nothing going else going on")}
+    mfcc_computer = KA.MfccComputer(sample_frequency=16000, frame_length=25, frame_shift=10, num_mel_bins=23,
+                                    num_coefficients=13, snip_edges=False, dither=0.0, use_energy=False)
+    segs = [(k, fx.pcm[int(a * 16000): int(b * 16000)]) for k, (a, b, _) in cuts.items()]
+    mfcc_computer.export_feats(tmp_path / "feats.ark", segs, write_scp=True, compress=True)
+    raw = dict(K.read_ark((tmp_path / "feats.ark").read_bytes(), "matrix"))
+    direct = {k: mfcc_computer.compute_mfccs(x) for k, x in segs}
+    for k in raw:   # 8-bit codec: coarse but close
+        assert raw[k].shape == direct[k].shape and np.abs(raw[k] - direct[k]).max() < 0.02 * (direct[k].max() - direct[k].min())
+    KA.CmvnComputer().export_cmvn(tmp_path / "cmvn.ark", raw, {"1": ["1-1", "1-2"]})
+    cm = dict(K.read_ark((tmp_path / "cmvn.ark").read_bytes(), "matrix"))["1"]
+    assert cm.shape == (2, 14) and cm.dtype == np.float64 and cm[0, 13] == sum(v.shape[0] for v in raw.values())
+    fa = KA.FeatureArchive(tmp_path / "feats.scp", utt2spk={"1-1": "1", "1-2": "1"}, cmvn_file_name=tmp_path / "cmvn.scp",
+                           deltas=True)
+    feats = dict(fa)
+    assert fa.use_deltas and not fa.use_splices
+    for k, m in raw.items():   # same chain through the oracle on the decompressed matrices
+        ref = O.deltas(O.cmvn_apply(cm, m))
+        assert np.abs(feats[k] - ref).max() < 1e-3
+    lex = KA.LexiconCompiler(position_dependent_phones=True, phones=fx.mono_meta["phones"], silence_phone="sp", oov_phone="spn")
+    lex.load_pronunciations(helpers.REF / "test_acoustic.txt")
+    lex.build_phone_table(["sil", "sp", "spn"])
+    gc = KA.TrainingGraphCompiler(tmp_path / "final.mdl", tmp_path / "tree", lex)
+    gc.export_graphs(tmp_path / "fsts.ark", [(k, t) for k, (_a, _b, t) in cuts.items()])
+    graphs = list(K.read_ark((tmp_path / "fsts.ark").read_bytes(), "fst"))
+    aligner = KA.GmmAligner(tmp_path / "final.mdl", beam=100, retry_beam=400)
+    seen = []
+    aligner.export_alignments(tmp_path / "ali.ark", graphs, feats, word_file_name=tmp_path / "words.ark",
+                              likelihood_file_name=tmp_path / "likes.ark", callback=seen.append)
+    assert [k for k, _ in seen] == list(cuts) and all(like is not None for _, like in seen)
+    aa = KA.AlignmentArchive(tmp_path / "ali.ark", words_file_name=tmp_path / "words.ark", likelihood_file_name=tmp_path / "likes.ark")
+    al = aa["1-2"]
+    assert len(al.alignment) == feats["1-2"].shape[0] and len(al.words) == len(cuts["1-2"][2].split())
+    assert [a.utterance_id for a in aa] == list(cuts)
+    with pytest.raises(KeyError):
+        aa["1-3"]
+    direct_al = aligner.align_utterance(graphs[1][1], feats["1-2"])
+    assert direct_al.alignment == al.alignment and direct_al.words == al.words

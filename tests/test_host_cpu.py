@@ -126,3 +126,37 @@ def test_two_rank_gloo_sharding(tmp_path):
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
     assert all("ok" in o for o in outs)
+
+
+def test_compressed_matrix_round_trip_and_scp(tmp_path):
+    """Kaldi CompressedMatrix ("CM") writer against the reader: values come back within the format's quantisation step
+    (1/64, 1/128, 1/63 of the column's inter-percentile segments), headers are monotone, scp offsets land on the objects."""
+    import io
+
+    from montreal_forced_aligner_amd import kaldi_io as K
+
+    rng = np.random.default_rng(5)
+    m = (rng.standard_normal((137, 13)) * np.linspace(0.5, 30, 13) + np.linspace(-20, 40, 13)).astype(np.float32)
+    m[:, 3] = 7.25                      # a constant column still needs strictly increasing percentiles
+    buf = io.BytesIO()
+    K.write_compressed_matrix(buf, m)
+    assert len(buf.getvalue()) == 3 + 16 + 8 * 13 + 137 * 13       # "CM " + global header + column headers + one byte per value
+    back = K.BinaryReader(buf.getvalue()).matrix()
+    assert back.shape == m.shape
+    for c in range(m.shape[1]):
+        sd = np.sort(m[:, c])
+        q = m.shape[0] // 4
+        step = max(sd[q] - sd[0], sd[3 * q] - sd[q], sd[-1] - sd[3 * q]) / 63.0 + (m.max() - m.min()) / 65535.0 * 2
+        assert np.abs(back[:, c] - m[:, c]).max() <= step, c
+    small = rng.standard_normal((3, 4)).astype(np.float32)      # fewer than five rows: Kaldi's small-matrix rule
+    buf = io.BytesIO()
+    K.write_compressed_matrix(buf, small)
+    assert np.abs(K.BinaryReader(buf.getvalue()).matrix() - small).max() < 0.05 * (small.max() - small.min()) + 1e-3
+    # table + scp
+    ark, scp = tmp_path / "feats.ark", tmp_path / "feats.scp"
+    K.write_table(ark, [("spk1-utt1", m), ("spk1-utt2", small)], "compressed_matrix", scp)
+    entries = K.read_scp(scp)
+    assert [e[0] for e in entries] == ["spk1-utt1", "spk1-utt2"]
+    cache = {}
+    assert K.read_scp_object(cache, entries[1][1], entries[1][2], "matrix").shape == (3, 4)
+    assert [k for k, _ in K.read_ark(ark.read_bytes(), "matrix")] == ["spk1-utt1", "spk1-utt2"]
