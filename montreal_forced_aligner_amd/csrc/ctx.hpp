@@ -10,6 +10,16 @@
 
 #include "../../include/mfa_hip.h"
 
+// Packed model layout (built by mfa_load_gmm, read by gmm.hip and fmllr.hip).  Rows (Gaussians) are grouped in blocks of
+// 32; a block is stored operand-major: for every group m of 8 k-values and half h, the 32 rows' 4-float pieces lie side
+// by side —  float offset of (row, logical k = 8m + 2c + h):
+//     (row >> 5) · 32·kpad  +  ((2m + h) · 32 + (row & 31)) · 4  +  c
+// so the 16-byte A-operand loads of the 32 lanes of a half-wavefront (one row each) read 512 contiguous bytes.
+__host__ __device__ inline size_t mfa_packed_offset(int row, int k, int kpad) {
+  const int m = k >> 3, o = k & 7, h = o & 1, c = o >> 1;
+  return (size_t)(row >> 5) * 32 * kpad + (size_t)(((2 * m + h) * 32 + (row & 31)) * 4 + c);
+}
+
 enum { MFA_K_MFCC = 0, MFA_K_CMVN = 1, MFA_K_FEATS = 2, MFA_K_GMM = 3, MFA_K_VITERBI = 4, MFA_K_COUNT = 5 };
 
 struct mfa_ctx {

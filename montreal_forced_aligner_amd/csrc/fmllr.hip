@@ -24,7 +24,6 @@ struct FmllrFrameParams {
 };
 
 // logical k of a packed row is stored at 8m + 4(o&1) + (o>>1) with k = 8m + o
-__device__ __forceinline__ int packed_index(int k) { int m = k >> 3, o = k & 7; return 8 * m + 4 * (o & 1) + (o >> 1); }
 
 __global__ __launch_bounds__(256) void fmllr_frame_kernel(FmllrFrameParams p) {
   __shared__ float post_s[4][128];
@@ -50,10 +49,9 @@ __global__ __launch_bounds__(256) void fmllr_frame_kernel(FmllrFrameParams p) {
     const int g = lane + 64 * rnd;
     float acc = -INFINITY;
     if (g < n) {
-      const float *wr = p.w + (size_t)(r0 + g) * p.kpad;
       acc = p.gc[r0 + g];
-      for (int k = 0; k < p.D; k++) acc = fmaf(wr[packed_index(k)], x[k], acc);
-      for (int k = 0; k < p.D; k++) { float xv = x[k]; acc = fmaf(wr[packed_index(p.D + k)], xv * xv, acc); }
+      for (int k = 0; k < p.D; k++) acc = fmaf(p.w[mfa_packed_offset(r0 + g, k, p.kpad)], x[k], acc);
+      for (int k = 0; k < p.D; k++) { float xv = x[k]; acc = fmaf(p.w[mfa_packed_offset(r0 + g, p.D + k, p.kpad)], xv * xv, acc); }
     }
     ll[rnd] = acc;
     mx = fmaxf(mx, acc);
@@ -75,9 +73,8 @@ __global__ __launch_bounds__(256) void fmllr_frame_kernel(FmllrFrameParams p) {
     float a = 0.0f, b = 0.0f;
     for (int g = 0; g < n; g++) {
       const float pg = ((volatile float *)post)[g];
-      const float *wr = p.w + (size_t)(r0 + g) * p.kpad;
-      a = fmaf(wr[packed_index(lane)], pg, a);
-      b = fmaf(-2.0f * wr[packed_index(p.D + lane)], pg, b);  // stored −½·inv_var
+      a = fmaf(p.w[mfa_packed_offset(r0 + g, lane, p.kpad)], pg, a);
+      b = fmaf(-2.0f * p.w[mfa_packed_offset(r0 + g, p.D + lane, p.kpad)], pg, b);  // stored −½·inv_var
     }
     a_out[lane] = a; b_out[lane] = b;
   }

@@ -7,10 +7,10 @@
 // Per pdf:       LL = max + log Σ_{ll ≥ max+ln ε} exp(ll − max)  (Kaldi: expf, double sum, log; here: hardware exp2/log2
 //                and a float32 tree sum — within 1 ulp of the Kaldi value at score magnitudes ≥ 16, see reg_expsum).
 //
-// Packed model (built once in mfa_load_gmm): every pdf owns `slot` consecutive rows of W[rows][kpad]
-// (slot ∈ {1,4,8,16,32·n}; pad rows have zero weights and gconst −1e30 so they fall under the cutoff).  Within each group
-// of 8 k-values a row is stored permuted, stored[8m+4h+c] = logical[8m+2c+h], so that one 16-byte load per lane yields the
-// A operands of four consecutive MFMA steps (lane l feeds A[row l&31][k = 2s + (l>>5)]).
+// Packed model (built once in mfa_load_gmm): every pdf owns `slot` consecutive rows (slot ∈ {1,4,8,16,32·n}; pad rows have
+// zero weights and gconst −1e30 so they fall under the cutoff).  Rows are stored in blocks of 32, operand-major
+// (mfa_packed_offset in ctx.hpp): one 16-byte load per lane yields the A operands of four consecutive MFMA steps (lane l
+// feeds A[row l&31][k = 2s + (l>>5)]), and the 32 lanes of a half-wavefront read 512 contiguous bytes.
 // One 32-row MFMA block then serves 32/slot pdfs of the utterance's (slot-sorted) pdf list; rows ↔ accumulator registers:
 // row = (r&3) + 8(r>>2) + 4(l>>5), so 4-row slots reduce inside a lane and 8/16/32-row slots add one cross-half shuffle.
 //
@@ -65,6 +65,11 @@ __device__ __forceinline__ float swap32(float v, int h) {
   return __shfl_xor(v, 32);
 #endif
 }
+// address of the 4-float piece (operand group 0, half h) of a packed row: see mfa_packed_offset in ctx.hpp
+__device__ __forceinline__ const float *row_ptr(const float *w, int kpad, int row, int h) {
+  return w + (size_t)(row >> 5) * 32 * kpad + (h * 32 + (row & 31)) * 4;
+}
+
 template <int M8, int kNT>
 struct Tile {
   // One wavefront: B operands for kNT frame tiles, generic block evaluation.
@@ -90,9 +95,10 @@ struct Tile {
 
   // acc[n] = gconst(rows) + W(block rows) · x̃(tile n).  arow: this lane's A row (already offset by 4h floats);
   // gcv: gconst of the row this lane (lane&31) addresses.
+  // arow: this lane's piece of operand group 0 (row_ptr below); group m lies 2·32·4 floats further on
   __device__ __forceinline__ static void load_a(const float *arow, f32x4 (&a)[M8]) {
 #pragma unroll
-    for (int m = 0; m < M8; m++) a[m] = *reinterpret_cast<const f32x4 *>(arow + 8 * m);
+    for (int m = 0; m < M8; m++) a[m] = *reinterpret_cast<const f32x4 *>(arow + 256 * m);
   }
   __device__ __forceinline__ void block(const float *arow, float gcv, int lane, f32x16 (&acc)[kNT]) const {
     f32x4 a[M8];
@@ -224,7 +230,7 @@ __device__ __forceinline__ void score_tile(const GmmParams &p, int utt, int t_ba
     const int last = n_single - 1;
     auto pdf_at = [&](int jj) { return __builtin_amdgcn_readfirstlane(list[min(jj, last)]); };
     auto row_of = [&](int pdf) { return __builtin_amdgcn_readfirstlane(p.row0[pdf]); };
-    const float *wl = p.w + (size_t)col * p.kpad + 4 * h;  // this lane's row within a block, k offset of its half
+    const float *wl = p.w + (h * 32 + col) * 4;  // this lane's piece inside a block (blocks start at multiples of 32 rows)
     f32x4 a[M8], g[4];
     int r1 = row_of(pdf_at(first32 + 1));
     int pdf2 = pdf_at(first32 + 2);
@@ -264,7 +270,7 @@ __device__ __forceinline__ void score_tile(const GmmParams &p, int utt, int t_ba
             acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][cc4], tile.b[n][4 * m + cc4], acc[n], 0, 0, 0);
         }
 #ifndef GMM_DIAG_NO_LOADS   // timing-only builds (tools/: -DGMM_DIAG_*): results are wrong by construction
-        a[m] = *reinterpret_cast<const f32x4 *>(wn + 8 * m);
+        a[m] = *reinterpret_cast<const f32x4 *>(wn + 256 * m);
 #endif
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -330,7 +336,7 @@ __device__ __forceinline__ void score_tile(const GmmParams &p, int utt, int t_ba
     for (int n = 0; n < kNT; n++) { mx[n] = -INFINITY; sum[n] = 0.0f; }
     for (int blk = 0; blk < nb; blk++) {
       const int rr = r0 + 32 * blk + col;
-      tile.block(p.w + (size_t)rr * p.kpad + 4 * h, p.gc[rr], lane, acc);
+      tile.block(row_ptr(p.w, p.kpad, rr, h), p.gc[rr], lane, acc);
 #pragma unroll
       for (int n = 0; n < kNT; n++) {
         float m = reg_max<0, 16>(acc[n]);
@@ -340,7 +346,7 @@ __device__ __forceinline__ void score_tile(const GmmParams &p, int utt, int t_ba
     }
     for (int blk = 0; blk < nb; blk++) {
       const int rr = r0 + 32 * blk + col;
-      tile.block(p.w + (size_t)rr * p.kpad + 4 * h, p.gc[rr], lane, acc);
+      tile.block(row_ptr(p.w, p.kpad, rr, h), p.gc[rr], lane, acc);
 #pragma unroll
       for (int n = 0; n < kNT; n++) {
         float sv = reg_expsum<0, 16>(acc[n], mx[n], mx[n] + p.min_log_diff);
@@ -362,7 +368,7 @@ __device__ __forceinline__ void score_tile(const GmmParams &p, int utt, int t_ba
     const int which = col >> 4, within = col & 15;
     const int idx = j + which;
     const int row = idx < cc[1] ? p.row0[list[base + idx]] + within : p.num_rows;
-    tile.block(p.w + (size_t)row * p.kpad + 4 * h, p.gc[row], lane, acc);
+    tile.block(row_ptr(p.w, p.kpad, row, h), p.gc[row], lane, acc);
 #pragma unroll
     for (int n = 0; n < kNT; n++) {
       int t = t_base + 32 * n + col;
@@ -382,7 +388,7 @@ __device__ __forceinline__ void score_tile(const GmmParams &p, int utt, int t_ba
     const int which = col >> 3, within = col & 7;
     const int idx = j + which;
     const int row = idx < cc[2] ? p.row0[list[base + idx]] + within : p.num_rows;
-    tile.block(p.w + (size_t)row * p.kpad + 4 * h, p.gc[row], lane, acc);
+    tile.block(row_ptr(p.w, p.kpad, row, h), p.gc[row], lane, acc);
 #pragma unroll
     for (int n = 0; n < kNT; n++) {
       int t = t_base + 32 * n + col;
@@ -407,7 +413,7 @@ __device__ __forceinline__ void score_tile(const GmmParams &p, int utt, int t_ba
     const int which = col >> 2, within = col & 3;
     const int idx = j + which;
     const int row = idx < cc[3] ? p.row0[list[base + idx]] + within : p.num_rows;
-    tile.block(p.w + (size_t)row * p.kpad + 4 * h, p.gc[row], lane, acc);
+    tile.block(row_ptr(p.w, p.kpad, row, h), p.gc[row], lane, acc);
 #pragma unroll
     for (int n = 0; n < kNT; n++) {
       int t = t_base + 32 * n + col;
@@ -429,7 +435,7 @@ __device__ __forceinline__ void score_tile(const GmmParams &p, int utt, int t_ba
   for (int j = 0; j < need[5]; j += 32) {
     const int idx = j + col;
     const int row = idx < cc[4] ? p.row0[list[base + idx]] : p.num_rows;
-    tile.block(p.w + (size_t)row * p.kpad + 4 * h, p.gc[row], lane, acc);
+    tile.block(row_ptr(p.w, p.kpad, row, h), p.gc[row], lane, acc);
 #pragma unroll
     for (int n = 0; n < kNT; n++) {
       int t = t_base + 32 * n + col;
@@ -551,12 +557,10 @@ __global__ void gmm_naive_kernel(GmmParams p) {
   double sum = 0.0;
   for (int pass = 0; pass < 2; pass++) {
     for (int r = 0; r < rows; r++) {
-      const float *w = p.w + (size_t)(r0 + r) * p.kpad;
       float acc = p.gc[r0 + r];
       for (int k = 0; k < 2 * p.dim; k++) {
-        int m = k >> 3, o = k & 7;  // logical k = 8m + 2c + h is stored at 8m + 4h + c
         float xv = k < p.dim ? x[k] : x[k - p.dim] * x[k - p.dim];
-        acc = fmaf(w[8 * m + 4 * (o & 1) + (o >> 1)], xv, acc);
+        acc = fmaf(p.w[mfa_packed_offset(r0 + r, k, p.kpad)], xv, acc);
       }
       if (pass == 0) mx = fmaxf(mx, acc);
       else if (acc >= mx + p.min_log_diff) sum += (double)expf(acc - mx);
@@ -593,17 +597,15 @@ MFA_API int mfa_load_gmm(mfa_ctx *c, int32_t dim, int32_t num_pdfs, const int32_
       if (slot[p] == cls) { row0[p] = rows; rows += cls == 32 ? 32 * nblk[p] : cls; }
   rows = (rows + 3) & ~3;
   row0[num_pdfs] = rows;
-  std::vector<float> w((size_t)(rows + 1) * kpad, 0.0f), gc(rows + 1, kPadGconst);
+  // whole 32-row blocks, plus room for the dummy row `rows` (zero weights, gconst −1e30) that idle lanes address
+  const int blocks = (rows + 1 + 31) / 32;
+  std::vector<float> w((size_t)blocks * 32 * kpad, 0.0f), gc((size_t)blocks * 32, kPadGconst);
   for (int p = 0; p < num_pdfs; p++) {
     int g0 = h_pdf_offsets[p], g = h_pdf_offsets[p + 1] - g0;
     for (int i = 0; i < g; i++) {
-      float *dst = w.data() + (size_t)(row0[p] + i) * kpad;
       const float *mi = h_means_invvars + (size_t)(g0 + i) * dim, *iv = h_inv_vars + (size_t)(g0 + i) * dim;
-      for (int k = 0; k < 2 * dim; k++) {
-        float v = k < dim ? mi[k] : -0.5f * iv[k - dim];
-        int m = k >> 3, o = k & 7;
-        dst[8 * m + 4 * (o & 1) + (o >> 1)] = v;  // stored[8m+4h+c] = logical[8m+2c+h]
-      }
+      for (int k = 0; k < 2 * dim; k++)
+        w[mfa_packed_offset(row0[p] + i, k, kpad)] = k < dim ? mi[k] : -0.5f * iv[k - dim];
       gc[row0[p] + i] = h_gconsts[g0 + i];
     }
   }
