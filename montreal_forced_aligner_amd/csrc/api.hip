@@ -23,7 +23,7 @@ MFA_API void mfa_destroy(mfa_ctx *c) {
   hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);
   void *ptrs[] = {c->d_window, c->d_twiddle, c->d_melw, c->d_melidx, c->d_dct, c->d_lifter, c->d_w, c->d_gc,
-                  c->d_row0, c->d_nblk, c->d_slot, c->d_ws, c->d_nrows, c->d_gmm_queue};
+                  c->d_row0, c->d_nblk, c->d_slot, c->d_ws, c->d_nrows, c->d_gmm_queue, c->d_wb};
   for (void *p : ptrs) if (p) hipFree(p);
   for (auto &p : c->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
   for (auto e : c->event_pool) hipEventDestroy(e);

@@ -53,6 +53,7 @@ struct mfa_ctx {
   bool gmm_ready = false;
   int dim = 0, kpad = 0, num_pdfs = 0, num_rows = 0;
   float *d_w = nullptr;        // [num_rows][kpad] permuted weights
+  void *d_wb = nullptr;        // bf16×3 split of d_w for gmm_bf16_kernel (see gmm.hip), or NULL
   float *d_gc = nullptr;       // [num_rows]
   int32_t *d_row0 = nullptr;   // [num_pdfs] first packed row
   int32_t *d_nblk = nullptr;   // [num_pdfs] number of 32-row blocks (slot 32) else 1

@@ -24,6 +24,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
+#include <cstring>
 #include <utility>
 #include <vector>
 
@@ -33,6 +34,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // a wavefront owns NT 32-frame tiles; a workgroup is kWaves wavefronts (template parameter)
 constexpr float kPadGconst = -1.0e30f;
@@ -40,15 +42,18 @@ constexpr float kPadGconst = -1.0e30f;
 struct GmmParams {
   int dim, kpad, num_rows;  // num_rows = index of the dummy row
   const float *w; const float *gc; const int32_t *row0; const int32_t *nblk; const int32_t *slot;
+  const uint4 *wb;   // bf16×3 split of the packed rows, 32-row blocks of [step][split][half][row] 16-byte units (or NULL)
   const float *feats; const int64_t *frame_off;
   const int32_t *pdf_list; const int64_t *pdf_off; const int32_t *class_counts; const int64_t *ll_off;
   unsigned long long *trace;   // debug (mfa_debug_gmm_trace): per workgroup {start, end, hw id, blocks} or NULL
+  int skip_single;             // 1: class 0 (single-block 32-row pdfs) is left to gmm_bf16_kernel
   int ff_bias;                 // debug (MFA_GMM_FF_BIAS): added to the tile's last frame before the reachability test
   const int32_t *first_frame;  // parallel to pdf_list (ascending inside each class) or NULL: see mfa_gmm_score_batch
   float *out;
   float min_log_diff;  // logf(FLT_EPSILON), computed on the host so device and oracle use the same constant
   int n_utt, tiles;    // tiles = 256-frame tiles per utterance (ceil(max_frames / 256)); items = (utterance, tile)
-  int *queue;          // [0..8) phase-1 and [8..16) phase-2 per-XCD item counters, [16] max first frame; zeroed per launch
+  int *queue;          // [0..8) phase-1 and [8..16) phase-2 per-XCD item counters; zeroed per launch
+  const int *max_ff;   // largest first_frame of the batch (device scalar)
 };
 
 // row index (within a 32-row MFMA block) held by accumulator register r of a lane in half h
@@ -167,6 +172,30 @@ __device__ __forceinline__ float reg_expsum(const f32x16 &v, float mx, float cut
     for (int r = 0; r + w < n; r += 2 * w) e[r] += e[r + w];
   return e[0];
 }
+// bf16×3 path: Σ_r exp(v[r] − mx) without Kaldi's cutoff (terms below max + ln ε add < 4e-6 to the sum in total — inside
+// that path's tolerance, and mathematically the exact log-sum-exp) and with the argument formed by one packed fma per two
+// terms; 16 exp2, 8 v_pk_fma_f32, 8 packed adds per tile instead of ≈110 instructions.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float reg_expsum_fast(const f32x16 &v, float mx) {
+  const float l2e = 1.44269504088896341f;
+  const f32x2 lv = {l2e, l2e};
+  const float nm = -mx * l2e;
+  const f32x2 nv = {nm, nm};
+  f32x2 e[8];
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    const f32x2 x = {v[2 * r], v[2 * r + 1]};
+    const f32x2 arg = __builtin_elementwise_fma(x, lv, nv);
+    e[r].x = __builtin_amdgcn_exp2f(arg.x);
+    e[r].y = __builtin_amdgcn_exp2f(arg.y);
+  }
+#pragma unroll
+  for (int w = 1; w < 8; w <<= 1)
+#pragma unroll
+    for (int r = 0; r + w < 8; r += 2 * w) e[r] += e[r + w];
+  return e[0].x + e[0].y;
+}
+
 // LL = max + ln(sum) with the hardware log2 (1 ulp on a value ≤ 7, i.e. ≲4e-7 absolute).
 __device__ __forceinline__ float finish(float mx, float sum) {
   return fmaf(__builtin_amdgcn_logf(sum), 0.693147180559945309f, mx);
@@ -213,11 +242,13 @@ __device__ __forceinline__ void score_tile(const GmmParams &p, int utt, int t_ba
     }
   }
   float *out = p.out + p.ll_off[utt];
+  // skip_single: the single-block pdfs are scored by gmm_bf16_kernel; only the other classes are left for this launch
+  if (p.skip_single && need[1] + need[2] + need[3] + need[4] + need[5] == 0) return;
 
   Tile<M8, kNT> tile;
   tile.load_b(p, f0, T, t_base, lane);
   f32x16 acc[kNT];
-  const int n_single = need[0];
+  const int n_single = p.skip_single ? 0 : need[0];
 
   // ---- single-block 32-row pdfs (the bulk of a context-dependent model): one pdf per MFMA block.
   // Software pipeline, no extra registers: as soon as the MFMAs that read operand group a[m] of block j have been issued,
@@ -483,7 +514,7 @@ __global__ __launch_bounds__(64 * kWaves, kMinWaves) void gmm_kernel(GmmParams p
   // leading tiles whose first sub-tile cannot yet see every pdf (first possible frame beyond that sub-tile's last frame)
   int light = 0;
   if (p.first_frame) {
-    const int mff = __builtin_amdgcn_readfirstlane(p.queue[16]);
+    const int mff = __builtin_amdgcn_readfirstlane(*p.max_ff);
     light = mff >= kFramesPerWave ? min(p.tiles, (mff - (kFramesPerWave - 1) + kFramesPerTile - 1) / kFramesPerTile) : 0;
   }
   const int heavy = p.tiles - light;
@@ -528,7 +559,206 @@ __global__ __launch_bounds__(64 * kWaves, kMinWaves) void gmm_kernel(GmmParams p
   }
 }
 
-// max over the batch of the pdfs' first possible frames → queue[16] (the persistent kernel derives its phase split from it)
+// ---------------------------------------------------------------------------------------------------------------------
+// bf16×3 scoring of the single-block 32-row pdfs on v_mfma_f32_32x32x16_bf16 (the default for that slot class;
+// MFA_GMM_BF16=0 sends it back to the bit-exact f32 kernel).
+// A float32 value is the exact sum of three bf16 pieces (8 + 8 + 8 mantissa bits), x = x1 + x2 + x3, and a product of two
+// bf16 values is exact in float32, so   x·w ≈ x1w1 + (x1w2 + x2w1) + (x1w3 + x2w2 + x3w1)   with a relative error of
+// ≈2^-24 per term — the error of ONE float32 rounding (tools/mfma_bf16_layout_test.hip: 5.0e-8 of Σ|terms| against
+// float64).  Six bf16 MFMAs of 32 cycles cover 16 k-values that cost eight f32 MFMAs of 64 cycles: 2.7× the f32 rate.
+// What changes is the order of the accumulation, so scores agree with the fmaf-chain oracle to float32 rounding noise
+// (≲2e-4 absolute on |score| ≈ 100; north_star's bar is 1e-3), not bit for bit like the f32 path.
+//
+// At this MFMA rate a wavefront cannot stream its own copy of the model rows (4× the L1/L2 traffic of the f32 kernel per
+// unit time), so the kernel is organised like a GEMM: the workgroup's four wavefronts (64 frames each, x̃ split once into
+// registers: 120 VGPRs) share every 32-row block through LDS, double-buffered — while block j is multiplied out of one
+// buffer, block j+1 travels global → registers → the other buffer; one barrier per block.
+template <int kSteps>   // 16-k steps per row: 5 for D ≤ 40, 6 for D ≤ 48
+__global__ __launch_bounds__(256, 2) void gmm_bf16_kernel(GmmParams p) {
+  constexpr int kNT = 2, kWaves = 4, kFramesPerWave = 64, kFramesPerTile = 256;
+  constexpr int kUnits = kSteps * 3 * 2 * 32;          // 16-byte units per block
+  constexpr int kLoads = (kUnits + 255) / 256;         // units each thread moves per block
+  const int lane0 = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ float stage_all[kWaves][64 * 33];
+  __shared__ uint4 a_lds[2][kUnits];
+  __shared__ __attribute__((aligned(16))) float gc_lds[2][32];
+  constexpr int kBlkCache = 1024;                     // pdf → 32-row block index, staged per item (two dependent global
+  __shared__ int blk_lds[kBlkCache];                  // loads per pdf must not sit in the block loop)
+  __shared__ int s_item;
+  float *stage = stage_all[wave];
+  const int my_xcd = (int)(__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u);
+  for (int hop = 0; hop < 8; hop++) {
+    const int q = (my_xcd + hop) & 7;
+    const int n_items = ((p.n_utt - q + 7) >> 3) * p.tiles;
+    for (;;) {
+      __syncthreads();
+      if (threadIdx.x == 0) s_item = atomicAdd(&p.queue[q], 1);
+      __syncthreads();
+      const int item = s_item;
+      if (item >= n_items) break;
+      int lane = lane0;                                // opaque per item: keeps lane-dependent addresses out of long-lived registers
+      asm volatile("" : "+v"(lane));
+      const int col = lane & 31, h = lane >> 5;
+      const int utt = (item / p.tiles) * 8 + q, tl = p.tiles - 1 - item % p.tiles;
+      const int64_t f0 = p.frame_off[utt];
+      const int T = (int)(p.frame_off[utt + 1] - f0);
+      if (tl * kFramesPerTile >= T) continue;          // uniform over the workgroup
+      const int t_base = (tl * kWaves + wave) * kFramesPerWave;
+      const bool active = t_base < T;                  // a wavefront past the end still helps move blocks and joins barriers
+      const int64_t l0 = p.pdf_off[utt];
+      const int P = (int)(p.pdf_off[utt + 1] - l0);
+      const int32_t *list = p.pdf_list + l0;
+      const int n_all = p.class_counts[(size_t)utt * 6];
+      // pdfs the tile's LAST frame can be asked for (the four wavefronts walk the same prefix: leading sub-tiles score a few
+      // cells they could have skipped — cheap at this rate, and it keeps the workgroup in step)
+      int n_single = n_all;
+      if (p.first_frame) {
+        const int t_last = min(T, (tl + 1) * kFramesPerTile) - 1 + p.ff_bias;
+        n_single = 0;
+        for (int i0 = 0; i0 < n_all; i0 += 64) {
+          const int i = i0 + lane;
+          n_single += __popcll(__ballot(i < n_all && p.first_frame[l0 + i] <= t_last));
+        }
+      }
+      float *out = p.out + p.ll_off[utt];
+      if (n_single > 0) {
+        // ---- x̃ = [x, x²] of this wavefront's 64 frames, split into bf16 triples: b[tile][step][piece], lane (frame, half)
+        bf16x8 b[kNT][kSteps][3];
+#pragma unroll
+        for (int n = 0; n < kNT; n++) {
+          int t = t_base + 32 * n + col;
+          t = t < T ? t : T - 1;
+          t = t < 0 ? 0 : t;
+          const float *x = p.feats + (f0 + t) * p.dim;
+#pragma unroll
+          for (int s = 0; s < kSteps; s++) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+              const int k = 16 * s + 8 * h + e;
+              const int idx = k < p.dim ? k : (k < 2 * p.dim ? k - p.dim : 0);
+              const float xv = x[idx];
+              const float v = k < p.dim ? xv : (k < 2 * p.dim ? xv * xv : 0.0f);
+              const __bf16 v1 = (__bf16)v;
+              const float r1 = v - (float)v1;
+              const __bf16 v2 = (__bf16)r1;
+              const float r2 = r1 - (float)v2;
+              b[n][s][0][e] = v1; b[n][s][1][e] = v2; b[n][s][2][e] = (__bf16)r2;
+            }
+          }
+        }
+        const int last = n_single - 1;
+        // Block copy global → LDS without a register stop (global_load_lds_dwordx4: every lane's 16 bytes land at a
+        // wavefront-uniform LDS base + 16·lane, which is exactly the linear unit order of a block).
+        typedef __attribute__((address_space(1))) const void *gptr_t;
+        typedef __attribute__((address_space(3))) void *lptr_t;
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+        auto fetch = [&](int blk, int buf) {
+          const uint4 *src = p.wb + (size_t)blk * kUnits;
+#pragma unroll
+          for (int i = 0; i < kLoads; i++) {
+            const int u0 = 64 * wave_u + 256 * i;        // first unit this wavefront moves in round i (uniform)
+            if (u0 < kUnits)
+              __builtin_amdgcn_global_load_lds((gptr_t)(src + u0 + lane), (lptr_t)&a_lds[buf][u0], 16, 0, 0);
+          }
+          if (wave_u == 0 && lane < 8)
+            __builtin_amdgcn_global_load_lds((gptr_t)(p.gc + (size_t)blk * 32 + 4 * lane), (lptr_t)&gc_lds[buf][0], 16, 0, 0);
+        };
+        auto landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+        for (int c0 = 0; c0 < n_single; c0 += kBlkCache) {
+        const int c1 = min(n_single, c0 + kBlkCache);
+        __syncthreads();                                   // previous chunk's table is no longer read
+        for (int i = c0 + threadIdx.x; i < c1; i += 256) blk_lds[i - c0] = p.row0[list[i]] >> 5;
+        __syncthreads();
+        auto block_of = [&](int jj) { return blk_lds[min(jj, c1 - 1) - c0]; };
+        fetch(block_of(c0), 0);
+        landed();
+        __syncthreads();
+        for (int j = c0; j < c1; j++) {
+          const int buf = (j - c0) & 1;
+#ifndef BF16_DIAG_NO_FETCH   // timing-only builds (tools/gmm_ablation.sh): results are wrong by construction
+          fetch(block_of(j + 1), buf ^ 1);                 // block j+1 (the chunk's last trip re-fetches its last block: harmless)
+#endif
+          if (active) {
+            f32x16 acc[kNT];
+            {
+              f32x16 init;
+#pragma unroll
+              for (int qq = 0; qq < 4; qq++) {
+                const float4 gq = *reinterpret_cast<const float4 *>(&gc_lds[buf][8 * qq + 4 * h]);
+                init[4 * qq] = gq.x; init[4 * qq + 1] = gq.y; init[4 * qq + 2] = gq.z; init[4 * qq + 3] = gq.w;
+              }
+#pragma unroll
+              for (int n = 0; n < kNT; n++) acc[n] = init;
+            }
+            // operand pieces of step s+1 are read from LDS while step s is multiplied
+            auto read_a = [&](int s, bf16x8 (&a)[3]) {
+#pragma unroll
+              for (int qq = 0; qq < 3; qq++)
+                a[qq] = __builtin_bit_cast(bf16x8, a_lds[buf][((s * 3 + qq) * 2 + h) * 32 + col]);
+            };
+            bf16x8 a_cur[3], a_nxt[3];
+            read_a(0, a_cur);
+#pragma unroll
+            for (int s = 0; s < kSteps; s++) {
+              if (s + 1 < kSteps) read_a(s + 1, a_nxt);
+              // six products per 16 k-values, smallest terms first; the two tiles alternate so that consecutive MFMAs never
+              // wait on each other's accumulator
+              constexpr int pa[6] = {2, 1, 0, 1, 0, 0}, pb[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+              for (int t6 = 0; t6 < 6; t6++)
+#pragma unroll
+                for (int n = 0; n < kNT; n++)
+                  acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[pa[t6]], b[n][s][pb[t6]], acc[n], 0, 0, 0);
+#pragma unroll
+              for (int qq = 0; qq < 3; qq++) a_cur[qq] = a_nxt[qq];
+            }
+            // ---- log-sum-exp epilogue and LDS-staged, coalesced score stores: as in score_tile
+            float mx[kNT], sum[kNT];
+#pragma unroll
+            for (int n = 0; n < kNT; n++) {
+#ifdef BF16_DIAG_NO_EPILOGUE
+              mx[n] = acc[n][0] + acc[n][15]; sum[n] = 1.0f;
+#else
+              float m = reg_max<0, 16>(acc[n]);
+              m = fmaxf(m, swap32(m, h));
+              float sv = reg_expsum_fast(acc[n], m);
+              sv += swap32(sv, h);
+              mx[n] = m; sum[n] = sv;
+#endif
+            }
+            const float v = finish(h ? mx[1] : mx[0], h ? sum[1] : sum[0]);
+            const int jj = j & 31;                         // kBlkCache is a multiple of 32: chunks keep the 32-column phase
+            stage[(32 * h + col) * 33 + jj] = v;
+#ifdef BF16_DIAG_NO_FLUSH
+            if (v == 12345.678f) {
+#else
+            if (jj == 31 || j == last) {
+#endif
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+              __builtin_amdgcn_wave_barrier();
+              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+              const int j0 = j - jj, cnt = jj + 1;
+#pragma unroll 4
+              for (int i = 0; i < 32; i++) {
+                const int r = h + 2 * i, t = t_base + r;
+                if (col < cnt && t < T) __builtin_nontemporal_store(stage[r * 33 + col], &out[(size_t)t * P + j0 + col]);
+              }
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+              __builtin_amdgcn_wave_barrier();
+            }
+          }
+          landed();
+#ifndef BF16_DIAG_NO_BARRIER
+          __syncthreads();                               // block j+1 is in place; everybody is done with block j
+#endif
+        }
+        }
+      }
+    }
+  }
+}
+
+// max over the batch of the pdfs' first possible frames → *max_ff (the persistent kernel derives its phase split from it)
 __global__ void gmm_max_first_frame_kernel(const int32_t *first_frame, const int64_t *pdf_off, int n_utt, int *out) {
   const int64_t n = pdf_off[n_utt];
   int m = 0;
@@ -609,7 +839,36 @@ MFA_API int mfa_load_gmm(mfa_ctx *c, int32_t dim, int32_t num_pdfs, const int32_
       gc[row0[p] + i] = h_gconsts[g0 + i];
     }
   }
-  void *old[] = {c->d_w, c->d_gc, c->d_row0, c->d_nblk, c->d_slot, c->d_nrows};
+  // bf16×3 split for the opt-in bf16 kernel: blocks of [step][piece][half][row] × 8 bf16 (natural k order, zero padded)
+  std::vector<uint16_t> wb;
+  const int steps = kpad / 16;
+  const bool want_bf16 = (kpad == 80 || kpad == 96);
+  if (want_bf16) {
+    wb.assign((size_t)blocks * steps * 3 * 2 * 32 * 8, 0);
+    auto to_bf16 = [](float f) -> uint16_t {   // round to nearest even, as the device's v_cvt_pk_bf16_f32
+      uint32_t u; memcpy(&u, &f, 4);
+      u += 0x7FFFu + ((u >> 16) & 1u);
+      return (uint16_t)(u >> 16);
+    };
+    auto from_bf16 = [](uint16_t b) -> float { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; };
+    for (int row = 0; row < rows; row++) {
+      for (int k = 0; k < 2 * dim; k++) {
+        const float v = w[mfa_packed_offset(row, k, kpad)];
+        const uint16_t v1 = to_bf16(v);
+        const float r1 = v - from_bf16(v1);
+        const uint16_t v2 = to_bf16(r1);
+        const float r2 = r1 - from_bf16(v2);
+        const uint16_t piece[3] = {v1, v2, to_bf16(r2)};
+        const int s_ = k >> 4, hh = (k >> 3) & 1, e = k & 7;
+        for (int qq = 0; qq < 3; qq++) {
+          const size_t unit = (size_t)(row >> 5) * steps * 3 * 2 * 32 + (size_t)((s_ * 3 + qq) * 2 + hh) * 32 + (row & 31);
+          wb[unit * 8 + e] = piece[qq];
+        }
+      }
+    }
+  }
+  void *old[] = {c->d_w, c->d_gc, c->d_row0, c->d_nblk, c->d_slot, c->d_nrows, c->d_wb};
+  c->d_wb = nullptr;
   for (void *q : old) if (q) hipFree(q);
   c->d_w = nullptr; c->d_gc = nullptr; c->d_row0 = nullptr; c->d_nblk = nullptr; c->d_slot = nullptr; c->d_nrows = nullptr;
   MFA_HIP_CHECK(c, hipMalloc((void **)&c->d_w, w.size() * 4));
@@ -618,6 +877,10 @@ MFA_API int mfa_load_gmm(mfa_ctx *c, int32_t dim, int32_t num_pdfs, const int32_
   MFA_HIP_CHECK(c, hipMalloc((void **)&c->d_nblk, nblk.size() * 4));
   MFA_HIP_CHECK(c, hipMalloc((void **)&c->d_slot, slot.size() * 4));
   MFA_HIP_CHECK(c, hipMemcpy(c->d_w, w.data(), w.size() * 4, hipMemcpyHostToDevice));
+  if (want_bf16) {
+    MFA_HIP_CHECK(c, hipMalloc((void **)&c->d_wb, wb.size() * 2));
+    MFA_HIP_CHECK(c, hipMemcpy(c->d_wb, wb.data(), wb.size() * 2, hipMemcpyHostToDevice));
+  }
   MFA_HIP_CHECK(c, hipMemcpy(c->d_gc, gc.data(), gc.size() * 4, hipMemcpyHostToDevice));
   MFA_HIP_CHECK(c, hipMemcpy(c->d_row0, row0.data(), row0.size() * 4, hipMemcpyHostToDevice));
   MFA_HIP_CHECK(c, hipMemcpy(c->d_nblk, nblk.data(), nblk.size() * 4, hipMemcpyHostToDevice));
@@ -727,9 +990,10 @@ MFA_API int mfa_gmm_score_batch(mfa_ctx *c, const float *d_feats, const int64_t 
     constexpr int kFramesPerItem = 256;
     p.n_utt = n_utt;
     p.tiles = (max_frames + kFramesPerItem - 1) / kFramesPerItem;
-    if (!c->d_gmm_queue) MFA_HIP_CHECK(c, hipMalloc((void **)&c->d_gmm_queue, 32 * sizeof(int)));
-    MFA_HIP_CHECK(c, hipMemsetAsync(c->d_gmm_queue, 0, 32 * sizeof(int), c->stream));
+    if (!c->d_gmm_queue) MFA_HIP_CHECK(c, hipMalloc((void **)&c->d_gmm_queue, 64 * sizeof(int)));
+    MFA_HIP_CHECK(c, hipMemsetAsync(c->d_gmm_queue, 0, 64 * sizeof(int), c->stream));
     p.queue = c->d_gmm_queue;
+    p.max_ff = c->d_gmm_queue + 16;
     if (d_pdf_first_frame)
       hipLaunchKernelGGL(gmm_max_first_frame_kernel, dim3(64), dim3(256), 0, c->stream, d_pdf_first_frame, d_pdf_off, n_utt,
                          c->d_gmm_queue + 16);
@@ -741,6 +1005,17 @@ MFA_API int mfa_gmm_score_batch(mfa_ctx *c, const float *d_feats, const int64_t 
     const int64_t items = (int64_t)n_utt * p.tiles;
     const int64_t wgs = std::min<int64_t>((int64_t)c->num_cus * 2, items);
     dim3 grid((unsigned)std::max<int64_t>(wgs, 1));
+    const char *bf = getenv("MFA_GMM_BF16");
+    p.wb = (const uint4 *)c->d_wb;
+    p.skip_single = 0;
+    if (!(bf && bf[0] == '0') && c->d_wb) {   // default on; MFA_GMM_BF16=0 keeps every class on the f32 kernel
+      // class 0 on the bf16×3 kernel, then the f32 kernel for whatever other slot classes the lists hold (second set of
+      // queue counters; an item with nothing left returns at once)
+      if (m8 == 10) hipLaunchKernelGGL((gmm_bf16_kernel<5>), grid, dim3(256), 0, c->stream, p);
+      else hipLaunchKernelGGL((gmm_bf16_kernel<6>), grid, dim3(256), 0, c->stream, p);
+      p.skip_single = 1;
+      p.queue = c->d_gmm_queue + 17;
+    }
     if (m8 <= 10) hipLaunchKernelGGL((gmm_kernel<10, 2, 2, 4>), grid, dim3(256), 0, c->stream, p);
     else hipLaunchKernelGGL((gmm_kernel<12, 2, 2, 4>), grid, dim3(256), 0, c->stream, p);
   }

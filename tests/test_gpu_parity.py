@@ -127,7 +127,8 @@ def test_gmm_single_gaussian_is_bit_exact(engine, fx):
         assert np.array_equal(got[u], ref), float(np.abs(got[u] - ref).max())
 
 
-def test_gmm_real_mixture_model(engine, fx):
+def test_gmm_real_mixture_model(engine, fx, monkeypatch):
+    monkeypatch.setenv("MFA_GMM_BF16", "0")   # this test pins the f32 MFMA kernel to the ulp
     am = fx.g2p_am  # 80 pdfs with 1..26 Gaussians: every slot class
     mf = [O.mfcc(s.astype(np.float32), O.default_mfcc_opts(snip_edges=1)) for s in _segments(fx)[:3]]
     feats = [O.affine(O.splice(O.cmvn_apply(O.cmvn_stats([m]), m)), fx.g2p_lda) for m in mf]
@@ -276,6 +277,35 @@ def test_end_to_end_pcm_to_alignment(engine, fx):
         a, b = frame_off[u], frame_off[u + 1]
         assert np.array_equal(res["ali"][a:b], ref["ali"])  # frame-identical boundaries
         assert abs(res["like"][u] - ref["like"]) / (b - a) < 1e-3  # per-frame log-likelihood (what MFA reports) within 1e-3
+
+
+@pytest.mark.parametrize("dim", [40, 39, 45])
+def test_gmm_bf16_split_kernel_within_float32_rounding(engine, dim, monkeypatch):
+    """Default scoring: 32-row single-block pdfs go through the bf16×3 MFMA kernel (products exact to 2^-24 per term,
+    accumulation order different from the oracle's fmaf chain); every other slot class stays on the f32 kernel.  Scores must
+    stay within float32 rounding noise of the oracle — an order of magnitude inside north_star's 1e-3 — and must not depend
+    on the tile an utterance's frames fall in."""
+    rng = np.random.default_rng(100 + dim)
+    sizes = [32] * 40 + [17, 20, 31, 32, 29] + [1, 4, 8, 16, 33, 64]
+    am = helpers.random_gmm(rng, dim, sizes)
+    feats = [rng.normal(0, 3, size=(t, dim)).astype(np.float32) for t in (1, 63, 64, 65, 257, 700)]
+    lists = [rng.permutation(am.num_pdfs)[:n].astype(np.int32) for n in (51, 30, 45, 1, 51, 40)]
+    monkeypatch.setenv("MFA_GMM_BF16", "0")
+    f32_scores, sorted_lists = _score(engine, am, feats, lists)
+    monkeypatch.delenv("MFA_GMM_BF16")          # default: bf16×3 for the single-block 32-row class
+    got, sorted_lists2 = _score(engine, am, feats, lists)
+    n_gauss = np.diff(am.pdf_offsets)
+    changed = 0
+    for u in range(len(feats)):
+        assert np.array_equal(sorted_lists[u], sorted_lists2[u])
+        ref = O.gmm_loglikes(feats[u], am.gconsts, am.means_invvars, am.inv_vars, am.pdf_offsets, sorted_lists[u])
+        scale = max(1.0, float(np.abs(ref).max()))
+        assert np.abs(got[u] - ref).max() < 4e-6 * scale, (u, float(np.abs(got[u] - ref).max()), scale)
+        single = (n_gauss[sorted_lists[u]] > 16) & (n_gauss[sorted_lists[u]] <= 32)
+        # columns of the other slot classes are produced by the f32 kernel in both runs: identical bits
+        assert np.array_equal(got[u][:, ~single], f32_scores[u][:, ~single])
+        changed += int((got[u][:, single] != f32_scores[u][:, single]).sum())
+    assert changed > 0   # the bf16 path really ran
 
 
 def test_reachability_bounded_scoring_changes_nothing(engine, fx):

@@ -10,8 +10,18 @@ import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(
 build() { MFA_HIPCC_FLAGS="$1" python -c "
 import sys; sys.path.insert(0, '.')
 from montreal_forced_aligner_amd import _lib; _lib.build_native(force=True)" 2>/dev/null; }
-run full
-for f in -DGMM_DIAG_NO_EPILOGUE -DGMM_DIAG_NO_LOADS -DGMM_DIAG_NO_FLUSH "-DGMM_DIAG_NO_EPILOGUE -DGMM_DIAG_NO_LOADS -DGMM_DIAG_NO_FLUSH"; do
-  build "$f"; run "$f"
-done
+if [ "$1" = "bf16" ]; then
+  export MFA_GMM_BF16=1
+  run full-bf16
+  for f in -DBF16_DIAG_NO_EPILOGUE -DBF16_DIAG_NO_FETCH -DBF16_DIAG_NO_FLUSH -DBF16_DIAG_NO_BARRIER \
+           "-DBF16_DIAG_NO_EPILOGUE -DBF16_DIAG_NO_FETCH -DBF16_DIAG_NO_FLUSH" \
+           "-DBF16_DIAG_NO_EPILOGUE -DBF16_DIAG_NO_FETCH -DBF16_DIAG_NO_FLUSH -DBF16_DIAG_NO_BARRIER"; do
+    build "$f"; run "$f"
+  done
+else
+  run full
+  for f in -DGMM_DIAG_NO_EPILOGUE -DGMM_DIAG_NO_LOADS -DGMM_DIAG_NO_FLUSH "-DGMM_DIAG_NO_EPILOGUE -DGMM_DIAG_NO_LOADS -DGMM_DIAG_NO_FLUSH"; do
+    build "$f"; run "$f"
+  done
+fi
 build ""
