@@ -609,15 +609,19 @@ __global__ __launch_bounds__(256, 2) void gmm_bf16_kernel(GmmParams p) {
       const int P = (int)(p.pdf_off[utt + 1] - l0);
       const int32_t *list = p.pdf_list + l0;
       const int n_all = p.class_counts[(size_t)utt * 6];
-      // pdfs the tile's LAST frame can be asked for (the four wavefronts walk the same prefix: leading sub-tiles score a few
-      // cells they could have skipped — cheap at this rate, and it keeps the workgroup in step)
-      int n_single = n_all;
+      // n_single: pdfs the tile's LAST frame can be asked for — the prefix the workgroup walks together (block copies and
+      // barriers are collective).  n_mine: the shorter prefix this wavefront's own 64 frames can be asked for; beyond it
+      // the wavefront only helps with the copies.
+      int n_single = n_all, n_mine = n_all;
       if (p.first_frame) {
         const int t_last = min(T, (tl + 1) * kFramesPerTile) - 1 + p.ff_bias;
-        n_single = 0;
+        const int t_mine = min(T, t_base + kFramesPerWave) - 1 + p.ff_bias;
+        n_single = 0; n_mine = 0;
         for (int i0 = 0; i0 < n_all; i0 += 64) {
           const int i = i0 + lane;
-          n_single += __popcll(__ballot(i < n_all && p.first_frame[l0 + i] <= t_last));
+          const int ff = i < n_all ? p.first_frame[l0 + i] : 0x7fffffff;
+          n_single += __popcll(__ballot(ff <= t_last));
+          n_mine += __popcll(__ballot(ff <= t_mine));
         }
       }
       float *out = p.out + p.ll_off[utt];
@@ -678,7 +682,7 @@ __global__ __launch_bounds__(256, 2) void gmm_bf16_kernel(GmmParams p) {
 #ifndef BF16_DIAG_NO_FETCH   // timing-only builds (tools/gmm_ablation.sh): results are wrong by construction
           fetch(block_of(j + 1), buf ^ 1);                 // block j+1 (the chunk's last trip re-fetches its last block: harmless)
 #endif
-          if (active) {
+          if (active && j < n_mine) {
             f32x16 acc[kNT];
             {
               f32x16 init;
@@ -732,7 +736,7 @@ __global__ __launch_bounds__(256, 2) void gmm_bf16_kernel(GmmParams p) {
 #ifdef BF16_DIAG_NO_FLUSH
             if (v == 12345.678f) {
 #else
-            if (jj == 31 || j == last) {
+            if (jj == 31 || j == n_mine - 1) {
 #endif
               __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
               __builtin_amdgcn_wave_barrier();
@@ -888,6 +892,9 @@ MFA_API int mfa_load_gmm(mfa_ctx *c, int32_t dim, int32_t num_pdfs, const int32_
   c->dim = dim; c->kpad = kpad; c->num_pdfs = num_pdfs; c->num_rows = rows;
   c->h_slot = slot;
   c->h_nblk = nblk;
+  c->all_single_block = true;
+  for (int p = 0; p < num_pdfs; p++)
+    if (slot[p] != 32 || nblk[p] != 1) c->all_single_block = false;
   c->gmm_ready = true;
   return 0;
 }
@@ -1016,7 +1023,9 @@ MFA_API int mfa_gmm_score_batch(mfa_ctx *c, const float *d_feats, const int64_t 
       p.skip_single = 1;
       p.queue = c->d_gmm_queue + 17;
     }
-    if (m8 <= 10) hipLaunchKernelGGL((gmm_kernel<10, 2, 2, 4>), grid, dim3(256), 0, c->stream, p);
+    if (p.skip_single && c->all_single_block) {
+      // every pdf of the model is a single 32-row block: nothing is left for the f32 kernel
+    } else if (m8 <= 10) hipLaunchKernelGGL((gmm_kernel<10, 2, 2, 4>), grid, dim3(256), 0, c->stream, p);
     else hipLaunchKernelGGL((gmm_kernel<12, 2, 2, 4>), grid, dim3(256), 0, c->stream, p);
   }
   MFA_HIP_CHECK(c, hipGetLastError());
