@@ -360,7 +360,7 @@ def main():
         except AttributeError:
             avail = os.cpu_count() or 1
         cores = max(1, min(16, avail))
-        n_s = args.cpu_sample or min(args.pool, (16 if mono else 4) * cores)
+        n_s = args.cpu_sample or min(args.pool, (16 if mono else 8) * cores)
         am = model.am
         tid2pdf = np.maximum(model.tm.id2pdf, 0)
         sample = []
