@@ -1,0 +1,264 @@
+"""Corpus-level driver: the fan-out / fan-in of ``AlignMixin.align_utterances`` (MFA/alignment/mixins.py:282-380) and the
+two-pass flow of ``CorpusAligner.align`` (MFA/alignment/base.py:510-539) over the device pipeline, ending in the interval
+and TextGrid layer (MFA/alignment/multiprocessing.py:1733-1751, MFA/textgrid.py:463-572).
+
+The reference fans utterances out to worker processes that each walk Kaldi table files one utterance at a time; here a
+rank takes the speakers ``sharding.assign_speakers`` gives it, cuts its utterances into length-bucketed ragged batches and
+pushes each batch through MFCC → CMVN → features → scores → Viterbi entirely in HBM.  Per-speaker CMVN needs every
+utterance of a speaker, so statistics are accumulated over the whole shard first (a cheap pass: MFCC + statistics
+kernels), exactly like ``calc_cmvn`` runs before alignment in the reference.
+
+A failed utterance yields ``None`` and is counted, never raised (MFA/alignment/mixins.py:308-314).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from pathlib import Path
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import ctm as _ctm
+from . import fmllr as _fmllr
+from . import graph as _graph
+from . import sharding
+from .engine import AlignmentEngine, fmllr_statistics
+from .model import DiagGmmModel, TransitionModel
+
+
+@dataclass
+class CorpusUtterance:
+    utt_id: str
+    speaker: str
+    pcm: np.ndarray                 # int16 mono at the model's sample rate
+    text: str
+    begin: float = 0.0              # position inside its sound file (for TextGrid export)
+    file_name: Optional[str] = None
+    file_duration: Optional[float] = None
+
+
+@dataclass
+class UtteranceResult:
+    utt_id: str
+    speaker: str
+    alignment: np.ndarray           # transition-ids, one per frame
+    words: np.ndarray
+    likelihood: float               # total; MFA reports likelihood / num_frames (mixins.py:351-357)
+    num_frames: int
+    ctm: Optional[_ctm.HierarchicalCtm] = None
+
+    @property
+    def per_frame_likelihood(self) -> float:
+        return self.likelihood / max(1, self.num_frames)
+
+
+@dataclass
+class AlignOptions:
+    beam: float = 10.0
+    retry_beam: float = 40.0
+    transition_scale: float = 1.0
+    acoustic_scale: float = 0.1
+    self_loop_scale: float = 0.1
+    boost_silence: float = 1.0
+    max_tokens: int = 1024
+    bp_tokens_per_frame: int = 256
+    batch_frames: int = 2_000_000   # frames per device batch (≈ 2 000 ten-second utterances)
+    fmllr_min_count: float = 500.0
+    silence_weight: float = 0.0
+
+
+class CorpusAligner:
+    """``CorpusAligner(tm, am, tree, lexicon, lda=None)`` then ``align(utterances)`` / ``export_textgrids(...)``."""
+
+    def __init__(self, tm: TransitionModel, am: DiagGmmModel, tree, lexicon, lda: Optional[np.ndarray] = None,
+                 options: Optional[AlignOptions] = None, device: int = 0, engine: Optional[AlignmentEngine] = None,
+                 mfcc_options: Optional[dict] = None, silence_phones: Sequence[int] = ()):
+        self.tm, self.am, self.tree, self.lexicon = tm, am, tree, lexicon
+        self.lda = None if lda is None else np.asarray(lda, dtype=np.float32)
+        self.opt = options or AlignOptions()
+        self.engine = engine or AlignmentEngine(device)
+        self.mfcc_options = dict(mfcc_options or {})
+        self.engine.configure_mfcc(**self.mfcc_options)
+        self.silence_phones = list(silence_phones)
+        if self.opt.boost_silence != 1.0 and self.silence_phones:
+            from .model import pdfs_of_phones
+            self.am.boost_silence(self.opt.boost_silence, pdfs_of_phones(tm, self.silence_phones))
+        self.engine.load_gmm(self.am)
+        self.compiler = _graph.TrainingGraphCompiler(tm, tree, lexicon)
+        self.scaled = tm.scaled_log_probs(self.opt.transition_scale, self.opt.self_loop_scale)
+        self.frame_shift = float(self.mfcc_options.get("frame_shift_ms", 10.0)) / 1000.0
+        self.failed: List[str] = []
+
+    # ------------------------------------------------------------------ helpers
+    def _batches(self, utts: Sequence[CorpusUtterance]) -> List[List[int]]:
+        """Length-bucketed batches (BASELINE configs[4]): sort by duration, cut at ``batch_frames``."""
+        order = np.argsort([len(u.pcm) for u in utts], kind="stable")
+        out, cur, frames = [], [], 0
+        for i in order:
+            t = self.engine.num_frames(len(utts[i].pcm))
+            if cur and frames + t > self.opt.batch_frames:
+                out.append(cur)
+                cur, frames = [], 0
+            cur.append(int(i))
+            frames += t
+        if cur:
+            out.append(cur)
+        return out
+
+    def _mfcc(self, utts: Sequence[CorpusUtterance], idx: Sequence[int]):
+        import torch
+
+        so = np.concatenate([[0], np.cumsum([len(utts[i].pcm) for i in idx])]).astype(np.int64)
+        pcm = torch.from_numpy(np.concatenate([np.ascontiguousarray(utts[i].pcm, dtype=np.int16) for i in idx])).to(self.engine.device)
+        return self.engine.mfcc(pcm, so)
+
+    def speaker_cmvn(self, utts: Sequence[CorpusUtterance]) -> Tuple[Dict[str, int], "object"]:
+        """calc_cmvn: float64 [n_spk, 2, dim+1] on the device, and the speaker → row map."""
+        import torch
+
+        spk_ids = {s: k for k, s in enumerate(dict.fromkeys(u.speaker for u in utts))}
+        total = torch.zeros((len(spk_ids), 2, self.engine.num_ceps + 1), dtype=torch.float64, device=self.engine.device)
+        for idx in self._batches(utts):
+            mfcc, fo = self._mfcc(utts, idx)
+            rows = np.array([spk_ids[utts[i].speaker] for i in idx], dtype=np.int32)
+            local, inv = np.unique(rows, return_inverse=True)
+            st = self.engine.cmvn_stats(mfcc, fo, inv.astype(np.int32), len(local))
+            total[torch.from_numpy(local.astype(np.int64)).to(self.engine.device)] += st
+        return spk_ids, total
+
+    def _pass(self, utts, spk_ids, cmvn, fmllr, want_feats=False):
+        """One alignment pass over all batches.  Returns per-utterance dicts (None where alignment failed) and, when
+        asked, what fMLLR estimation needs (features, alignments, frame offsets per batch)."""
+        import torch
+
+        eng, o = self.engine, self.opt
+        d_lda = None if self.lda is None else torch.from_numpy(self.lda).to(eng.device)
+        results: List[Optional[dict]] = [None] * len(utts)
+        kept = []
+        for idx in self._batches(utts):
+            mfcc, fo = self._mfcc(utts, idx)
+            rows = np.array([spk_ids[utts[i].speaker] for i in idx], dtype=np.int32)
+            feats = eng.features(mfcc, fo, rows, cmvn, lda=d_lda, fmllr=fmllr)
+            fsts = [_graph.add_transition_probs(self.compiler.compile_fst(utts[i].text), self.scaled) for i in idx]
+            graphs = eng.pack_graphs(fsts, self.tm)
+            ll, ll_off, ll_cols = eng.score(feats, fo, graphs.pdf_list, graphs.pdf_off_host, graphs.class_counts,
+                                            pdf_first_frame=graphs.pdf_first_frame)
+            res = eng.align(graphs, ll, ll_off, ll_cols, fo, beam=o.beam, retry_beam=o.retry_beam,
+                            acoustic_scale=o.acoustic_scale, max_tokens=o.max_tokens, bp_tokens_per_frame=o.bp_tokens_per_frame)
+            status = res["status"].cpu().numpy()
+            ali, words = res["ali"].cpu().numpy(), res["words"].cpu().numpy()
+            n_words, like = res["n_words"].cpu().numpy(), res["like"].cpu().numpy()
+            # Capacity overflows (status 3 tokens / 4 back-pointers) are not alignment failures: those utterances are decoded
+            # again on their own with the hard upper bounds (one token per graph state), which cannot overflow.
+            over = [k for k in range(len(idx)) if status[k] in (3, 4)]
+            if over:
+                sub = eng.pack_graphs([fsts[k] for k in over], self.tm)
+                fo2 = np.concatenate([[0], np.cumsum([fo[k + 1] - fo[k] for k in over])]).astype(np.int64)
+                rows_sel = torch.from_numpy(np.concatenate([np.arange(fo[k], fo[k + 1]) for k in over])).to(eng.device)
+                ll2, off2, cols2 = eng.score(feats[rows_sel].contiguous(), fo2, sub.pdf_list, sub.pdf_off_host, sub.class_counts,
+                                             pdf_first_frame=sub.pdf_first_frame)
+                r2 = eng.align(sub, ll2, off2, cols2, fo2, beam=o.beam, retry_beam=o.retry_beam, acoustic_scale=o.acoustic_scale,
+                               max_tokens=sub.max_states, bp_tokens_per_frame=sub.max_states)
+                st2, ali2, w2 = r2["status"].cpu().numpy(), r2["ali"].cpu().numpy(), r2["words"].cpu().numpy()
+                nw2, like2 = r2["n_words"].cpu().numpy(), r2["like"].cpu().numpy()
+                ali, words = ali.copy(), words.copy()
+                for j, k in enumerate(over):
+                    status[k] = st2[j]
+                    a, b = int(fo[k]), int(fo[k + 1])
+                    ali[a:b] = ali2[fo2[j]: fo2[j + 1]]
+                    n_words[k] = nw2[j]
+                    words[a: a + int(nw2[j])] = w2[fo2[j]: fo2[j] + int(nw2[j])]
+                    like[k] = like2[j]
+                if want_feats:
+                    res["ali"] = torch.from_numpy(ali).to(eng.device)
+            for k, i in enumerate(idx):
+                a, b = int(fo[k]), int(fo[k + 1])
+                if status[k] in (0, 1):
+                    results[i] = dict(ali=ali[a:b].copy(), words=words[a: a + int(n_words[k])].copy(), like=float(like[k]), frames=b - a)
+                elif status[k] > 2:
+                    raise RuntimeError(f"device decoder reported status {int(status[k])} for {utts[i].utt_id} (include/mfa_hip.h)")
+            if want_feats:
+                kept.append((idx, feats, res["ali"], fo, rows))
+        return results, kept
+
+    # ------------------------------------------------------------------ public
+    def align(self, utterances: Sequence[CorpusUtterance], speaker_adapted: bool = False, make_ctm: bool = True) -> List[Optional[UtteranceResult]]:
+        """First pass with speaker-independent features; with ``speaker_adapted`` (a SAT model, ``uses_speaker_adaptation``
+        in MFA) per-speaker fMLLR is estimated from it and a second pass is run with the transforms."""
+        import torch
+
+        utts = list(utterances)
+        self.failed = []
+        spk_ids, cmvn = self.speaker_cmvn(utts)
+        results, kept = self._pass(utts, spk_ids, cmvn, None, want_feats=speaker_adapted)
+        self.transforms: Optional[np.ndarray] = None
+        if speaker_adapted:
+            if self.lda is None:
+                raise NotImplementedError("speaker adaptation needs the LDA feature path")
+            D = self.lda.shape[0]
+            beta = np.zeros(len(spk_ids)); K = np.zeros((len(spk_ids), D, D + 1)); G = np.zeros((len(spk_ids), D, D + 1, D + 1))
+            for idx, feats, ali, fo, rows in kept:
+                ids, b, k, g = fmllr_statistics(self.engine, feats, fo, ali, self.tm, rows, self.silence_phones, self.opt.silence_weight)
+                beta[ids] += b; K[ids] += k; G[ids] += g
+            W = np.tile(np.eye(D, D + 1, dtype=np.float32), (len(spk_ids), 1, 1))
+            for s in range(len(spk_ids)):
+                W[s], _impr = _fmllr.compute_fmllr(beta[s], K[s], G[s], min_count=self.opt.fmllr_min_count)
+            self.transforms = W
+            results, _ = self._pass(utts, spk_ids, cmvn, torch.from_numpy(W).to(self.engine.device))
+        out: List[Optional[UtteranceResult]] = []
+        for u, r in zip(utts, results):
+            if r is None:
+                self.failed.append(u.utt_id)
+                out.append(None)
+                continue
+            ur = UtteranceResult(u.utt_id, u.speaker, r["ali"], r["words"], r["like"], r["frames"])
+            if make_ctm:
+                ivs = _ctm.generate_ctm(r["ali"], self.tm, self.lexicon.phone_table, self.frame_shift)
+                ur.ctm = _ctm.phones_to_pronunciations(self.lexicon, r["words"], ivs, text=u.text)
+                ur.ctm.likelihood = ur.per_frame_likelihood
+                ur.ctm.update_utterance_boundaries(u.begin, u.begin + len(u.pcm) / float(self.mfcc_options.get("sample_frequency", 16000.0)))
+            out.append(ur)
+        return out
+
+    def export_textgrids(self, utterances: Sequence[CorpusUtterance], results: Sequence[Optional[UtteranceResult]], output_directory,
+                         output_format: str = "long_textgrid", cleanup_silence: bool = True) -> List[Path]:
+        """One file per sound file, one (words, phones) tier pair per speaker (export_textgrid, MFA/textgrid.py:463-572)."""
+        out_dir = Path(output_directory)
+        out_dir.mkdir(parents=True, exist_ok=True)
+        sil = self.lexicon.silence_word
+        per_file: Dict[str, dict] = {}
+        for u, r in zip(utterances, results):
+            if r is None or r.ctm is None:
+                continue
+            name = u.file_name or u.utt_id
+            f = per_file.setdefault(name, dict(duration=0.0, speakers={}))
+            end = u.begin + len(u.pcm) / float(self.mfcc_options.get("sample_frequency", 16000.0))
+            f["duration"] = max(f["duration"], u.file_duration or end)
+            tiers = f["speakers"].setdefault(u.speaker, {"words": [], "phones": []})
+            for w in r.ctm.word_intervals:
+                if cleanup_silence and w.label == sil:
+                    continue
+                tiers["words"].append(_ctm.CtmInterval(w.begin, w.end, w.label))
+                tiers["phones"].extend(w.phones)
+        ext = {"long_textgrid": ".TextGrid", "short_textgrid": ".TextGrid", "json": ".json", "csv": ".csv"}[output_format]
+        written = []
+        for name, f in per_file.items():
+            for tiers in f["speakers"].values():
+                tiers["words"].sort(); tiers["phones"].sort()
+            path = out_dir / (name + ext)
+            _ctm.export_textgrid(f["speakers"], path, f["duration"], self.frame_shift, output_format)
+            written.append(path)
+        return written
+
+
+def align_sharded(aligner_factory, utterances: Sequence[CorpusUtterance], rank: int, world_size: int, **kw):
+    """One process per GPU: this rank aligns the speakers ``sharding.assign_speakers`` gives it (weights = audio seconds)
+    and every rank receives all results (host-side object gather; no collective on the data path)."""
+    spk_index = {s: k for k, s in enumerate(dict.fromkeys(u.speaker for u in utterances))}
+    rank_of = sharding.assign_speakers([spk_index[u.speaker] for u in utterances], world_size,
+                                       weights=[len(u.pcm) for u in utterances])
+    mine = sharding.local_indices(rank_of, rank)
+    aligner = aligner_factory()
+    local = aligner.align([utterances[i] for i in mine], **kw)
+    gathered = sharding.gather_results({int(i): r for i, r in zip(mine, local)}, world_size)
+    return [gathered.get(i) for i in range(len(utterances))]

@@ -1,0 +1,51 @@
+"""Corpus-level driver (aligner.CorpusAligner): per-speaker CMVN over a shard, length-bucketed batches, alignment, word /
+phone intervals, TextGrid files — the coarse flow of PretrainedAligner.align + export (MFA/alignment/mixins.py:282-380,
+MFA/alignment/base.py:510-539, MFA/textgrid.py:463-572) — checked against the oracle run with the same per-speaker CMVN."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+def test_corpus_aligner_on_reference_fixture(engine, fx, tmp_path):
+    from montreal_forced_aligner_amd import ctm as C
+    from montreal_forced_aligner_amd.aligner import AlignOptions, CorpusAligner, CorpusUtterance
+
+    sr = 16000
+    cuts = [("spkA", 0.0, 4.2, "this is the acoustic corpus i'm talking pretty fast here"),
+            ("spkA", 4.0, 6.5, "there's nothing going else going on"),
+            ("spkB", 23.5, 26.72, "um and that should be all thanks")]
+    utts = [CorpusUtterance(f"{s}-{k}", s, fx.pcm[int(a * sr): int(b * sr)], t, begin=a, file_name="acoustic_corpus",
+                            file_duration=len(fx.pcm) / sr) for k, (s, a, b, t) in enumerate(cuts)]
+    al = CorpusAligner(fx.mono_tm, fx.mono_am, fx.mono_tree, fx.mono_lex, options=AlignOptions(beam=100.0, retry_beam=400.0),
+                       engine=engine)
+    res = al.align(utts)
+    assert al.failed == [] and all(r is not None for r in res)
+    # oracle with the same per-speaker CMVN
+    mf = [O.mfcc(u.pcm.astype(np.float32), O.default_mfcc_opts()) for u in utts]
+    stats = {"spkA": O.cmvn_stats([mf[0], mf[1]]), "spkB": O.cmvn_stats([mf[2]])}
+    am, tm = fx.mono_am, fx.mono_tm
+    for u, r, m in zip(utts, res, mf):
+        x = O.deltas(O.cmvn_apply(stats[u.speaker], m))
+        fst = fx.mono_graph(u.text)
+        pl = np.unique(tm.id2pdf[fst.arcs["ilabel"]])
+        ref = helpers.oracle_align(tm, fst, O.gmm_loglikes(x, am.gconsts, am.means_invvars, am.inv_vars, am.pdf_offsets, pl), pl,
+                                   beam=100.0, retry_beam=400.0)
+        assert np.array_equal(r.alignment, ref["ali"]) and np.array_equal(r.words, ref["words"])
+        assert abs(r.per_frame_likelihood - ref["like"] / len(ref["ali"])) < 1e-3
+        words = [w.label for w in r.ctm.word_intervals if w.label != fx.mono_lex.silence_word]
+        assert words == u.text.split()
+        assert r.ctm.word_intervals[0].begin >= u.begin - 1e-9   # shifted to file time
+    paths = al.export_textgrids(utts, res, tmp_path / "out")
+    assert [p.name for p in paths] == ["acoustic_corpus.TextGrid"]
+    text = paths[0].read_text(encoding="utf8")
+    assert 'name = "spkA - words"' in text and 'name = "spkB - phones"' in text
+    assert text.count('text = "acoustic"') == 1 and 'xmax = %s' % round(len(fx.pcm) / sr, 6) in text
+    # a transcript the lexicon cannot spell and audio too short to hold it: counted as failed, not raised
+    bad = CorpusUtterance("spkB-x", "spkB", fx.pcm[: sr // 4], "this is the acoustic corpus i'm talking pretty fast here")
+    res2 = al.align([utts[2], bad])
+    assert res2[0] is not None and res2[1] is None and al.failed == ["spkB-x"]
+

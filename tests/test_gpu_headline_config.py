@@ -102,3 +102,43 @@ def test_ragged_batch_1_to_30_seconds(engine, setup):
     pcm, text, segs, spk = utts[3]
     ref, _ = _oracle_path(pcm, lda, fm[spk % 16], model, fsts[3], graphs.pdf_lists_host[3])
     assert ref["status"] == res["status"][3] and np.array_equal(ref["ali"], res["ali"][fo[3]: fo[4]])
+
+
+def test_corpus_aligner_two_pass_flow(engine, setup):
+    """CorpusAligner(speaker_adapted=True) = first pass → per-speaker fMLLR statistics on the device → host solve →
+    second pass with the transforms (MFA/alignment/base.py:510-539).  The transforms it used must be exactly what the
+    engine-level pieces give for the first-pass alignments, and the second pass must still spell every transcript."""
+    from montreal_forced_aligner_amd import fmllr as F
+    from montreal_forced_aligner_amd.aligner import AlignOptions, CorpusAligner, CorpusUtterance
+    from montreal_forced_aligner_amd.engine import fmllr_statistics
+
+    world, model, lda, fm, feats_of = setup
+    pt = world.lexicon.phone_table
+    sil = [pt.find("sil"), pt.find("spn")]
+    utts = []
+    for i in range(8):
+        pcm, text, segs, spk = world.utterance(9000 + i, speaker=3 + (i % 2))
+        utts.append(CorpusUtterance(f"s{spk}-{i}", f"s{spk}", pcm, text))
+    al = CorpusAligner(model.tm, model.am, model.tree, world.lexicon, lda=lda, engine=engine,
+                       options=AlignOptions(beam=10.0, retry_beam=40.0), silence_phones=sil)
+    first = al.align(utts, speaker_adapted=False, make_ctm=False)
+    second = al.align(utts, speaker_adapted=True)
+    assert all(r is not None for r in first) and all(r is not None for r in second)
+    # (the aligned log-likelihood omits fMLLR's log-determinant term, so it need not rise with the transform)
+    W = al.transforms
+    assert W.shape == (2, 40, 41) and np.isfinite(W).all()
+    assert np.abs(W[:, :, :40] - np.eye(40)).max() > 0.05          # 4 000 frames per speaker: well above min_count
+    # the same statistics and solve, by hand, from the first-pass alignments
+    spk_ids, cmvn = al.speaker_cmvn(utts)
+    so = np.concatenate([[0], np.cumsum([len(u.pcm) for u in utts])]).astype(np.int64)
+    mfcc, fo = engine.mfcc(torch.from_numpy(np.concatenate([u.pcm for u in utts])).to(engine.device), so)
+    rows = np.array([spk_ids[u.speaker] for u in utts], dtype=np.int32)
+    feats = engine.features(mfcc, fo, rows, cmvn, lda=torch.from_numpy(lda).to(engine.device))
+    ali = torch.from_numpy(np.concatenate([r.alignment for r in first]).astype(np.int32)).to(engine.device)
+    ids, beta, K, G = fmllr_statistics(engine, feats, fo, ali, model.tm, rows, sil, 0.0)
+    for k, s in enumerate(ids):
+        Wk, impr = F.compute_fmllr(beta[k], K[k], G[k], min_count=500.0)
+        assert impr > 0 and np.array_equal(Wk, W[s])
+    for u, r in zip(utts, second):
+        words = [w.label for w in r.ctm.word_intervals if w.label != world.lexicon.silence_word]
+        assert words == u.text.split()
