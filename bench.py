@@ -353,6 +353,32 @@ def main():
         "roofline": roofline,
     }
 
+    if rank == 0:
+        # Host-fed variant of the boundary (PCM arrives in pinned host memory): the copy a step would need, timed on its
+        # own stream.  Reported beside `value`, never part of it.
+        try:
+            host_pcm = torch.empty(pcm_all.shape, dtype=pcm_all.dtype, pin_memory=True)
+            host_pcm.copy_(pcm_all.cpu())
+            side = torch.cuda.Stream(dev)
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            with torch.cuda.stream(side):
+                dst = torch.empty_like(pcm_all)
+                dst.copy_(host_pcm, non_blocking=True)   # warm-up
+                ev0.record(side)
+                for _ in range(3):
+                    dst.copy_(host_pcm, non_blocking=True)
+                ev1.record(side)
+            side.synchronize()
+            h2d_ms = ev0.elapsed_time(ev1) / 3.0
+            out["host_fed"] = {"pcm_bytes_per_step": int(pcm_all.numel() * 2), "h2d_ms_per_step_pinned": round(h2d_ms, 3),
+                               "h2d_GBps": round(pcm_all.numel() * 2 / h2d_ms / 1e6, 2),
+                               "note": "copy of one step's PCM from pinned host memory on a side stream; shorter than the "
+                                       "step, so a double-buffered host-fed pipeline keeps `value`" if h2d_ms < dt / args.steps * 1e3
+                                       else "copy longer than the step: a host-fed pipeline would be PCIe-bound"}
+            del dst, host_pcm
+        except RuntimeError as e:   # pinned allocation can be refused in constrained containers
+            out["host_fed"] = {"error": str(e)[:200]}
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # a 1-GPU box grants a 16-core CPU share (of a much larger host): never size the pool by os.cpu_count() alone
         try:
