@@ -242,6 +242,15 @@ def main():
         for p_ in pipes:
             nz = int((p_.loglikes != 0).sum().item())
             log(rank, f"score cells written: {nz}/{p_.loglikes.numel()} = {nz / p_.loglikes.numel():.4f}")
+    if os.environ.get("MFA_VIT_STAMPS"):  # diagnostic (library built with -DVIT_STAMPS): decoder phase cycles → .npy
+        import ctypes as C
+        p_ = pipes[0]
+        stamps = torch.zeros(p_.n_utt * 12, dtype=torch.int64, device=dev)
+        eng.lib.mfa_debug_viterbi_stamps(eng.ctx, C.c_void_p(stamps.data_ptr()))
+        pipe.step()
+        torch.cuda.synchronize()
+        eng.lib.mfa_debug_viterbi_stamps(eng.ctx, None)
+        np.save(os.environ["MFA_VIT_STAMPS"], stamps.cpu().numpy().reshape(p_.n_utt, 12))
     if os.environ.get("MFA_GMM_TRACE"):  # diagnostic: per-wavefront timeline of one scoring launch → .npy
         import ctypes as C
         p_ = pipes[0]

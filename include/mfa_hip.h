@@ -137,6 +137,9 @@ MFA_API int mfa_gmm_score_batch(mfa_ctx *ctx, const float *d_feats, const int64_
  * it scores, four uint64 words {start, end (100 MHz wall clock), hardware id (HW_ID | XCC_ID << 32), 32-row blocks
  * walked} at d_trace[((u * tiles) * 4 + r) * 4], tiles = ceil(max_frames / 256).  NULL turns it off. */
 MFA_API int mfa_debug_gmm_trace(mfa_ctx *ctx, void *d_trace);
+/* Profiling aid, effective only in a library built with -DVIT_STAMPS (tools/viterbi_phases.py): the first-beam decoder
+ * launch leaves, per utterance, twelve uint64 shader-clock totals (one per phase of its frame loop) at d_stamps[u * 12]. */
+MFA_API int mfa_debug_viterbi_stamps(mfa_ctx *ctx, void *d_stamps);
 
 /* ---- Alignment: replaces GmmAligner.align_utterance(fst, feats) / .export_alignments
  *      (MFA/alignment/multiprocessing.py:846-853, :1311-1315; MFA/online/alignment.py:107) = Kaldi AddTransitionProbs

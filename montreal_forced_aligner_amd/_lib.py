@@ -91,6 +91,7 @@ SIGNATURES = {
     "mfa_gmm_sort_pdf_list_keyed": (C.c_int, [_vp, _vp, _vp, _i32, _vp]),
     "mfa_fst_first_frames": (C.c_int, [_i32, _vp, _vp, _i32, _vp]),
     "mfa_debug_gmm_trace": (C.c_int, [_vp, _vp]),
+    "mfa_debug_viterbi_stamps": (C.c_int, [_vp, _vp]),
     "mfa_gmm_score_batch": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mfa_align_batch": (C.c_int, [_vp, C.POINTER(GraphBatch), _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, C.POINTER(AlignOpts),
                                   _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -63,6 +63,7 @@ struct mfa_ctx {
   int32_t *d_nrows = nullptr;  // [num_pdfs] packed rows per pdf (fmllr.hip)
   int *d_gmm_queue = nullptr;  // [8] per-XCD work-item counters of the persistent scoring kernel
   int num_cus = 0;
+  void *vit_stamps = nullptr;  // debug: per-utterance phase cycle counters of the decoder (-DVIT_STAMPS builds)
   void *gmm_trace = nullptr;   // debug: per-wavefront timeline records of the scoring kernel (mfa_debug_gmm_trace)
 
   // Viterbi workspace

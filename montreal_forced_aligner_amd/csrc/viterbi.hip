@@ -58,6 +58,7 @@ struct VitParams {
   u32 *w_tokoff;                       // [total_frames + n_utt]
   u32 *w_hash;                         // [n_utt] hash size carried from pass 0 to the retry pass
   const u32 *w_arcnext;                // [total_arcs] (arc_off[next] << 7) | out-degree(next), built once per call
+  unsigned long long *stamps;          // -DVIT_STAMPS builds: per-utterance phase cycles (mfa_debug_viterbi_stamps) or NULL
   int llcap;                           // score-row cache capacity in LDS (floats); rows longer than this are read from HBM
   // outputs
   int32_t *ali; int32_t *words; int32_t *n_words; float *like; float *frame_like; int32_t *status;
@@ -133,6 +134,20 @@ __device__ __forceinline__ double cand_cost(float w, double cost, float ll, floa
 }
 
 // hand-over point between lanes of one wavefront (see the LDS carve comment in the kernel)
+// Optional per-phase cycle accounting (-DVIT_STAMPS): s_memtime deltas accumulated per phase over all frames of an
+// utterance, written to the buffer given to mfa_debug_viterbi_stamps ([n_utt][12] uint64; tools/viterbi_phases.py).
+#ifdef VIT_STAMPS
+#define STAMP(k)                                                                   \
+  do {                                                                             \
+    unsigned long long _t;                                                         \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");      \
+    stamp_acc[k] += _t - stamp_last;                                               \
+    stamp_last = _t;                                                               \
+  } while (0)
+#else
+#define STAMP(k) do {} while (0)
+#endif
+
 #define WSYNC()                                            \
   do {                                                     \
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
@@ -220,20 +235,37 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
   u64 bp_used = 0;
   WSYNC();
 
+#ifdef VIT_STAMPS
+  unsigned long long stamp_acc[12] = {0}, stamp_last;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
+#endif
   int t = 0;
   for (; t < T && status == ST_OK; t++) {
     const float *llt = ll + (size_t)t * P;
     if (row_cached) {
 #pragma unroll
       for (int r = 0; r < kPre; r++) if (lane + 64 * r < P) ll_row[lane + 64 * r] = pre[r];
-      if (t + 1 < T) {
+      WSYNC();
+    }
+    STAMP(0);   // score row staged
+    // Two address spaces, two loads, never a pointer select: a select turns into a FLAT load, whose wait
+    // (vmcnt(0) lgkmcnt(0)) drains every outstanding vector-memory operation — including the next row's prefetch.
+    auto score = [&](int col) -> float {
+      float v = ll_row[row_cached ? col : 0];   // LDS read, always (column 0 when the row is not staged)
+      if (!row_cached) v = *(const volatile float *)&llt[col];  // rows wider than the LDS cache: straight from HBM/L2
+      // (volatile: otherwise the two loads are merged back into one FLAT load of a selected address)
+      return v;
+    };
+    // Next frame's score row: requested after this frame's last dependent global load (vmcnt retires in order, so a
+    // prefetch issued before the arc gather would have to land before the gather's wait returns); it then has the
+    // claim / order / write phases and the next GetCutoff to arrive.
+    auto prefetch_next_row = [&]() {
+      if (row_cached && t + 1 < T) {
         const float *nx_row = llt + P;
 #pragma unroll
         for (int r = 0; r < kPre; r++) if (lane + 64 * r < P) pre[r] = nx_row[lane + 64 * r];
       }
-      WSYNC();
-    }
-    auto score = [&](int col) -> float { return row_cached ? ll_row[col] : llt[col]; };
+    };
     u32 *c_state = l_state0 + cur * N, *n_state = l_state0 + (cur ^ 1) * N;
     u32 *c_an = l_an0 + cur * N, *n_an = l_an0 + (cur ^ 1) * N;
     double *c_cost = l_cost0 + cur * N, *n_cost = l_cost0 + (cur ^ 1) * N;
@@ -281,6 +313,7 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
         abeam = (float)(v - best + (double)kBeamDelta);
       }
     }
+    STAMP(1);   // GetCutoff
     // PossiblyResizeHash
     { u32 want = (u32)((float)n * kHashRatio); if (want > H) H = want; }
 
@@ -325,6 +358,7 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
         WSYNC();
         if (narc > 0u) s_aux[cb] = (u32)lane + 1u;  // head of each token's candidate run
         WSYNC();
+        STAMP(2);   // candidate layout (scan, owner map)
         const u32 tok1 = incl_scan_max(s_aux[lane]);
         const bool valid = (u32)lane < ctot;
         const u32 tok = valid ? tok1 - 1u : 0u;
@@ -335,17 +369,20 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
         float w = 0.0f; int col = 0; u32 nx = 0u, nan_ = 0u;
         if (valid) { w = a_w[a]; col = a_col[a]; nx = (u32)a_next[a]; nan_ = a_an[a]; }
         const double nw = valid ? cand_cost(w, tcost, score(col), p.scale) : INFINITY;
+        STAMP(3);   // arc gather + score + cost
         const double seed = wave_min_f64((valid && tok == best_i) ? nw : INFINITY);  // the best token's candidates
         const double m_incl = incl_scan_min(nw);
         const double local = fmin(seed, shift_in_min(m_incl));
         const bool created = valid && nw < local + (double)abeam;
         const u32 cidx = (tok << kArcBits) | k;
+        STAMP(4);   // running cutoff (seed, prefix-min)
         const u32 s0 = created ? slot_of[nx] : 0u;
         if (created && s0 == kEmpty) claim(nx, nan_);
         WSYNC();  // claims are published before anybody re-reads the map
         const u32 sl = created ? lower(nx, nw, cidx) : kEmpty;
         WSYNC();  // every candidate of the frame has lowered its slot's cost
         if (sl != kEmpty && dkey(nw) == s_cost[sl]) atomicMin(&s_W[sl], cidx);
+        STAMP(5);   // claim / lower / winner
       }
     }
     if (!fast) {
@@ -447,6 +484,7 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
         }
       }
     }
+    prefetch_next_row();
     // the stash lives in HBM: make its stores visible before other lanes read them back (workgroup-scope fence waits for
     // them); frames that kept everything in registers/LDS only need the wavefront hand-over
     if (used_stash) __threadfence_block();
@@ -465,6 +503,7 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
       }
     }
     WSYNC();  // winners settled
+    STAMP(6);   // general path + stash winners (zero when the fast path ran)
     // ---------------- Kaldi list order of the new tokens
     for (u32 j0 = 0; j0 < nslots; j0 += 64) {
       u32 j = j0 + lane;
@@ -500,6 +539,7 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
       }
     }
     WSYNC();
+    STAMP(7);   // list order (bucket ranks, ordinal scan)
     // ---------------- write the new list + back-pointers, reset the tables
     if (bp_used + nslots > bp_cap) { status = ST_BP_OVERFLOW; break; }
     bool broken = false;  // defensive: an inconsistent table must never turn into an out-of-range store
@@ -532,7 +572,11 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
     cur ^= 1;
     if (!kListsInLds) __threadfence_block();  // token lists in HBM: stores must land before the next frame reads them
     WSYNC();
+    STAMP(8);   // new list, back-pointers, table reset
   }
+#ifdef VIT_STAMPS
+  if (lane == 0 && p.pass == 0 && p.stamps) for (int k = 0; k < 12; k++) p.stamps[(size_t)utt * 12 + k] = stamp_acc[k];
+#endif
   __threadfence_block();  // back-pointer records (HBM) are read back by the traceback below
   if (p.pass == 0 && lane == 0) p.w_hash[utt] = H;
   u32 *c_state = l_state0 + cur * N;
@@ -697,6 +741,11 @@ int pick_caps(const mfa_align_opts *o, int max_states, int max_arcs, int pass, i
 
 extern "C" {
 
+MFA_API int mfa_debug_viterbi_stamps(mfa_ctx *c, void *d_stamps) {
+  c->vit_stamps = d_stamps;
+  return 0;
+}
+
 MFA_API size_t mfa_align_workspace_bytes(mfa_ctx *c, int32_t n_utt, int64_t total_frames, const mfa_align_opts *o) {
   (void)c;
   int N = (o->max_tokens > 0 ? o->max_tokens : 1024) * 4, C = 8 * N;
@@ -769,6 +818,7 @@ MFA_API int mfa_align_batch(mfa_ctx *c, const mfa_graph_batch *g, const float *d
     p.w_hash = (u32 *)(base + w.hash);     // fixed location across launches
     p.w_arcnext = (const u32 *)(base + w.arcnext);
     p.llcap = kLlCap;
+    p.stamps = (unsigned long long *)c->vit_stamps;
     int32_t *d_list = (int32_t *)(base + w.list), *d_count = (int32_t *)(base + w.count);
     p.utt_list = nullptr; p.n_list = nullptr;
     p.ali = d_ali; p.words = d_words; p.n_words = d_n_words; p.like = d_like; p.frame_like = d_frame_like; p.status = d_status;
