@@ -247,6 +247,9 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
       for (int r = 0; r < kPre; r++) if (lane + 64 * r < P) ll_row[lane + 64 * r] = pre[r];
       WSYNC();
     }
+#ifdef VIT_STAMPS
+    stamp_acc[10] += (unsigned long long)n;   // tokens entering the frame
+#endif
     STAMP(0);   // score row staged
     // Two address spaces, two loads, never a pointer select: a select turns into a FLAT load, whose wait
     // (vmcnt(0) lgkmcnt(0)) drains every outstanding vector-memory operation — including the next row's prefetch.
@@ -292,6 +295,9 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
       }
       if (kle > (u32)kMinActive) { wcut = beam_cut; abeam = p.beam; }
       else {
+#ifdef VIT_STAMPS
+        stamp_acc[9] += 1;   // frames that needed the exact min_active selection
+#endif
         // sorted[min_active] (> beam_cut) = the smallest cost that has at least min_active+1 costs ≤ it
         double v = INFINITY;
         if (n <= 64) {  // costs are in registers: broadcast each with v_readlane, no LDS traffic

@@ -17,3 +17,4 @@ tot = per_frame.sum()
 for n, c in zip(names, per_frame):
     print(f"{n:42s} {c:8.0f} cycles/frame  {100 * c / tot:5.1f} %")
 print(f"{'total':42s} {tot:8.0f} cycles/frame")
+print(f"frames that ran the exact min_active selection: {a[:, 9].mean() / frames:.3f} of all; tokens per frame {a[:, 10].mean() / frames:.1f}")
