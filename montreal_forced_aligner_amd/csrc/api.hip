@@ -13,23 +13,27 @@ MFA_API mfa_ctx *mfa_create(int device_id) {
   c->device = device_id;
   if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; }
   c->stream = c->own_stream;
-  hipEventCreate(&c->t0);
-  hipEventCreate(&c->t1);
+  if (hipEventCreate(&c->t0) != hipSuccess || hipEventCreate(&c->t1) != hipSuccess) {
+    (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return nullptr;
+  }
   return c;
 }
 
 MFA_API void mfa_destroy(mfa_ctx *c) {
   if (!c) return;
-  hipSetDevice(c->device);
-  hipStreamSynchronize(c->stream);
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
   void *ptrs[] = {c->d_window, c->d_twiddle, c->d_melw, c->d_melidx, c->d_dct, c->d_lifter, c->d_w, c->d_gc,
                   c->d_row0, c->d_nblk, c->d_slot, c->d_ws, c->d_nrows, c->d_gmm_queue, c->d_wb};
-  for (void *p : ptrs) if (p) hipFree(p);
-  for (auto &p : c->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
-  for (auto e : c->event_pool) hipEventDestroy(e);
-  hipEventDestroy(c->t0);
-  hipEventDestroy(c->t1);
-  hipStreamDestroy(c->own_stream);
+  // teardown: nothing useful can be done with a failure here
+  for (void *p : ptrs) if (p) (void)hipFree(p);
+  for (auto &p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+  for (auto e : c->event_pool) (void)hipEventDestroy(e);
+  (void)hipEventDestroy(c->t0);
+  (void)hipEventDestroy(c->t1);
+  (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
 
@@ -48,7 +52,7 @@ MFA_API int mfa_synchronize(mfa_ctx *c) {
 
 MFA_API void *mfa_device_alloc(mfa_ctx *c, size_t bytes) {
   void *p = nullptr;
-  hipSetDevice(c->device);
+  if (hipSetDevice(c->device) != hipSuccess) { c->fail("hipSetDevice(%d) failed", c->device); return nullptr; }
   if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) { c->fail("hipMalloc(%zu) failed", bytes); return nullptr; }
   return p;
 }

@@ -93,16 +93,16 @@ struct KernelTimer {
   KernelTimer(mfa_ctx *ctx, int w) : c(ctx), which(w) {
     if (!c->kernel_timing) return;
     a = get(); b = get();
-    hipEventRecord(a, c->stream);
+    (void)hipEventRecord(a, c->stream);
   }
   ~KernelTimer() {
     if (!c->kernel_timing) return;
-    hipEventRecord(b, c->stream);
+    (void)hipEventRecord(b, c->stream);
     c->pending.push_back({which, a, b});
   }
   hipEvent_t get() {
     if (!c->event_pool.empty()) { hipEvent_t e = c->event_pool.back(); c->event_pool.pop_back(); return e; }
-    hipEvent_t e; hipEventCreate(&e); return e;
+    hipEvent_t e = nullptr; (void)hipEventCreate(&e); return e;
   }
 };
 

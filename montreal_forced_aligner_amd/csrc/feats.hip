@@ -280,7 +280,7 @@ MFA_API int mfa_cmvn_stats(mfa_ctx *c, const float *d_feats, const int64_t *d_fr
   if (n_utt <= 0 || n_spk <= 0) return 0;
   size_t need = (size_t)n_utt * 2 * (dim + 1) * sizeof(double);
   if (c->ws_bytes < need) {
-    if (c->d_ws) { MFA_HIP_CHECK(c, hipStreamSynchronize(c->stream)); hipFree(c->d_ws); c->d_ws = nullptr; c->ws_bytes = 0; }
+    if (c->d_ws) { MFA_HIP_CHECK(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->d_ws); c->d_ws = nullptr; c->ws_bytes = 0; }
     MFA_HIP_CHECK(c, hipMalloc(&c->d_ws, need));
     c->ws_bytes = need;
   }

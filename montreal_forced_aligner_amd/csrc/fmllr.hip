@@ -167,7 +167,7 @@ MFA_API int mfa_fmllr_acc_batch(mfa_ctx *c, const float *d_feats, const int64_t 
                                 int64_t total_frames, const int32_t *d_ali_pdf, const float *d_weight,
                                 const int32_t *d_spk_utt_off, const int32_t *d_spk_utt, int32_t n_spk, double *d_beta,
                                 double *d_K, double *d_G) {
-  hipSetDevice(c->device);
+  MFA_HIP_CHECK(c, hipSetDevice(c->device));
   if (!c->gmm_ready) return c->fail("mfa_load_gmm has not been called");
   const int D = c->dim;
   if (D > kMaxD) return c->fail("fMLLR statistics: feature dim %d > %d", D, kMaxD);
@@ -175,7 +175,7 @@ MFA_API int mfa_fmllr_acc_batch(mfa_ctx *c, const float *d_feats, const int64_t 
   if (n_utt <= 0 || n_spk <= 0 || total_frames <= 0) return 0;
   size_t need = (size_t)total_frames * (2 * D + 1) * sizeof(float);
   if (c->ws_bytes < need) {
-    if (c->d_ws) { MFA_HIP_CHECK(c, hipStreamSynchronize(c->stream)); hipFree(c->d_ws); c->d_ws = nullptr; c->ws_bytes = 0; }
+    if (c->d_ws) { MFA_HIP_CHECK(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->d_ws); c->d_ws = nullptr; c->ws_bytes = 0; }
     MFA_HIP_CHECK(c, hipMalloc(&c->d_ws, need));
     c->ws_bytes = need;
   }

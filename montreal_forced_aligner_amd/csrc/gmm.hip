@@ -650,7 +650,6 @@ __global__ __launch_bounds__(256, 2) void gmm_bf16_kernel(GmmParams p) {
             }
           }
         }
-        const int last = n_single - 1;
         // Block copy global → LDS without a register stop (global_load_lds_dwordx4: every lane's 16 bytes land at a
         // wavefront-uniform LDS base + 16·lane, which is exactly the linear unit order of a block).
         typedef __attribute__((address_space(1))) const void *gptr_t;
@@ -812,7 +811,7 @@ extern "C" {
 
 MFA_API int mfa_load_gmm(mfa_ctx *c, int32_t dim, int32_t num_pdfs, const int32_t *h_pdf_offsets, const float *h_gconsts,
                          const float *h_means_invvars, const float *h_inv_vars) {
-  hipSetDevice(c->device);
+  MFA_HIP_CHECK(c, hipSetDevice(c->device));
   if (dim <= 0 || num_pdfs <= 0) return c->fail("mfa_load_gmm: bad dim/num_pdfs %d/%d", dim, num_pdfs);
   // the MFMA kernel is instantiated for rows of exactly 80 or 96 floats; wider models use the naive kernel
   const int kpad = 2 * dim <= 80 ? 80 : (2 * dim <= 96 ? 96 : ((2 * dim + 7) / 8) * 8);
@@ -873,7 +872,7 @@ MFA_API int mfa_load_gmm(mfa_ctx *c, int32_t dim, int32_t num_pdfs, const int32_
   }
   void *old[] = {c->d_w, c->d_gc, c->d_row0, c->d_nblk, c->d_slot, c->d_nrows, c->d_wb};
   c->d_wb = nullptr;
-  for (void *q : old) if (q) hipFree(q);
+  for (void *q : old) if (q) (void)hipFree(q);
   c->d_w = nullptr; c->d_gc = nullptr; c->d_row0 = nullptr; c->d_nblk = nullptr; c->d_slot = nullptr; c->d_nrows = nullptr;
   MFA_HIP_CHECK(c, hipMalloc((void **)&c->d_w, w.size() * 4));
   MFA_HIP_CHECK(c, hipMalloc((void **)&c->d_gc, gc.size() * 4));

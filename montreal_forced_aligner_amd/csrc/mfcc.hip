@@ -234,7 +234,7 @@ float mel_scale(float f) { return 1127.0f * logf(1.0f + f / 700.0f); }
 extern "C" {
 
 MFA_API int mfa_mfcc_configure(mfa_ctx *c, const mfa_mfcc_opts *o) {
-  hipSetDevice(c->device);
+  MFA_HIP_CHECK(c, hipSetDevice(c->device));
   int win = (int)(o->sample_frequency * 0.001f * o->frame_length_ms);
   int shift = (int)(o->sample_frequency * 0.001f * o->frame_shift_ms);
   int nfft = 1;
@@ -320,7 +320,7 @@ MFA_API int mfa_mfcc_configure(mfa_ctx *c, const mfa_mfcc_opts *o) {
     lifter[i] = o->cepstral_lifter != 0.0f ? (float)(1.0 + 0.5 * o->cepstral_lifter * sin(M_PI * i / o->cepstral_lifter)) : 1.0f;
 
   auto upload = [&](void **dptr, const void *h, size_t bytes) -> int {
-    if (*dptr) { hipFree(*dptr); *dptr = nullptr; }
+    if (*dptr) { (void)hipFree(*dptr); *dptr = nullptr; }
     MFA_HIP_CHECK(c, hipMalloc(dptr, bytes));
     MFA_HIP_CHECK(c, hipMemcpy(*dptr, h, bytes, hipMemcpyHostToDevice));
     return 0;

@@ -73,21 +73,6 @@ __device__ __forceinline__ double dunkey(u64 k) {
   return __longlong_as_double((long long)b);
 }
 
-__device__ __forceinline__ double shfl_f64(double v, int src) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __shfl(lo, src); hi = __shfl(hi, src);
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double shfl_up_f64(double v, int d) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __shfl_up(lo, d); hi = __shfl_up(hi, d);
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double shfl_xor_f64(double v, int m) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __shfl_xor(lo, m); hi = __shfl_xor(hi, m);
-  return __hiloint2double(hi, lo);
-}
 // ---- wavefront primitives on the DPP crossbar (row_shr / row_bcast / wave_shr are single VALU operand modifiers on
 // gfx950; the ds_bpermute-based __shfl costs an LDS round trip per step).  Inclusive scan: Kogge-Stone inside each row
 // of 16 lanes, then row_bcast:15 / row_bcast:31 carry the row totals; lane 63 ends up holding the reduction.
@@ -122,7 +107,6 @@ __device__ __forceinline__ double incl_scan_min(double v) {
   return v;
 }
 __device__ __forceinline__ double wave_min_f64(double v) { return readlane_f64(incl_scan_min(v), 63); }
-__device__ __forceinline__ u32 wave_sum_u32(u32 v) { return (u32)__builtin_amdgcn_readlane((int)incl_scan_sum(v), 63); }
 __device__ __forceinline__ u32 wave_max_u32(u32 v) { return (u32)__builtin_amdgcn_readlane((int)incl_scan_max(v), 63); }
 // exclusive prefixes from an inclusive scan: shift the wavefront right by one lane (wave_shr:1), identity into lane 0
 __device__ __forceinline__ double shift_in_min(double incl) { return dpp_f64<0x138>((double)INFINITY, incl); }
@@ -269,7 +253,7 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
         for (int r = 0; r < kPre; r++) if (lane + 64 * r < P) pre[r] = nx_row[lane + 64 * r];
       }
     };
-    u32 *c_state = l_state0 + cur * N, *n_state = l_state0 + (cur ^ 1) * N;
+    u32 *n_state = l_state0 + (cur ^ 1) * N;
     u32 *c_an = l_an0 + cur * N, *n_an = l_an0 + (cur ^ 1) * N;
     double *c_cost = l_cost0 + cur * N, *n_cost = l_cost0 + (cur ^ 1) * N;
     // ---------------- GetCutoff: best cost (first index on ties), count
@@ -763,7 +747,7 @@ MFA_API int mfa_align_batch(mfa_ctx *c, const mfa_graph_batch *g, const float *d
                             const int32_t *d_ll_cols, const int64_t *d_frame_off, int64_t total_frames,
                             int64_t total_arcs, int32_t max_states, int32_t max_arcs, const mfa_align_opts *o, int32_t *d_ali, int32_t *d_words, int32_t *d_n_words,
                             float *d_like, float *d_frame_like, int32_t *d_status) {
-  hipSetDevice(c->device);
+  MFA_HIP_CHECK(c, hipSetDevice(c->device));
   const int n_utt = g->n_utt;
   if (n_utt <= 0) return 0;
   if (o->beam <= 0.0f || (o->retry_beam != 0.0f && o->retry_beam <= o->beam))
@@ -778,7 +762,7 @@ MFA_API int mfa_align_batch(mfa_ctx *c, const mfa_graph_batch *g, const float *d
   const int Nw = passes == 2 ? N[1] : N[0], Cw = passes == 2 ? C[1] : C[0];
   WsLayout w = ws_layout(n_utt, total_frames, Nw, Cw, bpf, total_arcs);
   if (c->ws_bytes < w.total) {
-    if (c->d_ws) { hipFree(c->d_ws); c->d_ws = nullptr; c->ws_bytes = 0; }
+    if (c->d_ws) { MFA_HIP_CHECK(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->d_ws); c->d_ws = nullptr; c->ws_bytes = 0; }
     MFA_HIP_CHECK(c, hipMalloc(&c->d_ws, w.total));
     c->ws_bytes = w.total;
   }
