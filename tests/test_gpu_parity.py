@@ -159,7 +159,7 @@ def test_gmm_random_models_all_slot_classes(engine, dim):
         assert np.abs(got[u] - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
 
 
-def _align_case(engine, tm, fx_am, fsts, lls_full, beam, retry, max_tokens=1024, scale=0.1):
+def _align_case(engine, tm, fx_am, fsts, lls_full, beam, retry, max_tokens=1024, scale=0.1, bp_tokens=512):
     """lls_full[u]: [T, num_pdfs] oracle scores for every pdf; the GPU gets the utterance's own columns."""
     engine.load_gmm(fx_am)  # pdf lists are ordered by the loaded model's slot classes
     graphs = engine.pack_graphs(fsts, tm)
@@ -169,7 +169,7 @@ def _align_case(engine, tm, fx_am, fsts, lls_full, beam, retry, max_tokens=1024,
     d_ll = _dev(engine, np.concatenate([c.reshape(-1) for c in cols]).astype(np.float32))
     ll_cols = _dev(engine, np.array([c.shape[1] for c in cols], dtype=np.int32))
     res = engine.align(graphs, d_ll, ll_off, ll_cols, frame_off, beam=beam, retry_beam=retry, acoustic_scale=scale,
-                       max_tokens=max_tokens, want_frame_likes=True)
+                       max_tokens=max_tokens, bp_tokens_per_frame=bp_tokens, want_frame_likes=True)
     res = {k: (v.cpu().numpy() if v is not None else None) for k, v in res.items()}
     for u, f in enumerate(fsts):
         ref = helpers.oracle_align(tm, f, cols[u], graphs.pdf_lists_host[u], acoustic_scale=scale, beam=beam, retry_beam=retry)
@@ -222,6 +222,56 @@ def test_viterbi_random_scores_all_paths(engine, fx):
         res = _align_case(engine, tm, fx.mono_am, fsts, lls, beam, retry)
         if trial == 3:
             assert 1 in res["status"].tolist()  # the retry launch really ran
+
+
+def _random_graph(rng, tm, n_states):
+    """Arbitrary epsilon-free graph over the model's transition-ids: nothing HMM-shaped about it — cycles, skips, dead ends,
+    out-degrees from 1 to 64, weights on a coarse grid (exact cost ties), a few final states."""
+    from montreal_forced_aligner_amd import kaldi_io as K
+
+    offs, arcs = [0], []
+    for s in range(n_states):
+        r = rng.random()
+        deg = 64 if r < 0.01 else (int(rng.integers(9, 30)) if r < 0.05 else int(rng.integers(1, 5)))
+        if s == n_states - 1 and rng.random() < 0.5:
+            deg = 0   # a dead end
+        for _ in range(deg):
+            q = rng.random()
+            dst = s if q < 0.3 else (min(n_states - 1, s + int(rng.integers(1, 4))) if q < 0.8 else int(rng.integers(0, n_states)))
+            arcs.append((int(rng.integers(1, tm.num_transition_ids + 1)), int(rng.integers(0, 50)) if rng.random() < 0.2 else 0,
+                         float(rng.integers(0, 12)) * 0.25, dst))
+        offs.append(len(arcs))
+    a = np.zeros(len(arcs), dtype=K.ARC_DTYPE)
+    for i, (il, ol, w, d) in enumerate(arcs):
+        a[i] = (il, ol, w, d)
+    final = np.full(n_states, np.inf, dtype=np.float32)
+    for s in rng.choice(n_states, size=max(1, n_states // 10), replace=False):
+        final[s] = float(rng.integers(0, 4)) * 0.5
+    return K.Fst(0, np.asarray(offs, dtype=np.int64), a, final)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_viterbi_random_graph_fuzz(engine, fx, seed):
+    """Decoder against the oracle on graphs that share nothing with a training graph's shape: exercises list-order rules
+    (cycles re-create states, many arcs into one state), exact ties, wide states (token-per-lane general path, stash),
+    token-capacity escalation (hundreds of live tokens), pruning to failure and the retry launch.  Bit-exact or it fails."""
+    tm = fx.mono_tm
+    rng = np.random.default_rng(1000 + seed)
+    fsts, lls = [], []
+    for u in range(20):
+        S = int(rng.choice([3, 8, 40, 150, 400, 1100])) if u else 1100
+        fsts.append(_random_graph(rng, tm, S))
+        T = int(rng.integers(2, 90))
+        if rng.random() < 0.3:   # quantised scores: ties everywhere
+            ll = (rng.integers(-240, -160, size=(T, tm.num_pdfs)) * 0.25).astype(np.float32)
+        else:
+            ll = rng.normal(-60.0, float(rng.choice([2.0, 10.0, 40.0])), size=(T, tm.num_pdfs)).astype(np.float32)
+        lls.append(ll)
+    beam, retry = [(1.0, 4.0), (8.0, 32.0), (50.0, 0.0)][seed]
+    # capacities at their hard upper bounds (one token per state), so the only statuses left are the decoder's own
+    res = _align_case(engine, tm, fx.mono_am, fsts, lls, beam, retry, max_tokens=2048, bp_tokens=1100)
+    assert set(res["status"].tolist()) <= {0, 1, 2}
+    assert (res["status"] != 2).any()
 
 
 def test_viterbi_ties_and_duplicate_paths(engine, fx):
