@@ -42,6 +42,9 @@ def parse_args():
     ap.add_argument("--pool", type=int, default=128, help="distinct synthetic utterances generated per rank")
     ap.add_argument("--workload", choices=["triphone", "mono"], default="triphone")
     ap.add_argument("--train-utts", type=int, default=120)
+    ap.add_argument("--gauss-per-pdf", type=int, default=32,
+                    help="triphone workload: Gaussians per pdf (BASELINE configs[2] = 32; other values exercise the other "
+                         "slot classes of the scoring kernels and are NOT the headline workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="utterances for the CPU baseline (0 = 2 per core)")
     ap.add_argument("--max-tokens", type=int, default=256)
@@ -153,7 +156,8 @@ def main():
 
     t0 = time.time()
     trainer = synth.train_monophone if mono else synth.train_triphone
-    model = trainer(world_, feature_fn, n_train=args.train_utts)
+    model = trainer(world_, feature_fn, n_train=args.train_utts) if mono or args.gauss_per_pdf == 32 else \
+        trainer(world_, feature_fn, n_train=args.train_utts, n_gauss=args.gauss_per_pdf)
     log(rank, f"synthetic {'monophone' if mono else 'triphone'} model: {model.am.num_pdfs} pdfs, {model.am.num_gauss} Gaussians, "
               f"dim {model.am.dim}, {model.tm.num_transition_ids} transition-ids ({time.time() - t0:.1f}s)")
     eng.load_gmm(model.am)
@@ -319,7 +323,7 @@ def main():
     # MFMA products (exact to 2^-24 per term), so the matrix pipe executes 6× the algorithmic flops and is priced against
     # the dense bf16 peak.  MFA_GMM_BF16=0 (or a model whose pdfs are not single 32-row blocks, like the monophone one):
     # the f32 MFMA kernel against the f32 peak.
-    bf16 = os.environ.get("MFA_GMM_BF16", "1") != "0" and not mono
+    bf16 = os.environ.get("MFA_GMM_BF16", "1") != "0" and not mono and 16 < args.gauss_per_pdf <= 32
     if bf16:
         roofline = {
             "kernel": "gmm_bf16_kernel (diagonal-GMM scoring, 3-way bf16 split on v_mfma_f32_32x32x16_bf16)", "bound": "mfma",

@@ -46,7 +46,7 @@ struct GmmParams {
   const float *feats; const int64_t *frame_off;
   const int32_t *pdf_list; const int64_t *pdf_off; const int32_t *class_counts; const int64_t *ll_off;
   unsigned long long *trace;   // debug (mfa_debug_gmm_trace): per workgroup {start, end, hw id, blocks} or NULL
-  int skip_single;             // 1: class 0 (single-block 32-row pdfs) is left to gmm_bf16_kernel
+  int skip_single;             // 1: the 32-row classes (0 and 1) are left to gmm_bf16_kernel
   int ff_bias;                 // debug (MFA_GMM_FF_BIAS): added to the tile's last frame before the reachability test
   const int32_t *first_frame;  // parallel to pdf_list (ascending inside each class) or NULL: see mfa_gmm_score_batch
   float *out;
@@ -242,8 +242,9 @@ __device__ __forceinline__ void score_tile(const GmmParams &p, int utt, int t_ba
     }
   }
   float *out = p.out + p.ll_off[utt];
-  // skip_single: the single-block pdfs are scored by gmm_bf16_kernel; only the other classes are left for this launch
-  if (p.skip_single && need[1] + need[2] + need[3] + need[4] + need[5] == 0) return;
+  // skip_single: the 32-row pdfs (single- and multi-block) are scored by gmm_bf16_kernel; only the small-slot classes are
+  // left for this launch
+  if (p.skip_single && need[2] + need[3] + need[4] + need[5] == 0) return;
 
   Tile<M8, kNT> tile;
   tile.load_b(p, f0, T, t_base, lane);
@@ -359,7 +360,7 @@ __device__ __forceinline__ void score_tile(const GmmParams &p, int utt, int t_ba
 
   // ---- 32-row pdfs with more than 32 Gaussians: several blocks, two passes (max, then the sum against that max)
   const int n32 = cc[0];
-  for (int j = max(first32, cc6[0]); j < cc6[0] + need[1]; j++) {
+  for (int j = max(first32, cc6[0]); j < cc6[0] + (p.skip_single ? 0 : need[1]); j++) {
     const int pdf = list[j];
     const int r0 = p.row0[pdf], nb = p.nblk[pdf];
     float mx[kNT], sum[kNT];
@@ -573,7 +574,9 @@ __global__ __launch_bounds__(64 * kWaves, kMinWaves) void gmm_kernel(GmmParams p
 // unit time), so the kernel is organised like a GEMM: the workgroup's four wavefronts (64 frames each, x̃ split once into
 // registers: 120 VGPRs) share every 32-row block through LDS, double-buffered — while block j is multiplied out of one
 // buffer, block j+1 travels global → registers → the other buffer; one barrier per block.
-template <int kSteps>   // 16-k steps per row: 5 for D ≤ 40, 6 for D ≤ 48
+// kMulti = false: instantiation for models without multi-block pdfs (every entry is a whole pdf: no entry flags, no merge
+// state — the headline configuration runs 5 % faster without them).
+template <int kSteps, bool kMulti>   // 16-k steps per row: 5 for D ≤ 40, 6 for D ≤ 48
 __global__ __launch_bounds__(256, 2) void gmm_bf16_kernel(GmmParams p) {
   constexpr int kNT = 2, kWaves = 4, kFramesPerWave = 64, kFramesPerTile = 256;
   constexpr int kUnits = kSteps * 3 * 2 * 32;          // 16-byte units per block
@@ -582,8 +585,13 @@ __global__ __launch_bounds__(256, 2) void gmm_bf16_kernel(GmmParams p) {
   __shared__ float stage_all[kWaves][64 * 33];
   __shared__ uint4 a_lds[2][kUnits];
   __shared__ __attribute__((aligned(16))) float gc_lds[2][32];
-  constexpr int kBlkCache = 1024;                     // pdf → 32-row block index, staged per item (two dependent global
-  __shared__ int blk_lds[kBlkCache];                  // loads per pdf must not sit in the block loop)
+  // Entry table of the item, staged in chunks (two dependent global loads per pdf must not sit in the block loop).  An
+  // entry is one 32-row block: a single-block pdf is one entry; a pdf with more than 32 Gaussians is a run of entries
+  // whose (max, sum) pairs are merged on the fly (online log-sum-exp) and emitted with its last block.
+  constexpr int kBlkCache = 1024;
+  constexpr int kFirst = 1 << 30, kLast = 1 << 31;
+  __shared__ int blk_lds[kBlkCache];                  // 32-row block index
+  __shared__ int col_lds[kBlkCache];                  // output column | kFirst | kLast
   __shared__ int s_item;
   float *stage = stage_all[wave];
   const int my_xcd = (int)(__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u);
@@ -608,24 +616,36 @@ __global__ __launch_bounds__(256, 2) void gmm_bf16_kernel(GmmParams p) {
       const int64_t l0 = p.pdf_off[utt];
       const int P = (int)(p.pdf_off[utt + 1] - l0);
       const int32_t *list = p.pdf_list + l0;
-      const int n_all = p.class_counts[(size_t)utt * 6];
-      // n_single: pdfs the tile's LAST frame can be asked for — the prefix the workgroup walks together (block copies and
-      // barriers are collective).  n_mine: the shorter prefix this wavefront's own 64 frames can be asked for; beyond it
-      // the wavefront only helps with the copies.
-      int n_single = n_all, n_mine = n_all;
+      const int cc0 = p.class_counts[(size_t)utt * 6], cc1 = kMulti ? p.class_counts[(size_t)utt * 6 + 1] : 0;
+      // n0 / n1: single-block / multi-block pdfs the tile's LAST frame can be asked for — the prefixes the workgroup walks
+      // together (block copies and barriers are collective).  n0_mine / n1_mine: the shorter prefixes this wavefront's own
+      // 64 frames can be asked for; beyond them the wavefront only helps with the copies.
+      int n0 = cc0, n1 = cc1, n0_mine = cc0, n1_mine = cc1;
       if (p.first_frame) {
         const int t_last = min(T, (tl + 1) * kFramesPerTile) - 1 + p.ff_bias;
         const int t_mine = min(T, t_base + kFramesPerWave) - 1 + p.ff_bias;
-        n_single = 0; n_mine = 0;
-        for (int i0 = 0; i0 < n_all; i0 += 64) {
+        n0 = n1 = n0_mine = n1_mine = 0;
+        for (int i0 = 0; i0 < cc0 + cc1; i0 += 64) {
           const int i = i0 + lane;
-          const int ff = i < n_all ? p.first_frame[l0 + i] : 0x7fffffff;
-          n_single += __popcll(__ballot(ff <= t_last));
-          n_mine += __popcll(__ballot(ff <= t_mine));
+          const int ff = i < cc0 + cc1 ? p.first_frame[l0 + i] : 0x7fffffff;
+          const unsigned long long all = __ballot(ff <= t_last), mine = __ballot(ff <= t_mine);
+          const unsigned long long c0m = __ballot(i < cc0);
+          n0 += __popcll(all & c0m); n1 += __popcll(all & ~c0m);
+          n0_mine += __popcll(mine & c0m); n1_mine += __popcll(mine & ~c0m);
         }
       }
+      // total entries: one per single-block pdf, nblk per multi-block pdf
+      int e_multi = 0;
+      for (int i0 = 0; i0 < n1; i0 += 64) {
+        const int i = i0 + lane;
+        int nb = i < n1 ? p.nblk[list[cc0 + i]] : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) nb += __shfl_xor(nb, o);
+        e_multi += nb;
+      }
+      const int n_entries = n0 + e_multi;
       float *out = p.out + p.ll_off[utt];
-      if (n_single > 0) {
+      if (n_entries > 0) {
         // ---- x̃ = [x, x²] of this wavefront's 64 frames, split into bf16 triples: b[tile][step][piece], lane (frame, half)
         bf16x8 b[kNT][kSteps][3];
 #pragma unroll
@@ -650,38 +670,75 @@ __global__ __launch_bounds__(256, 2) void gmm_bf16_kernel(GmmParams p) {
             }
           }
         }
-        // Block copy global → LDS without a register stop (global_load_lds_dwordx4: every lane's 16 bytes land at a
-        // wavefront-uniform LDS base + 16·lane, which is exactly the linear unit order of a block).
-        typedef __attribute__((address_space(1))) const void *gptr_t;
-        typedef __attribute__((address_space(3))) void *lptr_t;
-        const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-        auto fetch = [&](int blk, int buf) {
+        // Block copy global → registers (requested before block j is multiplied) → LDS (written after it).  The LDS-DMA form
+        // (global_load_lds) measured the same when it overlapped and much worse when it did not: the compiler cannot tell the
+        // two LDS buffers apart and drains vmcnt before every LDS read while a DMA write is in flight.
+        uint4 mv[kLoads];
+        float4 gmv = make_float4(0.f, 0.f, 0.f, 0.f);
+        auto fetch = [&](int blk) {
           const uint4 *src = p.wb + (size_t)blk * kUnits;
 #pragma unroll
           for (int i = 0; i < kLoads; i++) {
-            const int u0 = 64 * wave_u + 256 * i;        // first unit this wavefront moves in round i (uniform)
-            if (u0 < kUnits)
-              __builtin_amdgcn_global_load_lds((gptr_t)(src + u0 + lane), (lptr_t)&a_lds[buf][u0], 16, 0, 0);
+            const int u = threadIdx.x + 256 * i;
+            mv[i] = u < kUnits ? src[u] : make_uint4(0, 0, 0, 0);
           }
-          if (wave_u == 0 && lane < 8)
-            __builtin_amdgcn_global_load_lds((gptr_t)(p.gc + (size_t)blk * 32 + 4 * lane), (lptr_t)&gc_lds[buf][0], 16, 0, 0);
+          if (threadIdx.x < 8) gmv = *reinterpret_cast<const float4 *>(p.gc + (size_t)blk * 32 + 4 * threadIdx.x);
         };
-        auto landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
-        for (int c0 = 0; c0 < n_single; c0 += kBlkCache) {
-        const int c1 = min(n_single, c0 + kBlkCache);
+        auto deposit = [&](int buf) {
+#pragma unroll
+          for (int i = 0; i < kLoads; i++) {
+            const int u = threadIdx.x + 256 * i;
+            if (u < kUnits) a_lds[buf][u] = mv[i];
+          }
+          if (threadIdx.x < 8) *reinterpret_cast<float4 *>(&gc_lds[buf][4 * threadIdx.x]) = gmv;
+        };
+        int multi_pdf = 0, multi_blk = 0;                  // thread 0's cursor into the multi-block pdfs
+        int staged = 0, stage_col0 = 0;                    // columns waiting in the staging tile: stage_col0 .. +staged-1
+        float mx_run[kNT], sum_run[kNT];
+#pragma unroll
+        for (int n = 0; n < kNT; n++) { mx_run[n] = -INFINITY; sum_run[n] = 0.0f; }
+        auto flush = [&]() {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 4
+          for (int i = 0; i < 32; i++) {
+            const int r = h + 2 * i, t = t_base + r;
+            if (col < staged && t < T) __builtin_nontemporal_store(stage[r * 33 + col], &out[(size_t)t * P + stage_col0 + col]);
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          staged = 0;
+        };
+        for (int c0 = 0; c0 < n_entries; c0 += kBlkCache) {
+        const int c1 = min(n_entries, c0 + kBlkCache);
         __syncthreads();                                   // previous chunk's table is no longer read
-        for (int i = c0 + threadIdx.x; i < c1; i += 256) blk_lds[i - c0] = p.row0[list[i]] >> 5;
+        for (int i = c0 + threadIdx.x; i < min(c1, n0); i += 256) {
+          blk_lds[i - c0] = p.row0[list[i]] >> 5;
+          if (kMulti) col_lds[i - c0] = i | kFirst | kLast;
+        }
+        if (kMulti && threadIdx.x == 0) {
+          for (int e = max(c0, n0); e < c1; e++) {
+            const int pdf = list[cc0 + multi_pdf], nb = p.nblk[pdf];
+            blk_lds[e - c0] = (p.row0[pdf] >> 5) + multi_blk;
+            col_lds[e - c0] = (cc0 + multi_pdf) | (multi_blk == 0 ? kFirst : 0) | (multi_blk == nb - 1 ? kLast : 0);
+            if (++multi_blk == nb) { multi_blk = 0; multi_pdf++; }
+          }
+        }
         __syncthreads();
         auto block_of = [&](int jj) { return blk_lds[min(jj, c1 - 1) - c0]; };
-        fetch(block_of(c0), 0);
-        landed();
+        fetch(block_of(c0));
+        deposit(0);
         __syncthreads();
         for (int j = c0; j < c1; j++) {
           const int buf = (j - c0) & 1;
 #ifndef BF16_DIAG_NO_FETCH   // timing-only builds (tools/gmm_ablation.sh): results are wrong by construction
-          fetch(block_of(j + 1), buf ^ 1);                 // block j+1 (the chunk's last trip re-fetches its last block: harmless)
+          fetch(block_of(j + 1));                          // block j+1 (the chunk's last trip re-fetches its last block: harmless)
 #endif
-          if (active && j < n_mine) {
+          const int ecol = kMulti ? col_lds[j - c0] : (j | kFirst | kLast);
+          const int out_col = ecol & ~(kFirst | kLast);
+          const bool mine = out_col < cc0 ? out_col < n0_mine : out_col - cc0 < n1_mine;
+          if (active && mine) {
             f32x16 acc[kNT];
             {
               f32x16 init;
@@ -729,33 +786,41 @@ __global__ __launch_bounds__(256, 2) void gmm_bf16_kernel(GmmParams p) {
               mx[n] = m; sum[n] = sv;
 #endif
             }
-            const float v = finish(h ? mx[1] : mx[0], h ? sum[1] : sum[0]);
-            const int jj = j & 31;                         // kBlkCache is a multiple of 32: chunks keep the 32-column phase
-            stage[(32 * h + col) * 33 + jj] = v;
-#ifdef BF16_DIAG_NO_FLUSH
-            if (v == 12345.678f) {
-#else
-            if (jj == 31 || j == n_mine - 1) {
-#endif
-              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-              __builtin_amdgcn_wave_barrier();
-              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-              const int j0 = j - jj, cnt = jj + 1;
-#pragma unroll 4
-              for (int i = 0; i < 32; i++) {
-                const int r = h + 2 * i, t = t_base + r;
-                if (col < cnt && t < T) __builtin_nontemporal_store(stage[r * 33 + col], &out[(size_t)t * P + j0 + col]);
+            if (kMulti && !(ecol & kFirst)) {
+              // online log-sum-exp: fold this block's (max, sum) into the pdf's running pair
+#pragma unroll
+              for (int n = 0; n < kNT; n++) {
+                const float M = fmaxf(mx_run[n], mx[n]);
+                sum[n] = sum_run[n] * __builtin_amdgcn_exp2f((mx_run[n] - M) * 1.44269504088896341f) +
+                         sum[n] * __builtin_amdgcn_exp2f((mx[n] - M) * 1.44269504088896341f);
+                mx[n] = M;
               }
-              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-              __builtin_amdgcn_wave_barrier();
+            }
+            if (kMulti) {
+#pragma unroll
+              for (int n = 0; n < kNT; n++) { mx_run[n] = mx[n]; sum_run[n] = sum[n]; }
+            }
+#ifdef BF16_DIAG_NO_FLUSH
+            if (mx[0] == 12345.678f) {
+#else
+            if (ecol & kLast) {
+#endif
+              const float v = finish(h ? mx[1] : mx[0], h ? sum[1] : sum[0]);
+              if (staged > 0 && out_col != stage_col0 + staged) flush();   // a jump in the column sequence (class change)
+              if (staged == 0) stage_col0 = out_col;
+              stage[(32 * h + col) * 33 + staged] = v;
+              if (++staged == 32) flush();
             }
           }
-          landed();
+#ifndef BF16_DIAG_NO_FETCH
+          deposit(buf ^ 1);
+#endif
 #ifndef BF16_DIAG_NO_BARRIER
           __syncthreads();                               // block j+1 is in place; everybody is done with block j
 #endif
         }
         }
+        if (staged > 0) flush();
       }
     }
   }
@@ -891,9 +956,12 @@ MFA_API int mfa_load_gmm(mfa_ctx *c, int32_t dim, int32_t num_pdfs, const int32_
   c->dim = dim; c->kpad = kpad; c->num_pdfs = num_pdfs; c->num_rows = rows;
   c->h_slot = slot;
   c->h_nblk = nblk;
-  c->all_single_block = true;
-  for (int p = 0; p < num_pdfs; p++)
-    if (slot[p] != 32 || nblk[p] != 1) c->all_single_block = false;
+  c->all_single_block = true;   // (name kept: "all pdfs are 32-row pdfs", single- or multi-block)
+  c->has_multi_block = false;
+  for (int p = 0; p < num_pdfs; p++) {
+    if (slot[p] != 32) c->all_single_block = false;
+    if (nblk[p] > 1) c->has_multi_block = true;
+  }
   c->gmm_ready = true;
   return 0;
 }
@@ -1017,8 +1085,10 @@ MFA_API int mfa_gmm_score_batch(mfa_ctx *c, const float *d_feats, const int64_t 
     if (!(bf && bf[0] == '0') && c->d_wb) {   // default on; MFA_GMM_BF16=0 keeps every class on the f32 kernel
       // class 0 on the bf16×3 kernel, then the f32 kernel for whatever other slot classes the lists hold (second set of
       // queue counters; an item with nothing left returns at once)
-      if (m8 == 10) hipLaunchKernelGGL((gmm_bf16_kernel<5>), grid, dim3(256), 0, c->stream, p);
-      else hipLaunchKernelGGL((gmm_bf16_kernel<6>), grid, dim3(256), 0, c->stream, p);
+      if (m8 == 10 && c->has_multi_block) hipLaunchKernelGGL((gmm_bf16_kernel<5, true>), grid, dim3(256), 0, c->stream, p);
+      else if (m8 == 10) hipLaunchKernelGGL((gmm_bf16_kernel<5, false>), grid, dim3(256), 0, c->stream, p);
+      else if (c->has_multi_block) hipLaunchKernelGGL((gmm_bf16_kernel<6, true>), grid, dim3(256), 0, c->stream, p);
+      else hipLaunchKernelGGL((gmm_bf16_kernel<6, false>), grid, dim3(256), 0, c->stream, p);
       p.skip_single = 1;
       p.queue = c->d_gmm_queue + 17;
     }

@@ -331,15 +331,16 @@ def test_end_to_end_pcm_to_alignment(engine, fx):
 
 @pytest.mark.parametrize("dim", [40, 39, 45])
 def test_gmm_bf16_split_kernel_within_float32_rounding(engine, dim, monkeypatch):
-    """Default scoring: 32-row single-block pdfs go through the bf16×3 MFMA kernel (products exact to 2^-24 per term,
-    accumulation order different from the oracle's fmaf chain); every other slot class stays on the f32 kernel.  Scores must
+    """Default scoring: 32-row pdfs (17+ Gaussians; more than 32 = several blocks merged by an online log-sum-exp) go
+    through the bf16×3 MFMA kernel (products exact to 2^-24 per term, accumulation order different from the oracle's fmaf
+    chain); the small-slot classes stay on the f32 kernel.  Scores must
     stay within float32 rounding noise of the oracle — an order of magnitude inside north_star's 1e-3 — and must not depend
     on the tile an utterance's frames fall in."""
     rng = np.random.default_rng(100 + dim)
-    sizes = [32] * 40 + [17, 20, 31, 32, 29] + [1, 4, 8, 16, 33, 64]
+    sizes = [32] * 40 + [17, 20, 31, 32, 29] + [1, 4, 8, 16, 33, 64, 70, 100, 128]
     am = helpers.random_gmm(rng, dim, sizes)
     feats = [rng.normal(0, 3, size=(t, dim)).astype(np.float32) for t in (1, 63, 64, 65, 257, 700)]
-    lists = [rng.permutation(am.num_pdfs)[:n].astype(np.int32) for n in (51, 30, 45, 1, 51, 40)]
+    lists = [rng.permutation(am.num_pdfs)[:n].astype(np.int32) for n in (54, 30, 45, 1, 54, 40)]
     monkeypatch.setenv("MFA_GMM_BF16", "0")
     f32_scores, sorted_lists = _score(engine, am, feats, lists)
     monkeypatch.delenv("MFA_GMM_BF16")          # default: bf16×3 for the single-block 32-row class
@@ -351,8 +352,8 @@ def test_gmm_bf16_split_kernel_within_float32_rounding(engine, dim, monkeypatch)
         ref = O.gmm_loglikes(feats[u], am.gconsts, am.means_invvars, am.inv_vars, am.pdf_offsets, sorted_lists[u])
         scale = max(1.0, float(np.abs(ref).max()))
         assert np.abs(got[u] - ref).max() < 4e-6 * scale, (u, float(np.abs(got[u] - ref).max()), scale)
-        single = (n_gauss[sorted_lists[u]] > 16) & (n_gauss[sorted_lists[u]] <= 32)
-        # columns of the other slot classes are produced by the f32 kernel in both runs: identical bits
+        single = n_gauss[sorted_lists[u]] > 16   # 32-row pdfs, single- or multi-block: the bf16 kernel's classes
+        # columns of the small-slot classes are produced by the f32 kernel in both runs: identical bits
         assert np.array_equal(got[u][:, ~single], f32_scores[u][:, ~single])
         changed += int((got[u][:, single] != f32_scores[u][:, single]).sum())
     assert changed > 0   # the bf16 path really ran
