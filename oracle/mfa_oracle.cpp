@@ -10,8 +10,10 @@
 // PARITY STATUS: "parity unpinned" — the reference repo holds no golden vectors at
 // the kalpy boundary and kalpy/Kaldi cannot be imported or built in this
 // container.  This file is pinned only by (i) an independent
-// numpy restatement (oracle/np_oracle.py) and (ii) the structural fixtures the
-// reference ships (model dims, topology, TextGrids).
+// numpy restatement (oracle/np_oracle.py), (ii) the structural fixtures the
+// reference ships (model dims, topology, TextGrids) and (iii) its own output on
+// those fixtures, frozen as tests/golden/oracle_vectors.npz (generator:
+// tests/golden/make_golden.py) so that it cannot drift unnoticed.
 //
 // Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
 // the library built from this file.  The product path never does.
