@@ -313,7 +313,11 @@ def main():
     if not mono and B == 2048 and n_streams == 1 and args.reachability and os.path.exists(prof):
         try:
             with open(prof) as fh:
-                d_ = json.load(fh)["kernels"]["gmm_bf16_kernel" if os.environ.get("MFA_GMM_BF16", "1") != "0" else "gmm_kernel"]["derived"]
+                ks_ = json.load(fh)["kernels"]
+                if os.environ.get("MFA_GMM_BF16", "1") == "0":
+                    d_ = ks_["gmm_kernel"]["derived"]
+                else:
+                    d_ = (ks_.get("gmm_bf16_single_kernel") or ks_["gmm_bf16_kernel"])["derived"]
             traffic = float(d_["fetch_bytes_per_dispatch_raw"] + d_["write_bytes_per_dispatch"])
             traffic_src = ("profiles/r01_profile_summary_triphone_b2048.json: (FETCH_SIZE + WRITE_SIZE) KiB x 1024 per "
                            "launch, FETCH_SIZE uncorrected (gfx950 may tally 128-B reads at 64 B: up to 2x more)")
@@ -326,7 +330,7 @@ def main():
     bf16 = os.environ.get("MFA_GMM_BF16", "1") != "0" and not mono and 16 < args.gauss_per_pdf <= 32
     if bf16:
         roofline = {
-            "kernel": "gmm_bf16_kernel (diagonal-GMM scoring, 3-way bf16 split on v_mfma_f32_32x32x16_bf16)", "bound": "mfma",
+            "kernel": "gmm_bf16_single_kernel (diagonal-GMM scoring, 3-way bf16 split on v_mfma_f32_32x32x16_bf16)", "bound": "mfma",
             "achieved": round(6.0 * achieved, 3), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(6.0 * achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
             "algorithmic_flops_per_launch": flops_per_launch, "mfma_flops_per_algorithmic_flop": 6,

@@ -574,10 +574,10 @@ __global__ __launch_bounds__(64 * kWaves, kMinWaves) void gmm_kernel(GmmParams p
 // unit time), so the kernel is organised like a GEMM: the workgroup's four wavefronts (64 frames each, x̃ split once into
 // registers: 120 VGPRs) share every 32-row block through LDS, double-buffered — while block j is multiplied out of one
 // buffer, block j+1 travels global → registers → the other buffer; one barrier per block.
-// kMulti = false: instantiation for models without multi-block pdfs (every entry is a whole pdf: no entry flags, no merge
-// state — the headline configuration runs 5 % faster without them).
-template <int kSteps, bool kMulti>   // 16-k steps per row: 5 for D ≤ 40, 6 for D ≤ 48
+// General form (models that contain multi-block pdfs); gmm_bf16_single_kernel below is the lean form for models that do not.
+template <int kSteps>   // 16-k steps per row: 5 for D ≤ 40, 6 for D ≤ 48
 __global__ __launch_bounds__(256, 2) void gmm_bf16_kernel(GmmParams p) {
+  constexpr bool kMulti = true;
   constexpr int kNT = 2, kWaves = 4, kFramesPerWave = 64, kFramesPerTile = 256;
   constexpr int kUnits = kSteps * 3 * 2 * 32;          // 16-byte units per block
   constexpr int kLoads = (kUnits + 255) / 256;         // units each thread moves per block
@@ -821,6 +821,198 @@ __global__ __launch_bounds__(256, 2) void gmm_bf16_kernel(GmmParams p) {
         }
         }
         if (staged > 0) flush();
+      }
+    }
+  }
+}
+
+// Lean instantiation for models WITHOUT multi-block pdfs (the headline configuration): every entry is a whole pdf, so there
+// is no entry table beyond the block indices, no merge state, fixed 32-column staging phases, and the block copies go
+// global → LDS directly (global_load_lds_dwordx4; here the compiler lets them overlap).  3 % faster than the general kernel
+// on configs[2]; same arithmetic, same results.
+template <int kSteps>   // 16-k steps per row: 5 for D ≤ 40, 6 for D ≤ 48
+__global__ __launch_bounds__(256, 2) void gmm_bf16_single_kernel(GmmParams p) {
+  constexpr int kNT = 2, kWaves = 4, kFramesPerWave = 64, kFramesPerTile = 256;
+  constexpr int kUnits = kSteps * 3 * 2 * 32;          // 16-byte units per block
+  constexpr int kLoads = (kUnits + 255) / 256;         // units each thread moves per block
+  const int lane0 = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ float stage_all[kWaves][64 * 33];
+  __shared__ uint4 a_lds[2][kUnits];
+  __shared__ __attribute__((aligned(16))) float gc_lds[2][32];
+  constexpr int kBlkCache = 1024;                     // pdf → 32-row block index, staged per item (two dependent global
+  __shared__ int blk_lds[kBlkCache];                  // loads per pdf must not sit in the block loop)
+  __shared__ int s_item;
+  float *stage = stage_all[wave];
+  const int my_xcd = (int)(__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u);
+  for (int hop = 0; hop < 8; hop++) {
+    const int q = (my_xcd + hop) & 7;
+    const int n_items = ((p.n_utt - q + 7) >> 3) * p.tiles;
+    for (;;) {
+      __syncthreads();
+      if (threadIdx.x == 0) s_item = atomicAdd(&p.queue[q], 1);
+      __syncthreads();
+      const int item = s_item;
+      if (item >= n_items) break;
+      int lane = lane0;                                // opaque per item: keeps lane-dependent addresses out of long-lived registers
+      asm volatile("" : "+v"(lane));
+      const int col = lane & 31, h = lane >> 5;
+      const int utt = (item / p.tiles) * 8 + q, tl = p.tiles - 1 - item % p.tiles;
+      const int64_t f0 = p.frame_off[utt];
+      const int T = (int)(p.frame_off[utt + 1] - f0);
+      if (tl * kFramesPerTile >= T) continue;          // uniform over the workgroup
+      const int t_base = (tl * kWaves + wave) * kFramesPerWave;
+      const bool active = t_base < T;                  // a wavefront past the end still helps move blocks and joins barriers
+      const int64_t l0 = p.pdf_off[utt];
+      const int P = (int)(p.pdf_off[utt + 1] - l0);
+      const int32_t *list = p.pdf_list + l0;
+      const int n_all = p.class_counts[(size_t)utt * 6];
+      // n_single: pdfs the tile's LAST frame can be asked for — the prefix the workgroup walks together (block copies and
+      // barriers are collective).  n_mine: the shorter prefix this wavefront's own 64 frames can be asked for; beyond it
+      // the wavefront only helps with the copies.
+      int n_single = n_all, n_mine = n_all;
+      if (p.first_frame) {
+        const int t_last = min(T, (tl + 1) * kFramesPerTile) - 1 + p.ff_bias;
+        const int t_mine = min(T, t_base + kFramesPerWave) - 1 + p.ff_bias;
+        n_single = 0; n_mine = 0;
+        for (int i0 = 0; i0 < n_all; i0 += 64) {
+          const int i = i0 + lane;
+          const int ff = i < n_all ? p.first_frame[l0 + i] : 0x7fffffff;
+          n_single += __popcll(__ballot(ff <= t_last));
+          n_mine += __popcll(__ballot(ff <= t_mine));
+        }
+      }
+      float *out = p.out + p.ll_off[utt];
+      if (n_single > 0) {
+        // ---- x̃ = [x, x²] of this wavefront's 64 frames, split into bf16 triples: b[tile][step][piece], lane (frame, half)
+        bf16x8 b[kNT][kSteps][3];
+#pragma unroll
+        for (int n = 0; n < kNT; n++) {
+          int t = t_base + 32 * n + col;
+          t = t < T ? t : T - 1;
+          t = t < 0 ? 0 : t;
+          const float *x = p.feats + (f0 + t) * p.dim;
+#pragma unroll
+          for (int s = 0; s < kSteps; s++) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+              const int k = 16 * s + 8 * h + e;
+              const int idx = k < p.dim ? k : (k < 2 * p.dim ? k - p.dim : 0);
+              const float xv = x[idx];
+              const float v = k < p.dim ? xv : (k < 2 * p.dim ? xv * xv : 0.0f);
+              const __bf16 v1 = (__bf16)v;
+              const float r1 = v - (float)v1;
+              const __bf16 v2 = (__bf16)r1;
+              const float r2 = r1 - (float)v2;
+              b[n][s][0][e] = v1; b[n][s][1][e] = v2; b[n][s][2][e] = (__bf16)r2;
+            }
+          }
+        }
+        // Block copy global → LDS without a register stop (global_load_lds_dwordx4: every lane's 16 bytes land at a
+        // wavefront-uniform LDS base + 16·lane, which is exactly the linear unit order of a block).
+        typedef __attribute__((address_space(1))) const void *gptr_t;
+        typedef __attribute__((address_space(3))) void *lptr_t;
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+        auto fetch = [&](int blk, int buf) {
+          const uint4 *src = p.wb + (size_t)blk * kUnits;
+#pragma unroll
+          for (int i = 0; i < kLoads; i++) {
+            const int u0 = 64 * wave_u + 256 * i;        // first unit this wavefront moves in round i (uniform)
+            if (u0 < kUnits)
+              __builtin_amdgcn_global_load_lds((gptr_t)(src + u0 + lane), (lptr_t)&a_lds[buf][u0], 16, 0, 0);
+          }
+          if (wave_u == 0 && lane < 8)
+            __builtin_amdgcn_global_load_lds((gptr_t)(p.gc + (size_t)blk * 32 + 4 * lane), (lptr_t)&gc_lds[buf][0], 16, 0, 0);
+        };
+        auto landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+        for (int c0 = 0; c0 < n_single; c0 += kBlkCache) {
+        const int c1 = min(n_single, c0 + kBlkCache);
+        __syncthreads();                                   // previous chunk's table is no longer read
+        for (int i = c0 + threadIdx.x; i < c1; i += 256) blk_lds[i - c0] = p.row0[list[i]] >> 5;
+        __syncthreads();
+        auto block_of = [&](int jj) { return blk_lds[min(jj, c1 - 1) - c0]; };
+        fetch(block_of(c0), 0);
+        landed();
+        __syncthreads();
+        for (int j = c0; j < c1; j++) {
+          const int buf = (j - c0) & 1;
+#ifndef BF16_DIAG_NO_FETCH   // timing-only builds (tools/gmm_ablation.sh): results are wrong by construction
+          fetch(block_of(j + 1), buf ^ 1);                 // block j+1 (the chunk's last trip re-fetches its last block: harmless)
+#endif
+          if (active && j < n_mine) {
+            f32x16 acc[kNT];
+            {
+              f32x16 init;
+#pragma unroll
+              for (int qq = 0; qq < 4; qq++) {
+                const float4 gq = *reinterpret_cast<const float4 *>(&gc_lds[buf][8 * qq + 4 * h]);
+                init[4 * qq] = gq.x; init[4 * qq + 1] = gq.y; init[4 * qq + 2] = gq.z; init[4 * qq + 3] = gq.w;
+              }
+#pragma unroll
+              for (int n = 0; n < kNT; n++) acc[n] = init;
+            }
+            // operand pieces of step s+1 are read from LDS while step s is multiplied
+            auto read_a = [&](int s, bf16x8 (&a)[3]) {
+#pragma unroll
+              for (int qq = 0; qq < 3; qq++)
+                a[qq] = __builtin_bit_cast(bf16x8, a_lds[buf][((s * 3 + qq) * 2 + h) * 32 + col]);
+            };
+            bf16x8 a_cur[3], a_nxt[3];
+            read_a(0, a_cur);
+#pragma unroll
+            for (int s = 0; s < kSteps; s++) {
+              if (s + 1 < kSteps) read_a(s + 1, a_nxt);
+              // six products per 16 k-values, smallest terms first; the two tiles alternate so that consecutive MFMAs never
+              // wait on each other's accumulator
+              constexpr int pa[6] = {2, 1, 0, 1, 0, 0}, pb[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+              for (int t6 = 0; t6 < 6; t6++)
+#pragma unroll
+                for (int n = 0; n < kNT; n++)
+                  acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[pa[t6]], b[n][s][pb[t6]], acc[n], 0, 0, 0);
+#pragma unroll
+              for (int qq = 0; qq < 3; qq++) a_cur[qq] = a_nxt[qq];
+            }
+            // ---- log-sum-exp epilogue and LDS-staged, coalesced score stores: as in score_tile
+            float mx[kNT], sum[kNT];
+#pragma unroll
+            for (int n = 0; n < kNT; n++) {
+#ifdef BF16_DIAG_NO_EPILOGUE
+              mx[n] = acc[n][0] + acc[n][15]; sum[n] = 1.0f;
+#else
+              float m = reg_max<0, 16>(acc[n]);
+              m = fmaxf(m, swap32(m, h));
+              float sv = reg_expsum_fast(acc[n], m);
+              sv += swap32(sv, h);
+              mx[n] = m; sum[n] = sv;
+#endif
+            }
+            const float v = finish(h ? mx[1] : mx[0], h ? sum[1] : sum[0]);
+            const int jj = j & 31;                         // kBlkCache is a multiple of 32: chunks keep the 32-column phase
+            stage[(32 * h + col) * 33 + jj] = v;
+#ifdef BF16_DIAG_NO_FLUSH
+            if (v == 12345.678f) {
+#else
+            if (jj == 31 || j == n_mine - 1) {
+#endif
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+              __builtin_amdgcn_wave_barrier();
+              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+              const int j0 = j - jj, cnt = jj + 1;
+#pragma unroll 4
+              for (int i = 0; i < 32; i++) {
+                const int r = h + 2 * i, t = t_base + r;
+                if (col < cnt && t < T) __builtin_nontemporal_store(stage[r * 33 + col], &out[(size_t)t * P + j0 + col]);
+              }
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+              __builtin_amdgcn_wave_barrier();
+            }
+          }
+          landed();
+#ifndef BF16_DIAG_NO_BARRIER
+          __syncthreads();                               // block j+1 is in place; everybody is done with block j
+#endif
+        }
+        }
       }
     }
   }
@@ -1085,10 +1277,10 @@ MFA_API int mfa_gmm_score_batch(mfa_ctx *c, const float *d_feats, const int64_t 
     if (!(bf && bf[0] == '0') && c->d_wb) {   // default on; MFA_GMM_BF16=0 keeps every class on the f32 kernel
       // class 0 on the bf16×3 kernel, then the f32 kernel for whatever other slot classes the lists hold (second set of
       // queue counters; an item with nothing left returns at once)
-      if (m8 == 10 && c->has_multi_block) hipLaunchKernelGGL((gmm_bf16_kernel<5, true>), grid, dim3(256), 0, c->stream, p);
-      else if (m8 == 10) hipLaunchKernelGGL((gmm_bf16_kernel<5, false>), grid, dim3(256), 0, c->stream, p);
-      else if (c->has_multi_block) hipLaunchKernelGGL((gmm_bf16_kernel<6, true>), grid, dim3(256), 0, c->stream, p);
-      else hipLaunchKernelGGL((gmm_bf16_kernel<6, false>), grid, dim3(256), 0, c->stream, p);
+      if (m8 == 10 && c->has_multi_block) hipLaunchKernelGGL((gmm_bf16_kernel<5>), grid, dim3(256), 0, c->stream, p);
+      else if (m8 == 10) hipLaunchKernelGGL((gmm_bf16_single_kernel<5>), grid, dim3(256), 0, c->stream, p);
+      else if (c->has_multi_block) hipLaunchKernelGGL((gmm_bf16_kernel<6>), grid, dim3(256), 0, c->stream, p);
+      else hipLaunchKernelGGL((gmm_bf16_single_kernel<6>), grid, dim3(256), 0, c->stream, p);
       p.skip_single = 1;
       p.queue = c->d_gmm_queue + 17;
     }

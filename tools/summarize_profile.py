@@ -19,7 +19,7 @@ def rows(sub, suffix):
 
 
 def short(name):
-    for k in ("gmm_bf16_kernel", "gmm_kernel", "viterbi_kernel", "mfcc_kernel", "feats_lda_kernel", "feats_kernel", "cmvn_utt_kernel", "cmvn_spk_kernel",
+    for k in ("gmm_bf16_single_kernel", "gmm_bf16_kernel", "gmm_kernel", "viterbi_kernel", "mfcc_kernel", "feats_lda_kernel", "feats_kernel", "cmvn_utt_kernel", "cmvn_spk_kernel",
               "arcnext_kernel", "collect_pending_kernel", "finalize_pending_kernel", "gmm_max_first_frame_kernel"):
         if k in name:
             return k
