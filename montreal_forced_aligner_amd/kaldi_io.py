@@ -7,7 +7,6 @@ Host-side plumbing only: nothing here touches the GPU.
 """
 from __future__ import annotations
 
-import io
 import struct
 import zipfile
 from dataclasses import dataclass, field

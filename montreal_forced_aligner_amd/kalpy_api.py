@@ -16,7 +16,6 @@ the C ABI; a missing library or GPU raises ``MfaHipError`` — there is no CPU p
 """
 from __future__ import annotations
 
-import os
 from dataclasses import dataclass
 from pathlib import Path
 from typing import Dict, Iterable, Iterator, List, Optional, Sequence, Tuple, Union
