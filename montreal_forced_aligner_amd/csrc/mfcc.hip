@@ -25,7 +25,7 @@ constexpr int kWavesPerBlock = 4;
 constexpr int kFramesPerWave = 16;
 constexpr int kFramesPerBlock = kWavesPerBlock * kFramesPerWave;
 constexpr int kMaxBins = 32;
-constexpr int kMaxCeps = 32;
+constexpr int kMaxCeps = 16;    // four lanes per cepstral coefficient in the DCT
 constexpr int kMaxMelW = 768;   // Σ triangle lengths (≈ 2·256 for any bin count)
 
 struct MfccParams {
@@ -112,10 +112,19 @@ __global__ __launch_bounds__(256, 4) void mfcc_kernel(MfccParams p, const int16_
   const int seg_bin = p.melseg[4 * lane], seg_first = p.melseg[4 * lane + 1], seg_woff = p.melseg[4 * lane + 2];
   const int seg_info = p.melseg[4 * lane + 3];
   const int seg_taps = seg_info & 0xFFFF, seg_parts = (seg_info >> 16) & 0xFF, seg_is_first = seg_info >> 24;
-  const float lift = lane < p.nceps ? p.lifter[lane] : 0.0f;
+  const float lift_k = (lane >> 2) < p.nceps ? p.lifter[lane >> 2] : 0.0f;   // lane quad k owns cepstral coefficient k
 
   auto load_frame = [&](int f, float (&v)[8]) {
     const int64_t start = p.snip_edges ? (int64_t)f * p.shift : (int64_t)p.shift * f + p.shift / 2 - p.win / 2;
+    if (start >= 0 && start + p.win <= n) {   // interior frame (all but the first and last one or two): no reflection
+      const int16_t *xs = x + start;
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int s = lane + 64 * j;
+        v[j] = s < p.win ? (float)xs[s] : 0.0f;
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       const int s = lane + 64 * j;
@@ -212,16 +221,24 @@ __global__ __launch_bounds__(256, 4) void mfcc_kernel(MfccParams p, const int16_
         const float other = __shfl_down(acc, q);
         if (q < seg_parts) e += other;
       }
-      if (seg_is_first) mel[seg_bin] = logf(fmaxf(e, 1.1920928955078125e-07f));  // floor at FLT_EPSILON, then log
+      // floor at FLT_EPSILON, then log (hardware log2: ≲1e-6 absolute on values of 10–25, far inside the 2e-3 the FFT leaves)
+      if (seg_is_first) mel[seg_bin] = __builtin_amdgcn_logf(fmaxf(e, 1.1920928955078125e-07f)) * 0.693147180559945309f;
     }
     WAVE_SYNC();
     // ---- DCT-II rows 0..nceps-1 + lifter
-    if (lane < p.nceps) {
+    {
+      // four lanes per coefficient, each a quarter of the mel bins (ascending), added pairwise inside the quad
+      const int k = lane >> 2, part = lane & 3;
+      const int per = (p.nbins + 3) >> 2;
+      const int b0 = part * per, b1 = min(p.nbins, b0 + per);
       float acc = 0.0f;
-      const float *d = s_dct + lane * p.nbins;
-#pragma unroll 8
-      for (int b = 0; b < p.nbins; b++) acc = fmaf(d[b], mel[b], acc);
-      out[(f0 + f) * p.nceps + lane] = acc * lift;
+      if (k < p.nceps) {
+        const float *d = s_dct + k * p.nbins;
+        for (int b = b0; b < b1; b++) acc = fmaf(d[b], mel[b], acc);
+      }
+      acc += dpp_f32<0xB1>(0.0f, acc);   // quad_perm [1,0,3,2]
+      acc += dpp_f32<0x4E>(0.0f, acc);   // quad_perm [2,3,0,1]
+      if (part == 0 && k < p.nceps) out[(f0 + f) * p.nceps + k] = acc * lift_k;
     }
     WAVE_SYNC();
   }
