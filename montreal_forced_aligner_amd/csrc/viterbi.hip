@@ -57,7 +57,7 @@ struct VitParams {
   u64 *w_bp;                           // [total_frames*bpf] (arc index <<32 | prev pos)
   u32 *w_tokoff;                       // [total_frames + n_utt]
   u32 *w_hash;                         // [n_utt] hash size carried from pass 0 to the retry pass
-  const u32 *w_arcnext;                // [total_arcs] (arc_off[next] << 7) | out-degree(next), built once per call
+  const uint4 *w_arcnext;              // [total_arcs] {next, (arc_off[next] << 7) | out-degree(next), col, weight}, built once per call
   unsigned long long *stamps;          // -DVIT_STAMPS builds: per-utterance phase cycles (mfa_debug_viterbi_stamps) or NULL
   int llcap;                           // score-row cache capacity in LDS (floats); rows longer than this are read from HBM
   // outputs
@@ -157,10 +157,9 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
   const int64_t ab_ = p.g.d_arc_base[utt];
   const int32_t *arc_off = p.g.d_arc_off + so + utt;
   const float *final_w = p.g.d_final + so;
-  const int32_t *a_next = p.g.d_arc_next + ab_;
   const float *a_w = p.g.d_arc_weight + ab_;
   const int32_t *a_col = p.g.d_arc_col + ab_;
-  const u32 *a_an = p.w_arcnext + ab_;
+  const uint4 *a_rec = p.w_arcnext + ab_;
   const int64_t f0 = p.frame_off[utt];
   const int T = (int)(p.frame_off[utt + 1] - f0);
   const float *ll = p.ll + p.ll_off[utt];
@@ -357,7 +356,7 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
         const u32 k = valid ? (u32)lane - t_cbase[tok] : 0u;
         const u32 a = (tan >> 7) + k;
         float w = 0.0f; int col = 0; u32 nx = 0u, nan_ = 0u;
-        if (valid) { w = a_w[a]; col = a_col[a]; nx = (u32)a_next[a]; nan_ = a_an[a]; }
+        if (valid) { const uint4 rec = a_rec[a]; nx = rec.x; nan_ = rec.y; col = (int)rec.z; w = __uint_as_float(rec.w); }
         const double nw = valid ? cand_cost(w, tcost, score(col), p.scale) : INFINITY;
         STAMP(3);   // arc gather + score + cost
         const double seed = wave_min_f64((valid && tok == best_i) ? nw : INFINITY);  // the best token's candidates
@@ -408,7 +407,7 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
   #pragma unroll
         for (int k = 0; k < kArcCache; k++) {
           w[k] = 0.0f; col[k] = 0; nx[k] = 0; nan_[k] = 0;
-          if (k < narc) { w[k] = a_w[a0 + k]; col[k] = a_col[a0 + k]; nx[k] = (u32)a_next[a0 + k]; nan_[k] = a_an[a0 + k]; }
+          if (k < narc) { const uint4 rec = a_rec[a0 + k]; nx[k] = rec.x; nan_[k] = rec.y; col[k] = (int)rec.z; w[k] = __uint_as_float(rec.w); }
         }
         double m = INFINITY;
   #pragma unroll
@@ -454,8 +453,8 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
             cnw = cand_cost(a_w[a0 + k], cst, score(a_col[a0 + k]), p.scale);
             created = cnw < local + (double)abeam;
             local = fmin(local, cnw);
-            d = (u32)a_next[a0 + k];
-            dan = a_an[a0 + k];
+            d = a_rec[a0 + k].x;
+            dan = a_rec[a0 + k].y;
           }
           if (created && slot_of[d] == kEmpty) claim(d, dan);
           WSYNC();
@@ -669,16 +668,19 @@ __global__ void finalize_pending_kernel(int32_t *status, int n_utt) {
   if (i < n_utt && status[i] == ST_PENDING) status[i] = ST_FAILED;
 }
 
-// (first arc << 7 | out-degree) of every arc's destination state: folds the arc_off lookup of the NEXT frame into this
-// frame's arc fetch, so a frame costs one dependent HBM/L2 round trip instead of three.
-__global__ void arcnext_kernel(mfa_graph_batch g, u32 *out) {
+// One 16-byte record per arc for the frame loop: {destination state, (first arc << 7 | out-degree) of the destination,
+// score column, weight}.  The destination's arc range folds the arc_off lookup of the NEXT frame into this frame's arc
+// fetch (one dependent HBM/L2 round trip per frame instead of three), and the record makes that fetch one 16-byte load
+// touching one line instead of four 4-byte gathers from four arrays.
+__global__ void arcnext_kernel(mfa_graph_batch g, uint4 *out) {
   const int utt = blockIdx.x;
   const int64_t so = g.d_state_off[utt], ab = g.d_arc_base[utt];
   const int64_t na = g.d_arc_base[utt + 1] - ab;
   const int32_t *arc_off = g.d_arc_off + so + utt;
   for (int64_t a = threadIdx.x; a < na; a += blockDim.x) {
     const int d = g.d_arc_next[ab + a];
-    out[ab + a] = ((u32)arc_off[d] << 7) | (u32)(arc_off[d + 1] - arc_off[d]);
+    const u32 an = ((u32)arc_off[d] << 7) | (u32)(arc_off[d + 1] - arc_off[d]);
+    out[ab + a] = make_uint4((u32)d, an, (u32)g.d_arc_col[ab + a], __float_as_uint(g.d_arc_weight[ab + a]));
   }
 }
 
@@ -696,7 +698,7 @@ struct WsLayout {
 WsLayout ws_layout(int n_utt, int64_t total_frames, int N, int C, int bpf, int64_t total_arcs) {
   WsLayout w; size_t o = 0;
   auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 255) & ~(size_t)255; return at; };
-  w.arcnext = take((size_t)total_arcs * 4);
+  w.arcnext = take((size_t)total_arcs * 16);
   w.state = take((size_t)n_utt * 4 * N * 4);  // token states + their packed arc ranges
   w.cost = take((size_t)n_utt * 2 * N * 8);
   w.sta = take((size_t)n_utt * C * 4);
@@ -767,7 +769,7 @@ MFA_API int mfa_align_batch(mfa_ctx *c, const mfa_graph_batch *g, const float *d
     c->ws_bytes = w.total;
   }
   unsigned char *base = (unsigned char *)c->d_ws;
-  hipLaunchKernelGGL(arcnext_kernel, dim3(n_utt), dim3(256), 0, c->stream, *g, (u32 *)(base + w.arcnext));
+  hipLaunchKernelGGL(arcnext_kernel, dim3(n_utt), dim3(256), 0, c->stream, *g, (uint4 *)(base + w.arcnext));
   // Launch plan.  The decoder is latency-bound (one wavefront walks one utterance frame by frame), so throughput is the
   // number of wavefronts a CU can keep resident, and that is set by the LDS tables, which scale with the token capacity.
   // With the normal beam a frame rarely holds more than a few dozen tokens, so every utterance is first decoded with
@@ -806,7 +808,7 @@ MFA_API int mfa_align_batch(mfa_ctx *c, const mfa_graph_batch *g, const float *d
     p.w_stash_a = (u32 *)(base + wp.sta); p.w_stash_b = (u32 *)(base + wp.stb); p.w_stash_key = (u64 *)(base + wp.stkey);
     p.w_bp = (u64 *)(base + wp.bp); p.w_tokoff = (u32 *)(base + wp.tokoff);
     p.w_hash = (u32 *)(base + w.hash);     // fixed location across launches
-    p.w_arcnext = (const u32 *)(base + w.arcnext);
+    p.w_arcnext = (const uint4 *)(base + w.arcnext);
     p.llcap = kLlCap;
     p.stamps = (unsigned long long *)c->vit_stamps;
     int32_t *d_list = (int32_t *)(base + w.list), *d_count = (int32_t *)(base + w.count);
