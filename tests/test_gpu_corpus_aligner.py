@@ -44,6 +44,10 @@ def test_corpus_aligner_on_reference_fixture(engine, fx, tmp_path):
     text = paths[0].read_text(encoding="utf8")
     assert 'name = "spkA - words"' in text and 'name = "spkB - phones"' in text
     assert text.count('text = "acoustic"') == 1 and 'xmax = %s' % round(len(fx.pcm) / sr, 6) in text
+    # the one-rank form of the sharded entry point goes through the same speaker assignment and gather
+    from montreal_forced_aligner_amd.aligner import align_sharded
+    res_s = align_sharded(lambda: al, utts, rank=0, world_size=1)
+    assert all(np.array_equal(a.alignment, b.alignment) for a, b in zip(res, res_s))
     # a transcript the lexicon cannot spell and audio too short to hold it: counted as failed, not raised
     bad = CorpusUtterance("spkB-x", "spkB", fx.pcm[: sr // 4], "this is the acoustic corpus i'm talking pretty fast here")
     res2 = al.align([utts[2], bad])
