@@ -54,6 +54,12 @@ struct mfa_ctx {
   int dim = 0, kpad = 0, num_pdfs = 0, num_rows = 0;
   float *d_w = nullptr;        // [num_rows][kpad] permuted weights
   void *d_wb = nullptr;        // bf16×3 split of d_w for gmm_bf16_kernel (see gmm.hip), or NULL
+  void *d_wh = nullptr;        // f16×2 split of the column-scaled d_w for gmm_split_single_kernel<…, 2>, or NULL
+  float *d_gch = nullptr;      // gconsts × gmm_acc_scale
+  float *d_fscale = nullptr;   // [kpad] feature column scales of the f16 path
+  float gmm_acc_scale = 1.0f;  // S: the f16 path's accumulators are S × the log-likelihood terms (power of two)
+  int *d_gmm_redo = nullptr;   // tiles the f16 pass handed to the bf16×3 pass
+  int64_t gmm_redo_cap = 0;
   float *d_gc = nullptr;       // [num_rows]
   int32_t *d_row0 = nullptr;   // [num_pdfs] first packed row
   int32_t *d_nblk = nullptr;   // [num_pdfs] number of 32-row blocks (slot 32) else 1

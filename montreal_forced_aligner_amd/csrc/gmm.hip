@@ -25,6 +25,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -35,6 +36,7 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // a wavefront owns NT 32-frame tiles; a workgroup is kWaves wavefronts (template parameter)
 constexpr float kPadGconst = -1.0e30f;
@@ -43,6 +45,12 @@ struct GmmParams {
   int dim, kpad, num_rows;  // num_rows = index of the dummy row
   const float *w; const float *gc; const int32_t *row0; const int32_t *nblk; const int32_t *slot;
   const uint4 *wb;   // bf16×3 split of the packed rows, 32-row blocks of [step][split][half][row] 16-byte units (or NULL)
+  const uint4 *wh;   // f16×2 split of the column-scaled rows, same block layout with two pieces (or NULL)
+  const float *gch;  // gconsts × S for the f16 kernel
+  const float *fscale;   // [kpad] feature column scales S·2^-e_k for the f16 kernel
+  float acc_scale_inv;   // 1 / S
+  int *redo;         // [n_utt × tiles] tiles the f16 kernel declined (scaled feature outside the f16 range)
+  int redo_mode;     // 0: score everything; 2: score only the tiles flagged in redo
   const float *feats; const int64_t *frame_off;
   const int32_t *pdf_list; const int64_t *pdf_off; const int32_t *class_counts; const int64_t *ll_off;
   unsigned long long *trace;   // debug (mfa_debug_gmm_trace): per workgroup {start, end, hw id, blocks} or NULL
@@ -172,20 +180,20 @@ __device__ __forceinline__ float reg_expsum(const f32x16 &v, float mx, float cut
     for (int r = 0; r + w < n; r += 2 * w) e[r] += e[r + w];
   return e[0];
 }
-// bf16×3 path: Σ_r exp(v[r] − mx) without Kaldi's cutoff (terms below max + ln ε add < 4e-6 to the sum in total — inside
-// that path's tolerance, and mathematically the exact log-sum-exp) and with the argument formed by one packed fma per two
-// terms; 16 exp2, 8 v_pk_fma_f32, 8 packed adds per tile instead of ≈110 instructions.
+// split-operand paths: Σ_r exp(v[r] − mx) without Kaldi's cutoff (terms below max + ln ε add < 4e-6 to the sum in total —
+// inside those paths' tolerance, and mathematically the exact log-sum-exp), two terms per packed instruction: 16 exp2,
+// 8 v_pk_add_f32, 8 v_pk_mul_f32, 8 packed adds per tile instead of ≈110 instructions.  The difference is formed BEFORE the
+// multiplication by log2 e: fma(v, log2e, −mx·log2e) would carry the rounding of mx·log2e (2^-24·|mx|) into every term —
+// 5e-6 on the result at |mx| = 100 and an overflow to inf for an outlier frame with |mx| ≳ 1e9.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float reg_expsum_fast(const f32x16 &v, float mx) {
-  const float l2e = 1.44269504088896341f;
+__device__ __forceinline__ float reg_expsum_fast(const f32x16 &v, float mx, float l2e = 1.44269504088896341f) {
   const f32x2 lv = {l2e, l2e};
-  const float nm = -mx * l2e;
-  const f32x2 nv = {nm, nm};
+  const f32x2 mv = {mx, mx};
   f32x2 e[8];
 #pragma unroll
   for (int r = 0; r < 8; r++) {
     const f32x2 x = {v[2 * r], v[2 * r + 1]};
-    const f32x2 arg = __builtin_elementwise_fma(x, lv, nv);
+    const f32x2 arg = (x - mv) * lv;
     e[r].x = __builtin_amdgcn_exp2f(arg.x);
     e[r].y = __builtin_amdgcn_exp2f(arg.y);
   }
@@ -830,10 +838,19 @@ __global__ __launch_bounds__(256, 2) void gmm_bf16_kernel(GmmParams p) {
 // is no entry table beyond the block indices, no merge state, fixed 32-column staging phases, and the block copies go
 // global → LDS directly (global_load_lds_dwordx4; here the compiler lets them overlap).  3 % faster than the general kernel
 // on configs[2]; same arithmetic, same results.
-template <int kSteps>   // 16-k steps per row: 5 for D ≤ 40, 6 for D ≤ 48
-__global__ __launch_bounds__(256, 2) void gmm_bf16_single_kernel(GmmParams p) {
+//
+// kPieces = 3: operands are bf16 triples, six products per 16 k-values (2^-24 per term, any exponent range).
+// kPieces = 2: operands are f16 pairs, three products (a2·b1, a1·b2, a1·b1: 3·2^-22 per term worst case, half the matrix
+//   work).  f16 has 5 exponent bits, so the operands are scaled by powers of two chosen from the model at load time
+//   (mfa_load_gmm: weight column k × 2^e_k, feature column k × S·2^-e_k, accumulators therefore × S; all exact) and a tile
+//   whose scaled features leave the f16 range is not scored here: it is flagged in p.redo and scored by the kPieces = 3
+//   kernel, launched next with redo_mode 2.
+template <int kSteps, int kPieces>   // 16-k steps per row: 5 for D ≤ 40, 6 for D ≤ 48
+__global__ __launch_bounds__(256, 2) void gmm_split_single_kernel(GmmParams p) {
   constexpr int kNT = 2, kWaves = 4, kFramesPerWave = 64, kFramesPerTile = 256;
-  constexpr int kUnits = kSteps * 3 * 2 * 32;          // 16-byte units per block
+  constexpr bool kHalf = kPieces == 2;
+  using op8 = std::conditional_t<kHalf, f16x8, bf16x8>;
+  constexpr int kUnits = kSteps * kPieces * 2 * 32;    // 16-byte units per block
   constexpr int kLoads = (kUnits + 255) / 256;         // units each thread moves per block
   const int lane0 = threadIdx.x & 63, wave = threadIdx.x >> 6;
   __shared__ float stage_all[kWaves][64 * 33];
@@ -860,6 +877,7 @@ __global__ __launch_bounds__(256, 2) void gmm_bf16_single_kernel(GmmParams p) {
       const int64_t f0 = p.frame_off[utt];
       const int T = (int)(p.frame_off[utt + 1] - f0);
       if (tl * kFramesPerTile >= T) continue;          // uniform over the workgroup
+      if (!kHalf && p.redo_mode == 2 && p.redo[(size_t)utt * p.tiles + tl] == 0) continue;   // only what the f16 pass left
       const int t_base = (tl * kWaves + wave) * kFramesPerWave;
       const bool active = t_base < T;                  // a wavefront past the end still helps move blocks and joins barriers
       const int64_t l0 = p.pdf_off[utt];
@@ -884,7 +902,8 @@ __global__ __launch_bounds__(256, 2) void gmm_bf16_single_kernel(GmmParams p) {
       float *out = p.out + p.ll_off[utt];
       if (n_single > 0) {
         // ---- x̃ = [x, x²] of this wavefront's 64 frames, split into bf16 triples: b[tile][step][piece], lane (frame, half)
-        bf16x8 b[kNT][kSteps][3];
+        op8 b[kNT][kSteps][kPieces];
+        bool bad = false;                                  // kHalf: a scaled feature outside the f16 range (or NaN)
 #pragma unroll
         for (int n = 0; n < kNT; n++) {
           int t = t_base + 32 * n + col;
@@ -899,21 +918,38 @@ __global__ __launch_bounds__(256, 2) void gmm_bf16_single_kernel(GmmParams p) {
               const int idx = k < p.dim ? k : (k < 2 * p.dim ? k - p.dim : 0);
               const float xv = x[idx];
               const float v = k < p.dim ? xv : (k < 2 * p.dim ? xv * xv : 0.0f);
-              const __bf16 v1 = (__bf16)v;
-              const float r1 = v - (float)v1;
-              const __bf16 v2 = (__bf16)r1;
-              const float r2 = r1 - (float)v2;
-              b[n][s][0][e] = v1; b[n][s][1][e] = v2; b[n][s][2][e] = (__bf16)r2;
+              if constexpr (kHalf) {
+                const float sv = v * p.fscale[k];
+                bad |= !(fabsf(sv) <= 65000.0f);
+                const _Float16 v1 = (_Float16)sv;
+                b[n][s][0][e] = v1; b[n][s][1][e] = (_Float16)(sv - (float)v1);
+              } else {
+                const __bf16 v1 = (__bf16)v;
+                const float r1 = v - (float)v1;
+                const __bf16 v2 = (__bf16)r1;
+                const float r2 = r1 - (float)v2;
+                b[n][s][0][e] = v1; b[n][s][1][e] = v2; b[n][s][2][e] = (__bf16)r2;
+              }
             }
           }
         }
+        if constexpr (kHalf) {
+          if (__syncthreads_or(bad)) {                     // uniform: the whole tile goes to the bf16×3 pass
+            if (threadIdx.x == 0) p.redo[(size_t)utt * p.tiles + tl] = 1;
+            continue;
+          }
+        }
+        const uint4 *wsrc = kHalf ? p.wh : p.wb;
+        const float *gsrc = kHalf ? p.gch : p.gc;
+        const float inv_s = kHalf ? p.acc_scale_inv : 1.0f;
+        const float l2e_s = 1.44269504088896341f * inv_s;  // inv_s is a power of two: (x·inv_s)·log2e == x·(log2e·inv_s)
         // Block copy global → LDS without a register stop (global_load_lds_dwordx4: every lane's 16 bytes land at a
         // wavefront-uniform LDS base + 16·lane, which is exactly the linear unit order of a block).
         typedef __attribute__((address_space(1))) const void *gptr_t;
         typedef __attribute__((address_space(3))) void *lptr_t;
         const int wave_u = __builtin_amdgcn_readfirstlane(wave);
         auto fetch = [&](int blk, int buf) {
-          const uint4 *src = p.wb + (size_t)blk * kUnits;
+          const uint4 *src = wsrc + (size_t)blk * kUnits;
 #pragma unroll
           for (int i = 0; i < kLoads; i++) {
             const int u0 = 64 * wave_u + 256 * i;        // first unit this wavefront moves in round i (uniform)
@@ -921,7 +957,7 @@ __global__ __launch_bounds__(256, 2) void gmm_bf16_single_kernel(GmmParams p) {
               __builtin_amdgcn_global_load_lds((gptr_t)(src + u0 + lane), (lptr_t)&a_lds[buf][u0], 16, 0, 0);
           }
           if (wave_u == 0 && lane < 8)
-            __builtin_amdgcn_global_load_lds((gptr_t)(p.gc + (size_t)blk * 32 + 4 * lane), (lptr_t)&gc_lds[buf][0], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(gsrc + (size_t)blk * 32 + 4 * lane), (lptr_t)&gc_lds[buf][0], 16, 0, 0);
         };
         auto landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
         for (int c0 = 0; c0 < n_single; c0 += kBlkCache) {
@@ -951,26 +987,31 @@ __global__ __launch_bounds__(256, 2) void gmm_bf16_single_kernel(GmmParams p) {
               for (int n = 0; n < kNT; n++) acc[n] = init;
             }
             // operand pieces of step s+1 are read from LDS while step s is multiplied
-            auto read_a = [&](int s, bf16x8 (&a)[3]) {
+            auto read_a = [&](int s, op8 (&a)[kPieces]) {
 #pragma unroll
-              for (int qq = 0; qq < 3; qq++)
-                a[qq] = __builtin_bit_cast(bf16x8, a_lds[buf][((s * 3 + qq) * 2 + h) * 32 + col]);
+              for (int qq = 0; qq < kPieces; qq++)
+                a[qq] = __builtin_bit_cast(op8, a_lds[buf][((s * kPieces + qq) * 2 + h) * 32 + col]);
             };
-            bf16x8 a_cur[3], a_nxt[3];
+            op8 a_cur[kPieces], a_nxt[kPieces];
             read_a(0, a_cur);
 #pragma unroll
             for (int s = 0; s < kSteps; s++) {
               if (s + 1 < kSteps) read_a(s + 1, a_nxt);
-              // six products per 16 k-values, smallest terms first; the two tiles alternate so that consecutive MFMAs never
-              // wait on each other's accumulator
-              constexpr int pa[6] = {2, 1, 0, 1, 0, 0}, pb[6] = {0, 1, 2, 0, 1, 0};
+              // six (three) products per 16 k-values, smallest terms first; the two tiles alternate so that consecutive MFMAs
+              // never wait on each other's accumulator
+              constexpr int kProd = kHalf ? 3 : 6;
+              constexpr int pa[6] = {kHalf ? 1 : 2, kHalf ? 0 : 1, 0, 1, 0, 0}, pb[6] = {0, 1, kHalf ? 0 : 2, 0, 1, 0};
 #pragma unroll
-              for (int t6 = 0; t6 < 6; t6++)
+              for (int t6 = 0; t6 < kProd; t6++)
 #pragma unroll
-                for (int n = 0; n < kNT; n++)
-                  acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[pa[t6]], b[n][s][pb[t6]], acc[n], 0, 0, 0);
+                for (int n = 0; n < kNT; n++) {
+                  if constexpr (kHalf)
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[pa[t6]], b[n][s][pb[t6]], acc[n], 0, 0, 0);
+                  else
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[pa[t6]], b[n][s][pb[t6]], acc[n], 0, 0, 0);
+                }
 #pragma unroll
-              for (int qq = 0; qq < 3; qq++) a_cur[qq] = a_nxt[qq];
+              for (int qq = 0; qq < kPieces; qq++) a_cur[qq] = a_nxt[qq];
             }
             // ---- log-sum-exp epilogue and LDS-staged, coalesced score stores: as in score_tile
             float mx[kNT], sum[kNT];
@@ -981,9 +1022,9 @@ __global__ __launch_bounds__(256, 2) void gmm_bf16_single_kernel(GmmParams p) {
 #else
               float m = reg_max<0, 16>(acc[n]);
               m = fmaxf(m, swap32(m, h));
-              float sv = reg_expsum_fast(acc[n], m);
+              float sv = reg_expsum_fast(acc[n], m, l2e_s);
               sv += swap32(sv, h);
-              mx[n] = m; sum[n] = sv;
+              mx[n] = m * inv_s; sum[n] = sv;
 #endif
             }
             const float v = finish(h ? mx[1] : mx[0], h ? sum[1] : sum[0]);
@@ -1127,8 +1168,66 @@ MFA_API int mfa_load_gmm(mfa_ctx *c, int32_t dim, int32_t num_pdfs, const int32_
       }
     }
   }
-  void *old[] = {c->d_w, c->d_gc, c->d_row0, c->d_nblk, c->d_slot, c->d_nrows, c->d_wb};
-  c->d_wb = nullptr;
+  // f16×2 split (default scoring path of the 32-row classes without multi-block pdfs).  Column k of the weights is
+  // multiplied by 2^e_k and column k of x̃ by S·2^-e_k, so every product — and the gconst, stored × S — carries the one
+  // factor S and nothing is rounded differently.  The exponents balance the two operands inside the f16 range using the
+  // model's own idea of how large a feature can get (|μ| + 10σ over all Gaussians); features beyond 65000 after scaling
+  // are caught per tile on the device (see gmm_split_single_kernel).
+  std::vector<uint16_t> wh;
+  std::vector<float> fscale(kpad, 0.0f), gch;
+  float acc_scale = 1.0f;
+  if (want_bf16) {
+    std::vector<double> wmax(2 * dim, 0.0), xmax(2 * dim, 0.0);
+    for (int p = 0; p < num_pdfs; p++) {
+      int g0 = h_pdf_offsets[p], g = h_pdf_offsets[p + 1] - g0;
+      for (int i = 0; i < g; i++) {
+        const float *mi = h_means_invvars + (size_t)(g0 + i) * dim, *iv = h_inv_vars + (size_t)(g0 + i) * dim;
+        for (int k = 0; k < dim; k++) {
+          const double v = iv[k], m = mi[k];
+          if (std::isfinite(m)) wmax[k] = std::max(wmax[k], std::fabs(m));
+          if (std::isfinite(v)) wmax[dim + k] = std::max(wmax[dim + k], 0.5 * std::fabs(v));
+          if (std::isfinite(v) && std::isfinite(m) && v > 0) {
+            const double reach = std::fabs(m / v) + 10.0 / std::sqrt(v);
+            if (std::isfinite(reach)) { xmax[k] = std::max(xmax[k], reach); xmax[dim + k] = std::max(xmax[dim + k], reach * reach); }
+          }
+        }
+      }
+    }
+    int log_s = 12;
+    for (int k = 0; k < 2 * dim; k++)
+      if (wmax[k] > 0 && xmax[k] > 0) log_s = std::min(log_s, (int)std::floor(26.0 - std::log2(wmax[k] * xmax[k])));
+    log_s = std::max(log_s, -20);
+    acc_scale = std::ldexp(1.0f, log_s);
+    std::vector<int> e_w(2 * dim, 0);
+    for (int k = 0; k < 2 * dim; k++) {
+      if (!(wmax[k] > 0)) { fscale[k] = 0.0f; continue; }           // an all-zero weight column: x̃_k is irrelevant
+      const double xm = xmax[k] > 0 ? xmax[k] : 1.0;
+      int e = (int)std::lround(0.5 * (log_s + std::log2(xm) - std::log2(wmax[k])));
+      while (std::ldexp(wmax[k], e) > 32768.0) e--;                 // never let the weights themselves leave the range
+      e = std::max(-100, std::min(100, e));
+      e_w[k] = e;
+      fscale[k] = (float)std::ldexp(1.0, log_s - e);
+    }
+    wh.assign((size_t)blocks * steps * 2 * 2 * 32 * 8, 0);
+    auto f16_bits = [](float f) -> uint16_t { _Float16 hv = (_Float16)f; uint16_t u; memcpy(&u, &hv, 2); return u; };
+    for (int row = 0; row < rows; row++) {
+      for (int k = 0; k < 2 * dim; k++) {
+        const float v = std::ldexp(w[mfa_packed_offset(row, k, kpad)], e_w[k]);
+        const _Float16 v1 = (_Float16)v;
+        const float r1 = v - (float)v1;
+        const uint16_t piece[2] = {f16_bits(v), f16_bits(r1)};
+        const int s_ = k >> 4, hh = (k >> 3) & 1, e = k & 7;
+        for (int qq = 0; qq < 2; qq++) {
+          const size_t unit = (size_t)(row >> 5) * steps * 2 * 2 * 32 + (size_t)((s_ * 2 + qq) * 2 + hh) * 32 + (row & 31);
+          wh[unit * 8 + e] = piece[qq];
+        }
+      }
+    }
+    gch.resize(gc.size());
+    for (size_t i = 0; i < gc.size(); i++) gch[i] = gc[i] * acc_scale;
+  }
+  void *old[] = {c->d_w, c->d_gc, c->d_row0, c->d_nblk, c->d_slot, c->d_nrows, c->d_wb, c->d_wh, c->d_gch, c->d_fscale};
+  c->d_wb = nullptr; c->d_wh = nullptr; c->d_gch = nullptr; c->d_fscale = nullptr;
   for (void *q : old) if (q) (void)hipFree(q);
   c->d_w = nullptr; c->d_gc = nullptr; c->d_row0 = nullptr; c->d_nblk = nullptr; c->d_slot = nullptr; c->d_nrows = nullptr;
   MFA_HIP_CHECK(c, hipMalloc((void **)&c->d_w, w.size() * 4));
@@ -1140,6 +1239,13 @@ MFA_API int mfa_load_gmm(mfa_ctx *c, int32_t dim, int32_t num_pdfs, const int32_
   if (want_bf16) {
     MFA_HIP_CHECK(c, hipMalloc((void **)&c->d_wb, wb.size() * 2));
     MFA_HIP_CHECK(c, hipMemcpy(c->d_wb, wb.data(), wb.size() * 2, hipMemcpyHostToDevice));
+    MFA_HIP_CHECK(c, hipMalloc((void **)&c->d_wh, wh.size() * 2));
+    MFA_HIP_CHECK(c, hipMemcpy(c->d_wh, wh.data(), wh.size() * 2, hipMemcpyHostToDevice));
+    MFA_HIP_CHECK(c, hipMalloc((void **)&c->d_gch, gch.size() * 4));
+    MFA_HIP_CHECK(c, hipMemcpy(c->d_gch, gch.data(), gch.size() * 4, hipMemcpyHostToDevice));
+    MFA_HIP_CHECK(c, hipMalloc((void **)&c->d_fscale, fscale.size() * 4));
+    MFA_HIP_CHECK(c, hipMemcpy(c->d_fscale, fscale.data(), fscale.size() * 4, hipMemcpyHostToDevice));
+    c->gmm_acc_scale = acc_scale;
   }
   MFA_HIP_CHECK(c, hipMemcpy(c->d_gc, gc.data(), gc.size() * 4, hipMemcpyHostToDevice));
   MFA_HIP_CHECK(c, hipMemcpy(c->d_row0, row0.data(), row0.size() * 4, hipMemcpyHostToDevice));
@@ -1273,14 +1379,34 @@ MFA_API int mfa_gmm_score_batch(mfa_ctx *c, const float *d_feats, const int64_t 
     dim3 grid((unsigned)std::max<int64_t>(wgs, 1));
     const char *bf = getenv("MFA_GMM_BF16");
     p.wb = (const uint4 *)c->d_wb;
+    p.wh = nullptr; p.gch = nullptr; p.fscale = nullptr; p.acc_scale_inv = 1.0f; p.redo = nullptr; p.redo_mode = 0;
     p.skip_single = 0;
     if (!(bf && bf[0] == '0') && c->d_wb) {   // default on; MFA_GMM_BF16=0 keeps every class on the f32 kernel
       // class 0 on the bf16×3 kernel, then the f32 kernel for whatever other slot classes the lists hold (second set of
       // queue counters; an item with nothing left returns at once)
+      const char *hf = getenv("MFA_GMM_F16");
+      const bool use_f16 = !(hf && hf[0] == '0') && c->d_wh && !c->has_multi_block;
+      if (use_f16) {
+        // f16×2 pass over every tile, then the bf16×3 pass over the tiles it declined (third set of queue counters)
+        if (c->gmm_redo_cap < items) {
+          if (c->d_gmm_redo) (void)hipFree(c->d_gmm_redo);
+          c->d_gmm_redo = nullptr; c->gmm_redo_cap = 0;
+          MFA_HIP_CHECK(c, hipMalloc((void **)&c->d_gmm_redo, items * sizeof(int)));
+          c->gmm_redo_cap = items;
+        }
+        MFA_HIP_CHECK(c, hipMemsetAsync(c->d_gmm_redo, 0, items * sizeof(int), c->stream));
+        p.wh = (const uint4 *)c->d_wh; p.gch = c->d_gch; p.fscale = c->d_fscale;
+        p.acc_scale_inv = 1.0f / c->gmm_acc_scale;
+        p.redo = c->d_gmm_redo; p.redo_mode = 0;
+        if (m8 == 10) hipLaunchKernelGGL((gmm_split_single_kernel<5, 2>), grid, dim3(256), 0, c->stream, p);
+        else hipLaunchKernelGGL((gmm_split_single_kernel<6, 2>), grid, dim3(256), 0, c->stream, p);
+        p.redo_mode = 2;
+        p.queue = c->d_gmm_queue + 34;
+      }
       if (m8 == 10 && c->has_multi_block) hipLaunchKernelGGL((gmm_bf16_kernel<5>), grid, dim3(256), 0, c->stream, p);
-      else if (m8 == 10) hipLaunchKernelGGL((gmm_bf16_single_kernel<5>), grid, dim3(256), 0, c->stream, p);
+      else if (m8 == 10) hipLaunchKernelGGL((gmm_split_single_kernel<5, 3>), grid, dim3(256), 0, c->stream, p);
       else if (c->has_multi_block) hipLaunchKernelGGL((gmm_bf16_kernel<6>), grid, dim3(256), 0, c->stream, p);
-      else hipLaunchKernelGGL((gmm_bf16_single_kernel<6>), grid, dim3(256), 0, c->stream, p);
+      else hipLaunchKernelGGL((gmm_split_single_kernel<6, 3>), grid, dim3(256), 0, c->stream, p);
       p.skip_single = 1;
       p.queue = c->d_gmm_queue + 17;
     }

@@ -359,6 +359,45 @@ def test_gmm_bf16_split_kernel_within_float32_rounding(engine, dim, monkeypatch)
     assert changed > 0   # the bf16 path really ran
 
 
+@pytest.mark.parametrize("dim", [40, 45])
+def test_gmm_f16_split_kernel_within_tolerance_and_range_fallback(engine, dim, monkeypatch):
+    """Default scoring of a model without multi-block pdfs: the 32-row class goes through the f16×2 MFMA kernel (three
+    products per term, operands scaled by model-derived powers of two; worst case 3·2^-22 per term).  Scores stay within
+    2e-5 × scale of the oracle per (frame, pdf) cell — north_star allows 1e-3 on a log-likelihood — and a 256-frame tile
+    holding a feature value that leaves the f16 range after scaling is scored by the bf16×3 kernel instead: its cells are
+    bit-identical to a run with MFA_GMM_F16=0."""
+    rng = np.random.default_rng(300 + dim)
+    sizes = [32] * 40 + [17, 20, 31, 32, 29] + [1, 4, 8, 16]
+    am = helpers.random_gmm(rng, dim, sizes)
+    feats = [rng.normal(0, 3, size=(t, dim)).astype(np.float32) for t in (1, 63, 64, 65, 257, 700)]
+    feats[5][300, 3] = 3.0e5        # tile 1 of the last utterance (frames 256..511) leaves the f16 range
+    lists = [rng.permutation(am.num_pdfs)[:n].astype(np.int32) for n in (49, 30, 45, 1, 49, 40)]
+    monkeypatch.setenv("MFA_GMM_F16", "0")
+    bf16_scores, sorted_lists = _score(engine, am, feats, lists)
+    monkeypatch.delenv("MFA_GMM_F16")
+    got, sorted_lists2 = _score(engine, am, feats, lists)
+    n_gauss = np.diff(am.pdf_offsets)
+    changed, worst = 0, 0.0
+    for u in range(len(feats)):
+        assert np.array_equal(sorted_lists[u], sorted_lists2[u])
+        ref = O.gmm_loglikes(feats[u], am.gconsts, am.means_invvars, am.inv_vars, am.pdf_offsets, sorted_lists[u])
+        scale = np.maximum(1.0, np.abs(ref).max(axis=1, keepdims=True))     # per frame: the outlier frame is its own scale
+        err = np.abs(got[u] - ref) / scale
+        worst = max(worst, float(err.max()))
+        at = np.unravel_index(np.argmax(np.nan_to_num(err, nan=np.inf)), err.shape)
+        assert err.max() < 2e-5, (u, at, float(got[u][at]), float(ref[at]), float(bf16_scores[u][at]))
+        single = n_gauss[sorted_lists[u]] > 16
+        assert np.array_equal(got[u][:, ~single], bf16_scores[u][:, ~single])   # f32 kernel in both runs
+        if u == 5:
+            assert np.array_equal(got[u][256:512], bf16_scores[u][256:512])     # the declined tile
+            keep = np.r_[0:256, 512:700]
+            changed += int((got[u][keep][:, single] != bf16_scores[u][keep][:, single]).sum())
+        else:
+            changed += int((got[u][:, single] != bf16_scores[u][:, single]).sum())
+    assert changed > 0   # the f16 path really ran
+    print(f"f16x2 worst |err|/scale = {worst:.3g}")
+
+
 def test_reachability_bounded_scoring_changes_nothing(engine, fx):
     """Scoring with pdf_first_frame skips (frame, pdf) cells no decoder token can ask for: every cell it does write is
     bit-identical to the dense matrix, every cell at or after the pdf's first frame is written, and the alignment that
