@@ -316,24 +316,31 @@ def main():
                 ks_ = json.load(fh)["kernels"]
                 if os.environ.get("MFA_GMM_BF16", "1") == "0":
                     d_ = ks_["gmm_kernel"]["derived"]
-                else:
+                elif os.environ.get("MFA_GMM_F16", "1") == "0":
                     d_ = (ks_.get("gmm_bf16_single_kernel") or ks_["gmm_bf16_kernel"])["derived"]
+                else:
+                    d_ = ks_["gmm_split_single_kernel_f16"]["derived"]
             traffic = float(d_["fetch_bytes_per_dispatch_raw"] + d_["write_bytes_per_dispatch"])
             traffic_src = ("profiles/r01_profile_summary_triphone_b2048.json: (FETCH_SIZE + WRITE_SIZE) KiB x 1024 per "
                            "launch, FETCH_SIZE uncorrected (gfx950 may tally 128-B reads at 64 B: up to 2x more)")
         except (KeyError, ValueError):
             pass
-    # The scoring kernel of the headline workload.  Default: the bf16×3 kernel — every float32 product is formed as six bf16
-    # MFMA products (exact to 2^-24 per term), so the matrix pipe executes 6× the algorithmic flops and is priced against
-    # the dense bf16 peak.  MFA_GMM_BF16=0 (or a model whose pdfs are not single 32-row blocks, like the monophone one):
-    # the f32 MFMA kernel against the f32 peak.
+    # The scoring kernel of the headline workload.  Default: the f16×2 kernel — every float32 product is formed as three
+    # f16 MFMA products (3·2^-22 per term worst case), so the matrix pipe executes 3× the algorithmic flops and is priced
+    # against the dense f16 peak (same as bf16).  MFA_GMM_F16=0: the bf16×3 kernel, six products (2^-24 per term).
+    # MFA_GMM_BF16=0 (or a model whose pdfs are not single 32-row blocks, like the monophone one): the f32 MFMA kernel
+    # against the f32 peak.
     bf16 = os.environ.get("MFA_GMM_BF16", "1") != "0" and not mono and 16 < args.gauss_per_pdf <= 32
+    f16 = bf16 and os.environ.get("MFA_GMM_F16", "1") != "0"
     if bf16:
+        mult = 3.0 if f16 else 6.0
         roofline = {
-            "kernel": "gmm_bf16_single_kernel (diagonal-GMM scoring, 3-way bf16 split on v_mfma_f32_32x32x16_bf16)", "bound": "mfma",
-            "achieved": round(6.0 * achieved, 3), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(6.0 * achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-            "algorithmic_flops_per_launch": flops_per_launch, "mfma_flops_per_algorithmic_flop": 6,
+            "kernel": ("gmm_split_single_kernel<5,2> (diagonal-GMM scoring, 2-way f16 split on v_mfma_f32_32x32x16_f16)" if f16 else
+                       "gmm_split_single_kernel<5,3> (diagonal-GMM scoring, 3-way bf16 split on v_mfma_f32_32x32x16_bf16)"),
+            "bound": "mfma",
+            "achieved": round(mult * achieved, 3), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(mult * achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+            "algorithmic_flops_per_launch": flops_per_launch, "mfma_flops_per_algorithmic_flop": int(mult),
             "f32_equivalent_tflops": round(achieved, 3), "avg_launch_ms": round(gmm_ms, 4),
             **({"traffic_source": traffic_src} if traffic is not None else {}),
         }
@@ -351,7 +358,8 @@ def main():
         "value": round(value, 2), "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None,
-        "dtype": ("f32 scores from 3-way bf16-split products (2^-24 per term), f64 path costs" if bf16
+        "dtype": ("f32 scores from 2-way f16-split products (3*2^-22 per term worst case), f64 path costs" if bf16 and f16
+                  else "f32 scores from 3-way bf16-split products (2^-24 per term), f64 path costs" if bf16
                   else "f32 (scores), f64 (path costs)"), "data": "synthetic",
         "config": {
             "workload": ("BASELINE configs[2]: synthetic 10 s 16 kHz utterances, context-dependent SAT-style GMM "

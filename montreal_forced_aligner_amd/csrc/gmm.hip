@@ -960,6 +960,73 @@ __global__ __launch_bounds__(256, 2) void gmm_split_single_kernel(GmmParams p) {
             __builtin_amdgcn_global_load_lds((gptr_t)(gsrc + (size_t)blk * 32 + 4 * lane), (lptr_t)&gc_lds[buf][0], 16, 0, 0);
         };
         auto landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+        // ---- block loop, software-pipelined inside the wavefront.  An 8-pass MFMA holds the matrix pipe for 32 cycles but the
+        // issue port for 4; a wavefront that issues its MFMAs back to back and its log-sum-exp afterwards leaves one of the
+        // two idle in turn, and the two wavefronts of a SIMD fall into step (whoever leads is slowed by sharing, whoever lags
+        // runs alone and catches up), so nothing overlaps.  Here the epilogue of block j-1 is cut into ≤ 7-instruction
+        // chunks and one chunk follows each MFMA of block j in program order (sched_barrier pins it): every stretch of the
+        // instruction stream keeps both the matrix pipe and the VALU busy.  Two accumulator sets alternate by block parity.
+        f32x16 acc2[2][kNT];
+#pragma unroll
+        for (int q2 = 0; q2 < 2; q2++)
+#pragma unroll
+          for (int n = 0; n < kNT; n++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc2[q2][n][r] = 0.0f;
+        float mxv[kNT] = {0.0f, 0.0f}, smv[kNT] = {1.0f, 1.0f}, tm[8];
+        f32x2 ex[8];
+        constexpr int kChunks = 27;
+        // chunk c of the epilogue of the block held in pv; results are bit-identical to reg_max / reg_expsum_fast / finish
+        auto epi = [&](int c, const f32x16 (&pv)[kNT], int column) {
+#ifdef BF16_DIAG_NO_EPILOGUE
+          if (c == 26) { smv[0] = pv[0][0] + pv[1][15]; stage[(32 * h + col) * 33 + column] = smv[0]; }
+#else
+          const int n = (c < 3 || (c >= 6 && c < 16)) ? 0 : 1;           // tile the chunk works on
+          if (c == 0 || c == 3) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) tm[r] = fmaxf(pv[n][r], pv[n][r + 8]);
+          } else if (c == 1 || c == 4) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) tm[r] = fmaxf(tm[r], tm[r + 4]);
+            tm[0] = fmaxf(tm[0], tm[2]); tm[1] = fmaxf(tm[1], tm[3]);
+            tm[0] = fmaxf(tm[0], tm[1]);
+          } else if (c == 2 || c == 5) {
+            mxv[n] = fmaxf(tm[0], swap32(tm[0], h));
+          } else if ((c >= 6 && c < 14) || (c >= 16 && c < 24)) {
+            const int g = c < 14 ? c - 6 : c - 16;
+            const f32x2 x = {pv[n][2 * g], pv[n][2 * g + 1]};
+            const f32x2 mv2 = {mxv[n], mxv[n]};
+            const f32x2 lv = {l2e_s, l2e_s};
+            const f32x2 arg = (x - mv2) * lv;
+            ex[g].x = __builtin_amdgcn_exp2f(arg.x);
+            ex[g].y = __builtin_amdgcn_exp2f(arg.y);
+          } else if (c == 14 || c == 24) {
+#pragma unroll
+            for (int w = 1; w < 8; w <<= 1)
+#pragma unroll
+              for (int r = 0; r + w < 8; r += 2 * w) ex[r] += ex[r + w];
+          } else if (c == 15 || c == 25) {
+            const float sv = ex[0].x + ex[0].y;
+            smv[n] = sv + swap32(sv, h);
+          } else if (c == 26) {
+            stage[(32 * h + col) * 33 + column] = finish((h ? mxv[1] : mxv[0]) * inv_s, h ? smv[1] : smv[0]);
+          }
+#endif
+        };
+        auto flush = [&](int jdone) {                        // columns [jdone − jdone%32, jdone] of the staged scores → HBM
+          const int jj = jdone & 31;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          const int j0 = jdone - jj, cnt = jj + 1;
+#pragma unroll 4
+          for (int i = 0; i < 32; i++) {
+            const int r = h + 2 * i, t = t_base + r;
+            if (col < cnt && t < T) __builtin_nontemporal_store(stage[r * 33 + col], &out[(size_t)t * P + j0 + col]);
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+        };
         for (int c0 = 0; c0 < n_single; c0 += kBlkCache) {
         const int c1 = min(n_single, c0 + kBlkCache);
         __syncthreads();                                   // previous chunk's table is no longer read
@@ -969,23 +1036,24 @@ __global__ __launch_bounds__(256, 2) void gmm_split_single_kernel(GmmParams p) {
         fetch(block_of(c0), 0);
         landed();
         __syncthreads();
-        for (int j = c0; j < c1; j++) {
-          const int buf = (j - c0) & 1;
+        // one trip: block j (parity par: c0 is even, so par is also the LDS buffer) is multiplied into acc2[par] while the
+        // epilogue of block j-1 runs out of acc2[par ^ 1]
+        auto trip = [&](auto par_c, int j) {
+          constexpr int par = decltype(par_c)::value;
+          constexpr int buf = par;
 #ifndef BF16_DIAG_NO_FETCH   // timing-only builds (tools/gmm_ablation.sh): results are wrong by construction
           fetch(block_of(j + 1), buf ^ 1);                 // block j+1 (the chunk's last trip re-fetches its last block: harmless)
 #endif
           if (active && j < n_mine) {
-            f32x16 acc[kNT];
-            {
-              f32x16 init;
+            f32x16 (&cur)[kNT] = acc2[par];
+            const f32x16 (&prev)[kNT] = acc2[par ^ 1];
+            f32x16 init;
 #pragma unroll
-              for (int qq = 0; qq < 4; qq++) {
-                const float4 gq = *reinterpret_cast<const float4 *>(&gc_lds[buf][8 * qq + 4 * h]);
-                init[4 * qq] = gq.x; init[4 * qq + 1] = gq.y; init[4 * qq + 2] = gq.z; init[4 * qq + 3] = gq.w;
-              }
-#pragma unroll
-              for (int n = 0; n < kNT; n++) acc[n] = init;
+            for (int qq = 0; qq < 4; qq++) {
+              const float4 gq = *reinterpret_cast<const float4 *>(&gc_lds[buf][8 * qq + 4 * h]);
+              init[4 * qq] = gq.x; init[4 * qq + 1] = gq.y; init[4 * qq + 2] = gq.z; init[4 * qq + 3] = gq.w;
             }
+            const int column = j == 0 ? 32 : ((j - 1) & 31); // the first block of an item has no predecessor: padding column
             // operand pieces of step s+1 are read from LDS while step s is multiplied
             auto read_a = [&](int s, op8 (&a)[kPieces]) {
 #pragma unroll
@@ -994,65 +1062,61 @@ __global__ __launch_bounds__(256, 2) void gmm_split_single_kernel(GmmParams p) {
             };
             op8 a_cur[kPieces], a_nxt[kPieces];
             read_a(0, a_cur);
+            // six (three) products per 16 k-values, smallest terms first; the two tiles alternate so that consecutive MFMAs
+            // never wait on each other's accumulator
+            constexpr int kProd = kHalf ? 3 : 6;
+            constexpr int kStride = (kSteps * kProd * kNT) / 30;   // MFMA slots per epilogue chunk
+            constexpr int pa[6] = {kHalf ? 1 : 2, kHalf ? 0 : 1, 0, 1, 0, 0}, pb[6] = {0, 1, kHalf ? 0 : 2, 0, 1, 0};
 #pragma unroll
             for (int s = 0; s < kSteps; s++) {
               if (s + 1 < kSteps) read_a(s + 1, a_nxt);
-              // six (three) products per 16 k-values, smallest terms first; the two tiles alternate so that consecutive MFMAs
-              // never wait on each other's accumulator
-              constexpr int kProd = kHalf ? 3 : 6;
-              constexpr int pa[6] = {kHalf ? 1 : 2, kHalf ? 0 : 1, 0, 1, 0, 0}, pb[6] = {0, 1, kHalf ? 0 : 2, 0, 1, 0};
 #pragma unroll
               for (int t6 = 0; t6 < kProd; t6++)
 #pragma unroll
                 for (int n = 0; n < kNT; n++) {
+                  const f32x16 &cin = (s == 0 && t6 == 0) ? init : cur[n];
                   if constexpr (kHalf)
-                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[pa[t6]], b[n][s][pb[t6]], acc[n], 0, 0, 0);
+                    cur[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[pa[t6]], b[n][s][pb[t6]], cin, 0, 0, 0);
                   else
-                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[pa[t6]], b[n][s][pb[t6]], acc[n], 0, 0, 0);
+                    cur[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[pa[t6]], b[n][s][pb[t6]], cin, 0, 0, 0);
+                  const int slot = (s * kProd + t6) * kNT + n;
+                  if (slot % kStride == 0 && slot / kStride < kChunks) epi(slot / kStride, prev, column);
+#ifndef BF16_DIAG_NO_INTERLEAVE
+                  __builtin_amdgcn_sched_barrier(0);
+#endif
                 }
 #pragma unroll
               for (int qq = 0; qq < kPieces; qq++) a_cur[qq] = a_nxt[qq];
             }
-            // ---- log-sum-exp epilogue and LDS-staged, coalesced score stores: as in score_tile
-            float mx[kNT], sum[kNT];
-#pragma unroll
-            for (int n = 0; n < kNT; n++) {
-#ifdef BF16_DIAG_NO_EPILOGUE
-              mx[n] = acc[n][0] + acc[n][15]; sum[n] = 1.0f;
-#else
-              float m = reg_max<0, 16>(acc[n]);
-              m = fmaxf(m, swap32(m, h));
-              float sv = reg_expsum_fast(acc[n], m, l2e_s);
-              sv += swap32(sv, h);
-              mx[n] = m * inv_s; sum[n] = sv;
-#endif
-            }
-            const float v = finish(h ? mx[1] : mx[0], h ? sum[1] : sum[0]);
-            const int jj = j & 31;                         // kBlkCache is a multiple of 32: chunks keep the 32-column phase
-            stage[(32 * h + col) * 33 + jj] = v;
 #ifdef BF16_DIAG_NO_FLUSH
-            if (v == 12345.678f) {
+            if (smv[0] == 12345.678f) flush(j - 1);          // timing-only build: keeps the staged values alive
 #else
-            if (jj == 31 || j == n_mine - 1) {
+            if (j > 0 && ((j - 1) & 31) == 31) flush(j - 1);
 #endif
-              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-              __builtin_amdgcn_wave_barrier();
-              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-              const int j0 = j - jj, cnt = jj + 1;
-#pragma unroll 4
-              for (int i = 0; i < 32; i++) {
-                const int r = h + 2 * i, t = t_base + r;
-                if (col < cnt && t < T) __builtin_nontemporal_store(stage[r * 33 + col], &out[(size_t)t * P + j0 + col]);
-              }
-              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-              __builtin_amdgcn_wave_barrier();
-            }
           }
           landed();
 #ifndef BF16_DIAG_NO_BARRIER
-          __syncthreads();                               // block j+1 is in place; everybody is done with block j
+          __syncthreads();                                 // block j+1 is in place; everybody is done with block j
 #endif
+        };
+        for (int j = c0; j < c1; j += 2) {
+          trip(std::integral_constant<int, 0>{}, j);
+          if (j + 1 < c1) trip(std::integral_constant<int, 1>{}, j + 1);
         }
+        }
+        if (active && n_mine > 0) {                          // drain: the last block's epilogue and the open columns
+          const int jp = n_mine - 1;
+          if (jp & 1) {
+#pragma unroll
+            for (int c = 0; c < kChunks; c++) epi(c, acc2[1], jp & 31);
+          } else {
+#pragma unroll
+            for (int c = 0; c < kChunks; c++) epi(c, acc2[0], jp & 31);
+          }
+#ifdef BF16_DIAG_NO_FLUSH
+          if (smv[0] == 12345.678f)
+#endif
+          flush(jp);
         }
       }
     }

@@ -4,7 +4,7 @@
 # only stage_ms_per_step.gmm matters.    bash tools/gmm_ablation.sh  (through gpurun, from the repo root)
 set -eo pipefail
 run() {
-  MFA_GMM_DIAG=1 python bench.py --no-cpu-baseline --steps 3 2>>gpurun_out/ablation.err | python -c "
+  MFA_GMM_DIAG=1 python bench.py --no-cpu-baseline --steps 3 $BENCH_ARGS 2>>gpurun_out/ablation.err | python -c "
 import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', d['stage_ms_per_step']['gmm'])"
 }
 build() { MFA_HIPCC_FLAGS="$1" python -c "
@@ -13,7 +13,7 @@ from montreal_forced_aligner_amd import _lib; _lib.build_native(force=True)" 2>/
 if [ "$1" = "bf16" ]; then
   export MFA_GMM_BF16=1
   run full-bf16
-  for f in -DBF16_DIAG_NO_EPILOGUE -DBF16_DIAG_NO_FETCH -DBF16_DIAG_NO_FLUSH -DBF16_DIAG_NO_BARRIER \
+  for f in -DBF16_DIAG_NO_EPILOGUE -DBF16_DIAG_NO_FETCH -DBF16_DIAG_NO_FLUSH -DBF16_DIAG_NO_BARRIER -DBF16_DIAG_NO_INTERLEAVE \
            "-DBF16_DIAG_NO_EPILOGUE -DBF16_DIAG_NO_FETCH -DBF16_DIAG_NO_FLUSH" \
            "-DBF16_DIAG_NO_EPILOGUE -DBF16_DIAG_NO_FETCH -DBF16_DIAG_NO_FLUSH -DBF16_DIAG_NO_BARRIER"; do
     build "$f"; run "$f"

@@ -19,7 +19,10 @@ def rows(sub, suffix):
 
 
 def short(name):
-    for k in ("gmm_bf16_single_kernel", "gmm_bf16_kernel", "gmm_kernel", "viterbi_kernel", "mfcc_kernel", "feats_lda_kernel", "feats_kernel", "cmvn_utt_kernel", "cmvn_spk_kernel",
+    if "gmm_split_single_kernel" in name:   # <steps, pieces>: 2 = f16×2 pass, 3 = bf16×3 pass (or its redo sweep)
+        pieces = name.split("gmm_split_single_kernel<")[-1].split(">")[0].replace(" ", "").split(",")[-1] if "<" in name else "?"
+        return {"2": "gmm_split_single_kernel_f16", "3": "gmm_split_single_kernel_bf16"}.get(pieces, "gmm_split_single_kernel")
+    for k in ("gmm_split_single_kernel", "gmm_bf16_single_kernel", "gmm_bf16_kernel", "gmm_kernel", "viterbi_kernel", "mfcc_kernel", "feats_lda_kernel", "feats_kernel", "cmvn_utt_kernel", "cmvn_spk_kernel",
               "arcnext_kernel", "collect_pending_kernel", "finalize_pending_kernel", "gmm_max_first_frame_kernel"):
         if k in name:
             return k
