@@ -108,6 +108,10 @@ def lib() -> C.CDLL:
                 f"{_SO} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(the alignment path has no CPU fallback)"
             )
+        # torch first: it brings its own HIP runtime, and the process must end up with ONE (device buffers and streams
+        # are shared with torch); loading libmfa_hip.so first would bind it to a second copy of libamdhip64
+        import torch  # noqa: F401
+
         try:
             handle = C.CDLL(str(_SO))
         except OSError as e:  # e.g. no ROCm runtime on this machine

@@ -51,6 +51,7 @@ struct GmmParams {
   float acc_scale_inv;   // 1 / S
   int *redo;         // [n_utt × tiles] tiles the f16 kernel declined (scaled feature outside the f16 range)
   int redo_mode;     // 0: score everything; 2: score only the tiles flagged in redo
+  int *redo_count;   // number of flagged tiles (device scalar, zeroed per launch): the redo sweep returns at once when 0
   const float *feats; const int64_t *frame_off;
   const int32_t *pdf_list; const int64_t *pdf_off; const int32_t *class_counts; const int64_t *ll_off;
   unsigned long long *trace;   // debug (mfa_debug_gmm_trace): per workgroup {start, end, hw id, blocks} or NULL
@@ -860,6 +861,7 @@ __global__ __launch_bounds__(256, 2) void gmm_split_single_kernel(GmmParams p) {
   __shared__ int blk_lds[kBlkCache];                  // loads per pdf must not sit in the block loop)
   __shared__ int s_item;
   float *stage = stage_all[wave];
+  if (!kHalf && p.redo_mode == 2 && *p.redo_count == 0) return;   // uniform: the f16 pass declined nothing
   const int my_xcd = (int)(__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u);
   for (int hop = 0; hop < 8; hop++) {
     const int q = (my_xcd + hop) & 7;
@@ -935,7 +937,7 @@ __global__ __launch_bounds__(256, 2) void gmm_split_single_kernel(GmmParams p) {
         }
         if constexpr (kHalf) {
           if (__syncthreads_or(bad)) {                     // uniform: the whole tile goes to the bf16×3 pass
-            if (threadIdx.x == 0) p.redo[(size_t)utt * p.tiles + tl] = 1;
+            if (threadIdx.x == 0) { p.redo[(size_t)utt * p.tiles + tl] = 1; atomicAdd(p.redo_count, 1); }
             continue;
           }
         }
@@ -1443,7 +1445,7 @@ MFA_API int mfa_gmm_score_batch(mfa_ctx *c, const float *d_feats, const int64_t 
     dim3 grid((unsigned)std::max<int64_t>(wgs, 1));
     const char *bf = getenv("MFA_GMM_BF16");
     p.wb = (const uint4 *)c->d_wb;
-    p.wh = nullptr; p.gch = nullptr; p.fscale = nullptr; p.acc_scale_inv = 1.0f; p.redo = nullptr; p.redo_mode = 0;
+    p.wh = nullptr; p.gch = nullptr; p.fscale = nullptr; p.acc_scale_inv = 1.0f; p.redo = nullptr; p.redo_mode = 0; p.redo_count = nullptr;
     p.skip_single = 0;
     if (!(bf && bf[0] == '0') && c->d_wb) {   // default on; MFA_GMM_BF16=0 keeps every class on the f32 kernel
       // class 0 on the bf16×3 kernel, then the f32 kernel for whatever other slot classes the lists hold (second set of
@@ -1461,7 +1463,7 @@ MFA_API int mfa_gmm_score_batch(mfa_ctx *c, const float *d_feats, const int64_t 
         MFA_HIP_CHECK(c, hipMemsetAsync(c->d_gmm_redo, 0, items * sizeof(int), c->stream));
         p.wh = (const uint4 *)c->d_wh; p.gch = c->d_gch; p.fscale = c->d_fscale;
         p.acc_scale_inv = 1.0f / c->gmm_acc_scale;
-        p.redo = c->d_gmm_redo; p.redo_mode = 0;
+        p.redo = c->d_gmm_redo; p.redo_mode = 0; p.redo_count = c->d_gmm_queue + 51;
         if (m8 == 10) hipLaunchKernelGGL((gmm_split_single_kernel<5, 2>), grid, dim3(256), 0, c->stream, p);
         else hipLaunchKernelGGL((gmm_split_single_kernel<6, 2>), grid, dim3(256), 0, c->stream, p);
         p.redo_mode = 2;
