@@ -359,6 +359,29 @@ def test_gmm_bf16_split_kernel_within_float32_rounding(engine, dim, monkeypatch)
     assert changed > 0   # the bf16 path really ran
 
 
+def test_gmm_real_mixture_model_default_path(engine, fx):
+    """The reference's own fixture model (80 pdfs, 1..26 Gaussians) on features computed from its fixture audio, scored
+    the way a user gets it (f16×2 for the 17+ Gaussian pdfs, f32 for the rest): every cell within 1e-4 of the oracle
+    (north_star: 1e-3), and the same cells again within 1e-4 when the features are 40× out of the model's range, where
+    every tile is declined by the f16 pass and scored by the bf16×3 pass."""
+    am = fx.g2p_am
+    mf = [O.mfcc(s.astype(np.float32), O.default_mfcc_opts(snip_edges=1)) for s in _segments(fx)[:3]]
+    feats = [O.affine(O.splice(O.cmvn_apply(O.cmvn_stats([m]), m)), fx.g2p_lda) for m in mf]
+    lists = [np.arange(am.num_pdfs, dtype=np.int32)] * 3
+    n_gauss = np.diff(am.pdf_offsets)
+    assert (n_gauss > 16).any() and n_gauss.max() <= 32
+    for scale_up, tol in ((1.0, 1e-4), (40.0, None)):
+        fs = [(f * scale_up).astype(np.float32) for f in feats]
+        got, sorted_lists = _score(engine, am, fs, lists)
+        for u in range(3):
+            ref = O.gmm_loglikes(fs[u], am.gconsts, am.means_invvars, am.inv_vars, am.pdf_offsets, sorted_lists[u])
+            err = np.abs(got[u] - ref)
+            if tol is not None:
+                assert err.max() < tol, (u, float(err.max()), float(np.abs(ref).max()))
+            else:   # scores of magnitude 1e5: float32 spacing is 8e-3 there
+                assert (err / np.maximum(1.0, np.abs(ref))).max() < 1e-6, (u, float((err / np.abs(ref)).max()))
+
+
 @pytest.mark.parametrize("dim", [40, 45])
 def test_gmm_f16_split_kernel_within_tolerance_and_range_fallback(engine, dim, monkeypatch):
     """Default scoring of a model without multi-block pdfs: the 32-row class goes through the f16×2 MFMA kernel (three
