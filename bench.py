@@ -38,7 +38,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=2048, help="utterances per step per GPU")
+    ap.add_argument("--batch", type=int, default=4096, help="utterances per step per GPU")
     ap.add_argument("--pool", type=int, default=128, help="distinct synthetic utterances generated per rank")
     ap.add_argument("--workload", choices=["triphone", "mono"], default="triphone")
     ap.add_argument("--train-utts", type=int, default=120)
@@ -307,10 +307,11 @@ def main():
     achieved = flops_per_launch / (gmm_ms * 1e-3) / 1e12 if gmm_ms > 0 else 0.0
     # fabric-side bytes of one scoring launch: PMC counters cannot be collected from inside this process, so the figure
     # is the one measured by tools/profile_round.sh (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this very
-    # command) and committed under profiles/; it applies to the default triphone workload at batch 2048 only
+    # command) and committed under profiles/; it applies to the triphone workload at the batch size in the file's name
     traffic, traffic_src = None, None
-    prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_profile_summary_triphone_b2048.json")
-    if not mono and B == 2048 and n_streams == 1 and args.reachability and os.path.exists(prof):
+    prof_name = f"r01_profile_summary_triphone_b{B}.json"
+    prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", prof_name)
+    if not mono and n_streams == 1 and args.reachability and os.path.exists(prof):
         try:
             with open(prof) as fh:
                 ks_ = json.load(fh)["kernels"]
@@ -321,7 +322,7 @@ def main():
                 else:
                     d_ = ks_["gmm_split_single_kernel_f16"]["derived"]
             traffic = float(d_["fetch_bytes_per_dispatch_raw"] + d_["write_bytes_per_dispatch"])
-            traffic_src = ("profiles/r01_profile_summary_triphone_b2048.json: (FETCH_SIZE + WRITE_SIZE) KiB x 1024 per "
+            traffic_src = (f"profiles/{prof_name}: (FETCH_SIZE + WRITE_SIZE) KiB x 1024 per "
                            "launch, FETCH_SIZE uncorrected (gfx950 may tally 128-B reads at 64 B: up to 2x more)")
         except (KeyError, ValueError):
             pass
