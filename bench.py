@@ -238,6 +238,24 @@ def main():
         if world > 1:
             dist.barrier()
 
+    if os.environ.get("MFA_BENCH_OVERLAP_PROBE") and n_streams == 2:  # diagnostic: can the decoder of one half-batch
+        pA, pB = pipes                                                   # share the chip with the front end of the other?
+        pipe.step()
+        torch.cuda.synchronize()
+
+        def timed(fn):
+            torch.cuda.synchronize()
+            t_ = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t_) * 1e3
+
+        for _ in range(2):
+            t_v, t_f, t_g = timed(pA.decode), timed(pB.front), timed(pB.score)
+            t_vf = timed(lambda: (pA.decode(), pB.front()))
+            t_vg = timed(lambda: (pA.decode(), pB.score()))
+            log(rank, f"overlap probe: decode {t_v:.2f} ms, front {t_f:.2f} ms, score {t_g:.2f} ms; decode||front {t_vf:.2f} ms, "
+                      f"decode||score {t_vg:.2f} ms")
     if os.environ.get("MFA_BENCH_FILL"):  # diagnostic: how much of the score matrix does one step write?
         for p_ in pipes:
             p_.loglikes.zero_()

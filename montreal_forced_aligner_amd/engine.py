@@ -371,7 +371,13 @@ class Pipeline:
         self.audio_seconds = float(np.diff(sample_off).sum() / e.mfcc_opts.sample_frequency)
 
     def step(self) -> None:
-        e, L, c = self.e, self.e.lib, self.e.ctx
+        self.front()
+        self.score()
+        self.decode()
+
+    def front(self) -> None:
+        """PCM → MFCC → CMVN statistics → final features (three launches on the engine's stream)."""
+        L, c = self.e.lib, self.e.ctx
         check(c, L.mfa_mfcc_batch(c, _ptr(self.pcm), _ptr(self.d_sample_off), _ptr(self.d_frame_off), self.n_utt,
                                   self.max_frames, _ptr(self.mfcc)), "mfa_mfcc_batch")
         check(c, L.mfa_cmvn_stats(c, _ptr(self.mfcc), _ptr(self.d_frame_off), self.n_utt, self.num_ceps, _ptr(self.d_spk_off),
@@ -384,11 +390,18 @@ class Pipeline:
                                    _ptr(self.d_utt2spk), _ptr(self.cmvn), 1, self.ctx_frames, _ptr(self.lda),
                                    int(self.lda.shape[0]), int(self.lda.shape[1]), _ptr(self.fmllr), _ptr(self.feats))
         check(c, rc, "mfa_feats_batch")
-        g = self.graphs
+
+    def score(self) -> None:
+        """features → GMM log-likelihoods of every utterance's pdf list."""
+        L, c, g = self.e.lib, self.e.ctx, self.graphs
         check(c, L.mfa_gmm_score_batch(c, _ptr(self.feats), _ptr(self.d_frame_off), self.n_utt, self.max_frames,
                                        _ptr(g.pdf_list), _ptr(g.pdf_off), _ptr(g.class_counts),
                                        _ptr(g.pdf_first_frame) if self.reachability else None, _ptr(self.d_ll_off),
                                        _ptr(self.loglikes)), "mfa_gmm_score_batch")
+
+    def decode(self) -> None:
+        """log-likelihoods + graphs → alignments (beam Viterbi, retry beam for the utterances that need it)."""
+        L, c, g = self.e.lib, self.e.ctx, self.graphs
         check(c, L.mfa_align_batch(c, C.byref(self.gstruct), _ptr(self.loglikes), _ptr(self.d_ll_off), _ptr(self.d_ll_cols),
                                    _ptr(self.d_frame_off), self.total_frames, g.total_arcs, g.max_states, g.max_arcs, C.byref(self.opts), _ptr(self.ali),
                                    _ptr(self.words), _ptr(self.n_words), _ptr(self.like), None, _ptr(self.status)),
