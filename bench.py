@@ -10,7 +10,8 @@ N > 1: one process per GPU (torch.distributed.run); utterances are sharded by sp
 per-GPU batch (weak scaling), no data-path collective; ranks meet only at the timing barriers.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     — dominant kernel (GMM scoring, f32 MFMA): algorithmic TFLOP/s measured with HIP events on the launch stream
+  roofline     — dominant kernel (GMM scoring on the matrix pipe: f16x2 split by default, bf16x3 with MFA_GMM_F16=0, f32 with
+                 MFA_GMM_BF16=0): executed MFMA TFLOP/s measured with HIP events on the launch stream
   cpu_baseline — the CPU oracle (a port, not stock Kaldi) timed on a bounded sample of the same workload.
 """
 from __future__ import annotations
