@@ -55,7 +55,7 @@ struct GmmParams {
   const float *feats; const int64_t *frame_off;
   const int32_t *pdf_list; const int64_t *pdf_off; const int32_t *class_counts; const int64_t *ll_off;
   unsigned long long *trace;   // debug (mfa_debug_gmm_trace): per workgroup {start, end, hw id, blocks} or NULL
-  int skip_single;             // 1: the 32-row classes (0 and 1) are left to gmm_bf16_kernel
+  int skip_single;             // 1: the 32-row classes (0 and 1) are left to the split kernels; 2: the 16/8/4-row classes too
   int ff_bias;                 // debug (MFA_GMM_FF_BIAS): added to the tile's last frame before the reachability test
   const int32_t *first_frame;  // parallel to pdf_list (ascending inside each class) or NULL: see mfa_gmm_score_batch
   float *out;
@@ -253,6 +253,7 @@ __device__ __forceinline__ void score_tile(const GmmParams &p, int utt, int t_ba
   float *out = p.out + p.ll_off[utt];
   // skip_single: the 32-row pdfs (single- and multi-block) are scored by gmm_bf16_kernel; only the small-slot classes are
   // left for this launch
+  if (p.skip_single >= 2) { need[2] = 0; need[3] = 0; need[4] = 0; }   // slots 16 / 8 / 4 went to gmm_split_small_kernel
   if (p.skip_single && need[2] + need[3] + need[4] + need[5] == 0) return;
 
   Tile<M8, kNT> tile;
@@ -1125,6 +1126,267 @@ __global__ __launch_bounds__(256, 2) void gmm_split_single_kernel(GmmParams p) {
   }
 }
 
+// The same kernel for the small-slot classes: pdfs of at most kSlot ∈ {16, 8, 4} Gaussians occupy kSlot consecutive model
+// rows (pad rows: zero weights, gconst −1e30), and 32 / kSlot of them — whichever the utterance's list puts next to each
+// other — are gathered into one virtual 32-row block: global_load_lds takes a per-lane source address, so the copy costs
+// what the contiguous one does.  The MFMAs are those of the 32-row class; the log-sum-exp runs over the kSlot rows of each
+// pdf (accumulator registers [8k, 8k+8) of both half-waves for kSlot = 16, [4k, 4k+4) for 8, [4i, 4i+4) of ONE half-wave
+// for 4) and a block yields 32 / kSlot score columns.  Not software-pipelined (the epilogues differ per class and these
+// classes are a minority of the rows of a 32-Gaussian model; for MFA's released models they are the majority — next step).
+template <int kSteps, int kPieces, int kSlot>
+__global__ __launch_bounds__(256, 2) void gmm_split_small_kernel(GmmParams p) {
+  constexpr int kNT = 2, kWaves = 4, kFramesPerWave = 64, kFramesPerTile = 256;
+  constexpr bool kHalf = kPieces == 2;
+  using op8 = std::conditional_t<kHalf, f16x8, bf16x8>;
+  constexpr int kUnits = kSteps * kPieces * 2 * 32;    // 16-byte units per block
+  constexpr int kLoads = (kUnits + 255) / 256;         // units each thread moves per block
+  const int lane0 = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ float stage_all[kWaves][64 * 33];
+  __shared__ uint4 a_lds[2][kUnits];
+  __shared__ __attribute__((aligned(16))) float gc_lds[2][64];
+  constexpr int kPdfs = 32 / kSlot;                   // pdfs per virtual block = score columns per block
+  constexpr int kCls = kSlot == 16 ? 2 : kSlot == 8 ? 3 : 4;   // position of this class in class_counts
+  constexpr int kBlkCache = 1024;                     // pdf → first model row, staged per item (two dependent global loads
+  __shared__ int blk_lds[kBlkCache];                  // per pdf must not sit in the block loop); a multiple of 32 pdfs
+  __shared__ int s_item;
+  float *stage = stage_all[wave];
+  if (!kHalf && p.redo_mode == 2 && *p.redo_count == 0) return;   // uniform: the f16 pass declined nothing
+  const int my_xcd = (int)(__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u);
+  for (int hop = 0; hop < 8; hop++) {
+    const int q = (my_xcd + hop) & 7;
+    const int n_items = ((p.n_utt - q + 7) >> 3) * p.tiles;
+    for (;;) {
+      __syncthreads();
+      if (threadIdx.x == 0) s_item = atomicAdd(&p.queue[q], 1);
+      __syncthreads();
+      const int item = s_item;
+      if (item >= n_items) break;
+      int lane = lane0;                                // opaque per item: keeps lane-dependent addresses out of long-lived registers
+      asm volatile("" : "+v"(lane));
+      const int col = lane & 31, h = lane >> 5;
+      const int utt = (item / p.tiles) * 8 + q, tl = p.tiles - 1 - item % p.tiles;
+      const int64_t f0 = p.frame_off[utt];
+      const int T = (int)(p.frame_off[utt + 1] - f0);
+      if (tl * kFramesPerTile >= T) continue;          // uniform over the workgroup
+      if (!kHalf && p.redo_mode == 2 && p.redo[(size_t)utt * p.tiles + tl] == 0) continue;   // only what the f16 pass left
+      const int t_base = (tl * kWaves + wave) * kFramesPerWave;
+      const bool active = t_base < T;                  // a wavefront past the end still helps move blocks and joins barriers
+      const int64_t l0 = p.pdf_off[utt];
+      const int P = (int)(p.pdf_off[utt + 1] - l0);
+      const int32_t *list = p.pdf_list + l0;
+      const int32_t *cc6 = p.class_counts + (size_t)utt * 6;
+      int base = cc6[0] + cc6[1];                      // columns of the classes in front of this one
+#pragma unroll
+      for (int q3 = 2; q3 < kCls; q3++) base += cc6[q3];
+      const int n_all = cc6[kCls];
+      if (n_all == 0) continue;                        // uniform
+      // n_single: pdfs the tile's LAST frame can be asked for — the prefix the workgroup walks together (block copies and
+      // barriers are collective).  n_mine: the shorter prefix this wavefront's own 64 frames can be asked for; beyond it
+      // the wavefront only helps with the copies.
+      int n_single = n_all, n_mine = n_all;
+      if (p.first_frame) {
+        const int t_last = min(T, (tl + 1) * kFramesPerTile) - 1 + p.ff_bias;
+        const int t_mine = min(T, t_base + kFramesPerWave) - 1 + p.ff_bias;
+        n_single = 0; n_mine = 0;
+        for (int i0 = 0; i0 < n_all; i0 += 64) {
+          const int i = i0 + lane;
+          const int ff = i < n_all ? p.first_frame[l0 + base + i] : 0x7fffffff;
+          n_single += __popcll(__ballot(ff <= t_last));
+          n_mine += __popcll(__ballot(ff <= t_mine));
+        }
+      }
+      float *out = p.out + p.ll_off[utt];
+      if (n_single > 0) {
+        // ---- x̃ = [x, x²] of this wavefront's 64 frames, split into bf16 triples: b[tile][step][piece], lane (frame, half)
+        op8 b[kNT][kSteps][kPieces];
+        bool bad = false;                                  // kHalf: a scaled feature outside the f16 range (or NaN)
+#pragma unroll
+        for (int n = 0; n < kNT; n++) {
+          int t = t_base + 32 * n + col;
+          t = t < T ? t : T - 1;
+          t = t < 0 ? 0 : t;
+          const float *x = p.feats + (f0 + t) * p.dim;
+#pragma unroll
+          for (int s = 0; s < kSteps; s++) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+              const int k = 16 * s + 8 * h + e;
+              const int idx = k < p.dim ? k : (k < 2 * p.dim ? k - p.dim : 0);
+              const float xv = x[idx];
+              const float v = k < p.dim ? xv : (k < 2 * p.dim ? xv * xv : 0.0f);
+              if constexpr (kHalf) {
+                const float sv = v * p.fscale[k];
+                bad |= !(fabsf(sv) <= 65000.0f);
+                const _Float16 v1 = (_Float16)sv;
+                b[n][s][0][e] = v1; b[n][s][1][e] = (_Float16)(sv - (float)v1);
+              } else {
+                const __bf16 v1 = (__bf16)v;
+                const float r1 = v - (float)v1;
+                const __bf16 v2 = (__bf16)r1;
+                const float r2 = r1 - (float)v2;
+                b[n][s][0][e] = v1; b[n][s][1][e] = v2; b[n][s][2][e] = (__bf16)r2;
+              }
+            }
+          }
+        }
+        if constexpr (kHalf) {
+          if (__syncthreads_or(bad)) {                     // uniform: the whole tile goes to the bf16×3 pass
+            if (threadIdx.x == 0) { p.redo[(size_t)utt * p.tiles + tl] = 1; atomicAdd(p.redo_count, 1); }
+            continue;
+          }
+        }
+        const uint4 *wsrc = kHalf ? p.wh : p.wb;
+        const float *gsrc = kHalf ? p.gch : p.gc;
+        const float inv_s = kHalf ? p.acc_scale_inv : 1.0f;
+        const float l2e_s = 1.44269504088896341f * inv_s;  // inv_s is a power of two: (x·inv_s)·log2e == x·(log2e·inv_s)
+        // Block copy global → LDS without a register stop (global_load_lds_dwordx4: every lane's 16 bytes land at a
+        // wavefront-uniform LDS base + 16·lane, which is exactly the linear unit order of a block).
+        typedef __attribute__((address_space(1))) const void *gptr_t;
+        typedef __attribute__((address_space(3))) void *lptr_t;
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+        // virtual block jb = pdfs [jb·kPdfs, (jb+1)·kPdfs) of the class; lane ↔ row ρ = lane mod 32 of every 32-unit group
+        const int rho = lane & 31, my_k = rho / kSlot, my_r = rho % kSlot;
+        auto fetch = [&](int jb, int buf, int c0, int c1) {
+          const int idx = jb * kPdfs + my_k;               // pdf this lane's row belongs to (class-relative)
+          const int row = idx < c1 ? blk_lds[idx - c0] + my_r : p.num_rows;   // past the needed prefix: the dummy row
+          const uint4 *src = wsrc + (size_t)(row >> 5) * kUnits + (row & 31);
+#pragma unroll
+          for (int i = 0; i < kLoads; i++) {
+            const int u0 = 64 * wave_u + 256 * i;        // first unit this wavefront moves in round i (uniform)
+            if (u0 < kUnits)
+              __builtin_amdgcn_global_load_lds((gptr_t)(src + ((u0 + lane) & ~31)), (lptr_t)&a_lds[buf][u0], 16, 0, 0);
+          }
+          if (wave_u == 0)
+            __builtin_amdgcn_global_load_lds((gptr_t)(gsrc + row), (lptr_t)&gc_lds[buf][0], 4, 0, 0);
+        };
+        auto landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+        // ---- block loop: multiply, reduce per pdf, stage one column per pdf, flush every 32 columns
+        const int nb_single = (n_single + kPdfs - 1) / kPdfs, nb_mine = (n_mine + kPdfs - 1) / kPdfs;
+        auto flush = [&](int col_last) {                     // columns [col_last − col_last%32, col_last] → HBM
+          const int jj = col_last & 31;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          const int j0 = col_last - jj, cnt = min(jj + 1, n_mine - j0);
+#pragma unroll 4
+          for (int i = 0; i < 32; i++) {
+            const int r = h + 2 * i, t = t_base + r;
+            if (col < cnt && t < T) __builtin_nontemporal_store(stage[r * 33 + col], &out[(size_t)t * P + base + j0 + col]);
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+        };
+        // Σ exp(x − m) over `cnt` registers from r0, pairwise; m: their maximum
+        auto group_max = [&](const f32x16 &v, int r0, int cnt) {
+          float m = v[r0];
+#pragma unroll
+          for (int r = 1; r < cnt; r++) m = fmaxf(m, v[r0 + r]);
+          return m;
+        };
+        auto group_expsum = [&](const f32x16 &v, int r0, int cnt, float m) {
+          float e[8];
+#pragma unroll
+          for (int r = 0; r < cnt; r++) e[r] = __builtin_amdgcn_exp2f((v[r0 + r] - m) * l2e_s);
+#pragma unroll
+          for (int w = 1; w < cnt; w <<= 1)
+#pragma unroll
+            for (int r = 0; r + w < cnt; r += 2 * w) e[r] += e[r + w];
+          return e[0];
+        };
+        for (int c0 = 0; c0 < n_single; c0 += kBlkCache) {
+        const int c1 = min(n_single, c0 + kBlkCache);
+        __syncthreads();                                   // previous chunk's table is no longer read
+        for (int i = c0 + threadIdx.x; i < c1; i += 256) blk_lds[i - c0] = p.row0[list[base + i]];
+        __syncthreads();
+        const int jb0 = c0 / kPdfs, jb1 = (c1 + kPdfs - 1) / kPdfs;
+        fetch(jb0, 0, c0, c1);
+        landed();
+        __syncthreads();
+        for (int jb = jb0; jb < jb1; jb++) {
+          const int buf = (jb - jb0) & 1;
+          fetch(min(jb + 1, jb1 - 1), buf ^ 1, c0, c1);
+          if (active && jb < nb_mine) {
+            f32x16 acc[kNT];
+            f32x16 init;
+#pragma unroll
+            for (int qq = 0; qq < 4; qq++) {
+              const float4 gq = *reinterpret_cast<const float4 *>(&gc_lds[buf][8 * qq + 4 * h]);
+              init[4 * qq] = gq.x; init[4 * qq + 1] = gq.y; init[4 * qq + 2] = gq.z; init[4 * qq + 3] = gq.w;
+            }
+            auto read_a = [&](int s, op8 (&a)[kPieces]) {
+#pragma unroll
+              for (int qq = 0; qq < kPieces; qq++)
+                a[qq] = __builtin_bit_cast(op8, a_lds[buf][((s * kPieces + qq) * 2 + h) * 32 + col]);
+            };
+            op8 a_cur[kPieces], a_nxt[kPieces];
+            read_a(0, a_cur);
+            constexpr int kProd = kHalf ? 3 : 6;
+            constexpr int pa[6] = {kHalf ? 1 : 2, kHalf ? 0 : 1, 0, 1, 0, 0}, pb[6] = {0, 1, kHalf ? 0 : 2, 0, 1, 0};
+#pragma unroll
+            for (int s = 0; s < kSteps; s++) {
+              if (s + 1 < kSteps) read_a(s + 1, a_nxt);
+#pragma unroll
+              for (int t6 = 0; t6 < kProd; t6++)
+#pragma unroll
+                for (int n = 0; n < kNT; n++) {
+                  const f32x16 &cin = (s == 0 && t6 == 0) ? init : acc[n];
+                  if constexpr (kHalf)
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[pa[t6]], b[n][s][pb[t6]], cin, 0, 0, 0);
+                  else
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[pa[t6]], b[n][s][pb[t6]], cin, 0, 0, 0);
+                }
+#pragma unroll
+              for (int qq = 0; qq < kPieces; qq++) a_cur[qq] = a_nxt[qq];
+            }
+            // ---- per-pdf log-sum-exp.  Accumulator register r of half-wave h is row (r & 3) + 8 (r >> 2) + 4 h.
+            const int colbase = (jb * kPdfs) & 31;           // first staging column of this block
+#pragma unroll
+            for (int n = 0; n < kNT; n++) {
+              float *srow = stage + (32 * n + col) * 33 + colbase;
+              if constexpr (kSlot == 16) {                   // pdf k: rows 16k..16k+15 = registers [8k, 8k+8) of both halves
+                float ll[2];
+#pragma unroll
+                for (int k2 = 0; k2 < 2; k2++) {
+                  float m = group_max(acc[n], 8 * k2, 8);
+                  m = fmaxf(m, swap32(m, h));
+                  float sv = group_expsum(acc[n], 8 * k2, 8, m);
+                  sv += swap32(sv, h);
+                  ll[k2] = finish(m * inv_s, sv);
+                }
+                srow[h] = h ? ll[1] : ll[0];                 // each half-wave stores one of the two columns
+              } else if constexpr (kSlot == 8) {             // pdf k: rows 8k..8k+7 = registers [4k, 4k+4) of both halves
+                float ll[4];
+#pragma unroll
+                for (int k2 = 0; k2 < 4; k2++) {
+                  float m = group_max(acc[n], 4 * k2, 4);
+                  m = fmaxf(m, swap32(m, h));
+                  float sv = group_expsum(acc[n], 4 * k2, 4, m);
+                  sv += swap32(sv, h);
+                  ll[k2] = finish(m * inv_s, sv);
+                }
+                srow[h] = h ? ll[1] : ll[0];
+                srow[2 + h] = h ? ll[3] : ll[2];
+              } else {                                       // kSlot 4: pdf 2i + h: rows 8i + 4h .. +3 = registers [4i, 4i+4)
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                  const float m = group_max(acc[n], 4 * i, 4);
+                  const float sv = group_expsum(acc[n], 4 * i, 4, m);
+                  srow[2 * i + h] = finish(m * inv_s, sv);
+                }
+              }
+            }
+            const int col_last = min((jb + 1) * kPdfs, n_mine) - 1;   // last valid column this block produced
+            if ((col_last & 31) == 31 || jb == nb_mine - 1) flush(col_last);
+          }
+          landed();
+          __syncthreads();                                 // block jb+1 is in place; everybody is done with block jb
+        }
+        }
+      }
+    }
+  }
+}
+
 // max over the batch of the pdfs' first possible frames → *max_ff (the persistent kernel derives its phase split from it)
 __global__ void gmm_max_first_frame_kernel(const int32_t *first_frame, const int64_t *pdf_off, int n_utt, int *out) {
   const int64_t n = pdf_off[n_utt];
@@ -1322,9 +1584,11 @@ MFA_API int mfa_load_gmm(mfa_ctx *c, int32_t dim, int32_t num_pdfs, const int32_
   c->h_nblk = nblk;
   c->all_single_block = true;   // (name kept: "all pdfs are 32-row pdfs", single- or multi-block)
   c->has_multi_block = false;
+  for (int q = 0; q < 5; q++) c->has_slot_class[q] = false;
   for (int p = 0; p < num_pdfs; p++) {
     if (slot[p] != 32) c->all_single_block = false;
     if (nblk[p] > 1) c->has_multi_block = true;
+    c->has_slot_class[class_index(slot[p])] = true;
   }
   c->gmm_ready = true;
   return 0;
@@ -1428,8 +1692,9 @@ MFA_API int mfa_gmm_score_batch(mfa_ctx *c, const float *d_feats, const int64_t 
     constexpr int kFramesPerItem = 256;
     p.n_utt = n_utt;
     p.tiles = (max_frames + kFramesPerItem - 1) / kFramesPerItem;
-    if (!c->d_gmm_queue) MFA_HIP_CHECK(c, hipMalloc((void **)&c->d_gmm_queue, 64 * sizeof(int)));
-    MFA_HIP_CHECK(c, hipMemsetAsync(c->d_gmm_queue, 0, 64 * sizeof(int), c->stream));
+    constexpr int kQueueInts = 64 + 6 * 16;   // counters of the main launches + six small-slot launches
+    if (!c->d_gmm_queue) MFA_HIP_CHECK(c, hipMalloc((void **)&c->d_gmm_queue, kQueueInts * sizeof(int)));
+    MFA_HIP_CHECK(c, hipMemsetAsync(c->d_gmm_queue, 0, kQueueInts * sizeof(int), c->stream));
     p.queue = c->d_gmm_queue;
     p.max_ff = c->d_gmm_queue + 16;
     if (d_pdf_first_frame)
@@ -1474,9 +1739,33 @@ MFA_API int mfa_gmm_score_batch(mfa_ctx *c, const float *d_feats, const int64_t 
       else if (c->has_multi_block) hipLaunchKernelGGL((gmm_bf16_kernel<6>), grid, dim3(256), 0, c->stream, p);
       else hipLaunchKernelGGL((gmm_split_single_kernel<6, 3>), grid, dim3(256), 0, c->stream, p);
       p.skip_single = 1;
+      if (!c->has_multi_block) {
+        // the 16- / 8- / 4-row classes on the same pipe (f16×2 pass, then the bf16×3 pass over declined tiles), each launch
+        // with its own queue counters; classes the model does not have are not launched
+        int qbase = 64;
+        auto small = [&](int slot_rows, int cls_idx) {
+          if (!c->has_slot_class[cls_idx]) return;
+          for (int pass = use_f16 ? 0 : 1; pass < 2; pass++) {
+            p.redo_mode = use_f16 ? (pass == 0 ? 0 : 2) : 0;
+            p.queue = c->d_gmm_queue + qbase; qbase += 16;
+#define MFA_LAUNCH_SMALL(STEPS, PIECES)                                                                                   \
+            do {                                                                                                        \
+              if (slot_rows == 16) hipLaunchKernelGGL((gmm_split_small_kernel<STEPS, PIECES, 16>), grid, dim3(256), 0, c->stream, p); \
+              else if (slot_rows == 8) hipLaunchKernelGGL((gmm_split_small_kernel<STEPS, PIECES, 8>), grid, dim3(256), 0, c->stream, p); \
+              else hipLaunchKernelGGL((gmm_split_small_kernel<STEPS, PIECES, 4>), grid, dim3(256), 0, c->stream, p); \
+            } while (0)
+            if (pass == 0) { if (m8 == 10) MFA_LAUNCH_SMALL(5, 2); else MFA_LAUNCH_SMALL(6, 2); }
+            else { if (m8 == 10) MFA_LAUNCH_SMALL(5, 3); else MFA_LAUNCH_SMALL(6, 3); }
+#undef MFA_LAUNCH_SMALL
+          }
+        };
+        small(16, 1); small(8, 2); small(4, 3);
+        p.skip_single = 2;
+      }
       p.queue = c->d_gmm_queue + 17;
     }
-    if (p.skip_single && c->all_single_block) {
+    const bool only_split_classes = !c->has_multi_block && !c->has_slot_class[4] && p.skip_single == 2;
+    if (p.skip_single && (c->all_single_block || only_split_classes)) {
       // every pdf of the model is a single 32-row block: nothing is left for the f32 kernel
     } else if (m8 <= 10) hipLaunchKernelGGL((gmm_kernel<10, 2, 2, 4>), grid, dim3(256), 0, c->stream, p);
     else hipLaunchKernelGGL((gmm_kernel<12, 2, 2, 4>), grid, dim3(256), 0, c->stream, p);
