@@ -1716,9 +1716,10 @@ MFA_API int mfa_gmm_score_batch(mfa_ctx *c, const float *d_feats, const int64_t 
       // class 0 on the bf16×3 kernel, then the f32 kernel for whatever other slot classes the lists hold (second set of
       // queue counters; an item with nothing left returns at once)
       const char *hf = getenv("MFA_GMM_F16");
-      const bool use_f16 = !(hf && hf[0] == '0') && c->d_wh && !c->has_multi_block;
-      if (use_f16) {
-        // f16×2 pass over every tile, then the bf16×3 pass over the tiles it declined (third set of queue counters)
+      const bool f16_ok = !(hf && hf[0] == '0') && c->d_wh;
+      const bool use_f16 = f16_ok && !c->has_multi_block;   // the 32-row class; the small-slot classes use f16 whenever f16_ok
+      if (f16_ok) {
+        // an f16×2 pass scores every tile it can and flags the others for the bf16×3 pass that follows it
         if (c->gmm_redo_cap < items) {
           if (c->d_gmm_redo) (void)hipFree(c->d_gmm_redo);
           c->d_gmm_redo = nullptr; c->gmm_redo_cap = 0;
@@ -1729,6 +1730,8 @@ MFA_API int mfa_gmm_score_batch(mfa_ctx *c, const float *d_feats, const int64_t 
         p.wh = (const uint4 *)c->d_wh; p.gch = c->d_gch; p.fscale = c->d_fscale;
         p.acc_scale_inv = 1.0f / c->gmm_acc_scale;
         p.redo = c->d_gmm_redo; p.redo_mode = 0; p.redo_count = c->d_gmm_queue + 51;
+      }
+      if (use_f16) {
         if (m8 == 10) hipLaunchKernelGGL((gmm_split_single_kernel<5, 2>), grid, dim3(256), 0, c->stream, p);
         else hipLaunchKernelGGL((gmm_split_single_kernel<6, 2>), grid, dim3(256), 0, c->stream, p);
         p.redo_mode = 2;
@@ -1739,14 +1742,14 @@ MFA_API int mfa_gmm_score_batch(mfa_ctx *c, const float *d_feats, const int64_t 
       else if (c->has_multi_block) hipLaunchKernelGGL((gmm_bf16_kernel<6>), grid, dim3(256), 0, c->stream, p);
       else hipLaunchKernelGGL((gmm_split_single_kernel<6, 3>), grid, dim3(256), 0, c->stream, p);
       p.skip_single = 1;
-      if (!c->has_multi_block) {
+      {
         // the 16- / 8- / 4-row classes on the same pipe (f16×2 pass, then the bf16×3 pass over declined tiles), each launch
         // with its own queue counters; classes the model does not have are not launched
         int qbase = 64;
         auto small = [&](int slot_rows, int cls_idx) {
           if (!c->has_slot_class[cls_idx]) return;
-          for (int pass = use_f16 ? 0 : 1; pass < 2; pass++) {
-            p.redo_mode = use_f16 ? (pass == 0 ? 0 : 2) : 0;
+          for (int pass = f16_ok ? 0 : 1; pass < 2; pass++) {
+            p.redo_mode = f16_ok ? (pass == 0 ? 0 : 2) : 0;
             p.queue = c->d_gmm_queue + qbase; qbase += 16;
 #define MFA_LAUNCH_SMALL(STEPS, PIECES)                                                                                   \
             do {                                                                                                        \
@@ -1764,7 +1767,7 @@ MFA_API int mfa_gmm_score_batch(mfa_ctx *c, const float *d_feats, const int64_t 
       }
       p.queue = c->d_gmm_queue + 17;
     }
-    const bool only_split_classes = !c->has_multi_block && !c->has_slot_class[4] && p.skip_single == 2;
+    const bool only_split_classes = !c->has_slot_class[4] && p.skip_single == 2;   // no single-Gaussian pdfs left over
     if (p.skip_single && (c->all_single_block || only_split_classes)) {
       // every pdf of the model is a single 32-row block: nothing is left for the f32 kernel
     } else if (m8 <= 10) hipLaunchKernelGGL((gmm_kernel<10, 2, 2, 4>), grid, dim3(256), 0, c->stream, p);

@@ -352,8 +352,8 @@ def test_gmm_bf16_split_kernel_within_float32_rounding(engine, dim, monkeypatch)
         ref = O.gmm_loglikes(feats[u], am.gconsts, am.means_invvars, am.inv_vars, am.pdf_offsets, sorted_lists[u])
         scale = max(1.0, float(np.abs(ref).max()))
         assert np.abs(got[u] - ref).max() < 4e-6 * scale, (u, float(np.abs(got[u] - ref).max()), scale)
-        single = n_gauss[sorted_lists[u]] > 16   # 32-row pdfs, single- or multi-block: the bf16 kernel's classes
-        # columns of the small-slot classes are produced by the f32 kernel in both runs: identical bits
+        single = n_gauss[sorted_lists[u]] > 1    # everything but single-Gaussian pdfs takes a split-operand kernel
+        # single-Gaussian columns are produced by the f32 kernel in both runs: identical bits
         assert np.array_equal(got[u][:, ~single], f32_scores[u][:, ~single])
         changed += int((got[u][:, single] != f32_scores[u][:, single]).sum())
     assert changed > 0   # the bf16 path really ran
