@@ -66,6 +66,7 @@ struct mfa_ctx {
   int32_t *d_slot = nullptr;   // [num_pdfs] slot class rows (1,4,8,16,32)
   std::vector<int32_t> h_slot, h_nblk;
   bool has_slot_class[5] = {false, false, false, false, false};   // model has pdfs of slot 32 / 16 / 8 / 4 / 1 rows
+  bool has_single32 = false;       // some pdf is one 32-row block (17–32 Gaussians): gmm_split_single_kernel has work
   bool has_multi_block = false;    // some pdf has more than 32 Gaussians (several blocks, merged by gmm_bf16_kernel<…, true>)
   bool all_single_block = false;   // every pdf occupies exactly one 32-row block (no work for the f32 kernel in bf16 mode)
   int32_t *d_nrows = nullptr;  // [num_pdfs] packed rows per pdf (fmllr.hip)

@@ -55,6 +55,7 @@ struct GmmParams {
   const float *feats; const int64_t *frame_off;
   const int32_t *pdf_list; const int64_t *pdf_off; const int32_t *class_counts; const int64_t *ll_off;
   unsigned long long *trace;   // debug (mfa_debug_gmm_trace): per workgroup {start, end, hw id, blocks} or NULL
+  int skip_cc0;                // gmm_bf16_kernel: 1 = the single-block 32-row class was scored by gmm_split_single_kernel
   int skip_single;             // 1: the 32-row classes (0 and 1) are left to the split kernels; 2: the 16/8/4-row classes too
   int ff_bias;                 // debug (MFA_GMM_FF_BIAS): added to the tile's last frame before the reachability test
   const int32_t *first_frame;  // parallel to pdf_list (ascending inside each class) or NULL: see mfa_gmm_score_batch
@@ -644,6 +645,7 @@ __global__ __launch_bounds__(256, 2) void gmm_bf16_kernel(GmmParams p) {
           n0_mine += __popcll(mine & c0m); n1_mine += __popcll(mine & ~c0m);
         }
       }
+      if (p.skip_cc0) { n0 = 0; n0_mine = 0; }         // columns keep their places: multi-block pdfs start at column cc0
       // total entries: one per single-block pdf, nblk per multi-block pdf
       int e_multi = 0;
       for (int i0 = 0; i0 < n1; i0 += 64) {
@@ -1585,9 +1587,11 @@ MFA_API int mfa_load_gmm(mfa_ctx *c, int32_t dim, int32_t num_pdfs, const int32_
   c->all_single_block = true;   // (name kept: "all pdfs are 32-row pdfs", single- or multi-block)
   c->has_multi_block = false;
   for (int q = 0; q < 5; q++) c->has_slot_class[q] = false;
+  c->has_single32 = false;
   for (int p = 0; p < num_pdfs; p++) {
     if (slot[p] != 32) c->all_single_block = false;
     if (nblk[p] > 1) c->has_multi_block = true;
+    if (slot[p] == 32 && nblk[p] == 1) c->has_single32 = true;
     c->has_slot_class[class_index(slot[p])] = true;
   }
   c->gmm_ready = true;
@@ -1692,7 +1696,7 @@ MFA_API int mfa_gmm_score_batch(mfa_ctx *c, const float *d_feats, const int64_t 
     constexpr int kFramesPerItem = 256;
     p.n_utt = n_utt;
     p.tiles = (max_frames + kFramesPerItem - 1) / kFramesPerItem;
-    constexpr int kQueueInts = 64 + 6 * 16;   // counters of the main launches + six small-slot launches
+    constexpr int kQueueInts = 64 + 7 * 16;   // counters of the main launches + six small-slot launches + the multi-block one
     if (!c->d_gmm_queue) MFA_HIP_CHECK(c, hipMalloc((void **)&c->d_gmm_queue, kQueueInts * sizeof(int)));
     MFA_HIP_CHECK(c, hipMemsetAsync(c->d_gmm_queue, 0, kQueueInts * sizeof(int), c->stream));
     p.queue = c->d_gmm_queue;
@@ -1710,14 +1714,15 @@ MFA_API int mfa_gmm_score_batch(mfa_ctx *c, const float *d_feats, const int64_t 
     dim3 grid((unsigned)std::max<int64_t>(wgs, 1));
     const char *bf = getenv("MFA_GMM_BF16");
     p.wb = (const uint4 *)c->d_wb;
-    p.wh = nullptr; p.gch = nullptr; p.fscale = nullptr; p.acc_scale_inv = 1.0f; p.redo = nullptr; p.redo_mode = 0; p.redo_count = nullptr;
+    p.wh = nullptr; p.gch = nullptr; p.fscale = nullptr; p.acc_scale_inv = 1.0f; p.redo = nullptr; p.redo_mode = 0; p.redo_count = nullptr; p.skip_cc0 = 0;
     p.skip_single = 0;
     if (!(bf && bf[0] == '0') && c->d_wb) {   // default on; MFA_GMM_BF16=0 keeps every class on the f32 kernel
       // class 0 on the bf16×3 kernel, then the f32 kernel for whatever other slot classes the lists hold (second set of
       // queue counters; an item with nothing left returns at once)
       const char *hf = getenv("MFA_GMM_F16");
       const bool f16_ok = !(hf && hf[0] == '0') && c->d_wh;
-      const bool use_f16 = f16_ok && !c->has_multi_block;   // the 32-row class; the small-slot classes use f16 whenever f16_ok
+      const bool use_f16 = f16_ok && c->has_single32;   // single-block 32-row class on the lean f16 kernel
+      p.skip_cc0 = 0;
       if (f16_ok) {
         // an f16×2 pass scores every tile it can and flags the others for the bf16×3 pass that follows it
         if (c->gmm_redo_cap < items) {
@@ -1736,11 +1741,19 @@ MFA_API int mfa_gmm_score_batch(mfa_ctx *c, const float *d_feats, const int64_t 
         else hipLaunchKernelGGL((gmm_split_single_kernel<6, 2>), grid, dim3(256), 0, c->stream, p);
         p.redo_mode = 2;
         p.queue = c->d_gmm_queue + 34;
+        if (m8 == 10) hipLaunchKernelGGL((gmm_split_single_kernel<5, 3>), grid, dim3(256), 0, c->stream, p);
+        else hipLaunchKernelGGL((gmm_split_single_kernel<6, 3>), grid, dim3(256), 0, c->stream, p);
+        p.redo_mode = 0;
+        p.skip_cc0 = 1;
+        p.queue = c->d_gmm_queue + 64 + 6 * 16;
       }
-      if (m8 == 10 && c->has_multi_block) hipLaunchKernelGGL((gmm_bf16_kernel<5>), grid, dim3(256), 0, c->stream, p);
-      else if (m8 == 10) hipLaunchKernelGGL((gmm_split_single_kernel<5, 3>), grid, dim3(256), 0, c->stream, p);
-      else if (c->has_multi_block) hipLaunchKernelGGL((gmm_bf16_kernel<6>), grid, dim3(256), 0, c->stream, p);
-      else hipLaunchKernelGGL((gmm_split_single_kernel<6, 3>), grid, dim3(256), 0, c->stream, p);
+      if (c->has_multi_block) {                           // pdfs of more than 32 Gaussians (and, without f16, the whole 32-row class)
+        if (m8 == 10) hipLaunchKernelGGL((gmm_bf16_kernel<5>), grid, dim3(256), 0, c->stream, p);
+        else hipLaunchKernelGGL((gmm_bf16_kernel<6>), grid, dim3(256), 0, c->stream, p);
+      } else if (!use_f16 && c->has_single32) {
+        if (m8 == 10) hipLaunchKernelGGL((gmm_split_single_kernel<5, 3>), grid, dim3(256), 0, c->stream, p);
+        else hipLaunchKernelGGL((gmm_split_single_kernel<6, 3>), grid, dim3(256), 0, c->stream, p);
+      }
       p.skip_single = 1;
       {
         // the 16- / 8- / 4-row classes on the same pipe (f16×2 pass, then the bf16×3 pass over declined tiles), each launch
