@@ -422,6 +422,48 @@ def test_gmm_f16_split_kernel_within_tolerance_and_range_fallback(engine, dim, m
     print(f"f16x2 worst |err|/scale = {worst:.3g}")
 
 
+@pytest.mark.parametrize("sizes", [[1, 2, 3, 4, 5, 8, 9, 12, 16, 17, 26, 32, 32, 4, 8, 16] * 4,
+                                   [1, 4, 8, 16, 20, 32, 33, 64, 70, 2, 6, 11] * 4])
+def test_reachability_keys_across_all_slot_classes(engine, sizes):
+    """Scoring with per-pdf first-frame keys on models that exercise every kernel family at once (single Gaussians on
+    the f32 kernel; 4-, 8-, 16-row classes as gathered virtual blocks; single 32-row blocks; multi-block pdfs): every
+    cell at or after its pdf's key must carry exactly the bits of the dense run, every cell written at all must be the
+    dense run's value, and cells are in fact skipped."""
+    rng = np.random.default_rng(len(sizes) + sizes[5])
+    dim = 40
+    am = helpers.random_gmm(rng, dim, sizes)
+    engine.load_gmm(am)
+    Ts = (700, 257, 64, 1)
+    feats = [rng.normal(0, 3, size=(t, dim)).astype(np.float32) for t in Ts]
+    lists, keys, counts = [], [], []
+    for t in Ts:
+        pl = rng.permutation(am.num_pdfs)[: max(1, am.num_pdfs - 5)].astype(np.int32)
+        ff = rng.integers(0, t + 40, size=len(pl)).astype(np.int32)   # some pdfs are never reachable in this utterance
+        pl, cc, ff = engine.sort_pdf_list(pl, first_frame=ff)
+        lists.append(pl); keys.append(ff); counts.append(cc)
+    frame_off = np.concatenate([[0], np.cumsum(Ts)]).astype(np.int64)
+    pdf_off = np.concatenate([[0], np.cumsum([len(p) for p in lists])]).astype(np.int64)
+    d_feats = _dev(engine, np.concatenate(feats))
+    d_list, d_cc = _dev(engine, np.concatenate(lists)), _dev(engine, np.stack(counts).astype(np.int32))
+    dense, ll_off, _ = engine.score(d_feats, frame_off, d_list, pdf_off, d_cc)
+    sparse, _, _ = engine.score(d_feats, frame_off, d_list, pdf_off, d_cc, pdf_first_frame=_dev(engine, np.concatenate(keys)))
+    dense, sparse = dense.cpu().numpy(), sparse.cpu().numpy()
+    skipped = 0
+    for u, t in enumerate(Ts):
+        P = len(lists[u])
+        du, su = dense[ll_off[u]: ll_off[u + 1]].reshape(t, P), sparse[ll_off[u]: ll_off[u + 1]].reshape(t, P)
+        ref = O.gmm_loglikes(feats[u], am.gconsts, am.means_invvars, am.inv_vars, am.pdf_offsets, lists[u])
+        assert np.abs(du - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
+        tt = np.arange(t)[:, None]
+        needed = tt >= keys[u][None, :]
+        assert np.array_equal(su[needed], du[needed])
+        written = su != 0.0                                      # a kernel may score a little more than it must (pdfs
+        assert np.array_equal(su[written], du[written])           # sharing a block): whatever it writes is the real score
+        early = (tt // 64 + 1) * 64 - 1 < keys[u][None, :]        # the whole 64-frame tile lies before the key
+        skipped += int((early & ~written).sum())
+    assert skipped > 0
+
+
 def test_reachability_bounded_scoring_changes_nothing(engine, fx):
     """Scoring with pdf_first_frame skips (frame, pdf) cells no decoder token can ask for: every cell it does write is
     bit-identical to the dense matrix, every cell at or after the pdf's first frame is written, and the alignment that
