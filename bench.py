@@ -43,7 +43,7 @@ def parse_args():
     ap.add_argument("--pool", type=int, default=128, help="distinct synthetic utterances generated per rank")
     ap.add_argument("--workload", choices=["triphone", "mono"], default="triphone")
     ap.add_argument("--train-utts", type=int, default=120)
-    ap.add_argument("--gauss-per-pdf", type=int, default=32,
+    ap.add_argument("--gauss-per-pdf", type=int, default=32,  # 0 = mixture sizes as in a trained model (1..48, median 11)
                     help="triphone workload: Gaussians per pdf (BASELINE configs[2] = 32; other values exercise the other "
                          "slot classes of the scoring kernels and are NOT the headline workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -350,7 +350,7 @@ def main():
     # against the dense f16 peak (same as bf16).  MFA_GMM_F16=0: the bf16×3 kernel, six products (2^-24 per term).
     # MFA_GMM_BF16=0 (or a model whose pdfs are not single 32-row blocks, like the monophone one): the f32 MFMA kernel
     # against the f32 peak.
-    bf16 = os.environ.get("MFA_GMM_BF16", "1") != "0" and not mono and 16 < args.gauss_per_pdf <= 32
+    bf16 = os.environ.get("MFA_GMM_BF16", "1") != "0" and not mono and (1 < args.gauss_per_pdf <= 32 or args.gauss_per_pdf == 0)
     f16 = bf16 and os.environ.get("MFA_GMM_F16", "1") != "0"
     if bf16:
         mult = 3.0 if f16 else 6.0

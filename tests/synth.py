@@ -294,12 +294,15 @@ def train_triphone(world: SynthWorld, feature_fn: Callable[[np.ndarray, int], np
 
     def add_leaf(mean, var):
         nonlocal pdf
-        w = rng.dirichlet(np.ones(n_gauss))
+        # n_gauss = 0: a mixture size per leaf as a trained model has them (occupancy-driven: log-normal, median 11,
+        # 1..48 — mostly small slots, a few leaves beyond one 32-row block)
+        ng = n_gauss if n_gauss > 0 else int(np.clip(np.round(rng.lognormal(2.4, 0.6)), 1, 48))
+        w = rng.dirichlet(np.ones(ng))
         sd = np.sqrt(var)
-        for k in range(n_gauss):
+        for k in range(ng):
             g = _gauss(mean + 0.3 * sd * rng.normal(size=dim), var, w[k])
             gcs.append(g[0]); mis.append(g[1]); ivs.append(g[2])
-        offs.append(offs[-1] + n_gauss)
+        offs.append(offs[-1] + ng)
         pdf += 1
         return pdf - 1
 
