@@ -1263,7 +1263,7 @@ __global__ __launch_bounds__(256, 2) void gmm_split_small_kernel(GmmParams p) {
         };
         auto landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
         // ---- block loop: multiply, reduce per pdf, stage one column per pdf, flush every 32 columns
-        const int nb_single = (n_single + kPdfs - 1) / kPdfs, nb_mine = (n_mine + kPdfs - 1) / kPdfs;
+        const int nb_mine = (n_mine + kPdfs - 1) / kPdfs;   // virtual blocks this wavefront multiplies
         auto flush = [&](int col_last) {                     // columns [col_last − col_last%32, col_last] → HBM
           const int jj = col_last & 31;
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
