@@ -134,8 +134,7 @@ MFA_API int mfa_fst_first_frames(int32_t n_states, const int32_t *h_arc_off, con
  *   - two f16 pieces per operand, power-of-two column scales fixed at mfa_load_gmm (3 * 2^-22 per term worst case;
  *     measured <= 1e-6 x max|score of the frame|); a 256-frame tile whose scaled features leave the f16 range is scored
  *     with three bf16 pieces instead.  MFA_GMM_F16=0: bf16 for all.
- *   - in a model that has pdfs of more than 32 Gaussians, the pdfs of 17 or more Gaussians always take three bf16 pieces
- *     per operand (2^-24 per term; within 4e-6 x max|score|), merged block by block with an online log-sum-exp.
+ *   - pdfs of more than 32 Gaussians are runs of 32-row blocks merged with an online log-sum-exp (same operand splits).
  * Both against a tolerance of 1e-3 on log-likelihoods.  Environment MFA_GMM_BF16=0 keeps every pdf on the float32 pipe. */
 MFA_API int mfa_gmm_score_batch(mfa_ctx *ctx, const float *d_feats, const int64_t *d_frame_off, int32_t n_utt,
                                 int32_t max_frames, const int32_t *d_pdf_list, const int64_t *d_pdf_off,

@@ -586,11 +586,14 @@ __global__ __launch_bounds__(64 * kWaves, kMinWaves) void gmm_kernel(GmmParams p
 // registers: 120 VGPRs) share every 32-row block through LDS, double-buffered — while block j is multiplied out of one
 // buffer, block j+1 travels global → registers → the other buffer; one barrier per block.
 // General form (models that contain multi-block pdfs); gmm_bf16_single_kernel below is the lean form for models that do not.
-template <int kSteps>   // 16-k steps per row: 5 for D ≤ 40, 6 for D ≤ 48
+// kPieces = 3: bf16 triples; kPieces = 2: scaled f16 pairs with the per-tile range fallback (see gmm_split_single_kernel).
+template <int kSteps, int kPieces>   // 16-k steps per row: 5 for D ≤ 40, 6 for D ≤ 48
 __global__ __launch_bounds__(256, 2) void gmm_bf16_kernel(GmmParams p) {
   constexpr bool kMulti = true;
+  constexpr bool kHalf = kPieces == 2;
+  using op8 = std::conditional_t<kHalf, f16x8, bf16x8>;
   constexpr int kNT = 2, kWaves = 4, kFramesPerWave = 64, kFramesPerTile = 256;
-  constexpr int kUnits = kSteps * 3 * 2 * 32;          // 16-byte units per block
+  constexpr int kUnits = kSteps * kPieces * 2 * 32;    // 16-byte units per block
   constexpr int kLoads = (kUnits + 255) / 256;         // units each thread moves per block
   const int lane0 = threadIdx.x & 63, wave = threadIdx.x >> 6;
   __shared__ float stage_all[kWaves][64 * 33];
@@ -605,6 +608,7 @@ __global__ __launch_bounds__(256, 2) void gmm_bf16_kernel(GmmParams p) {
   __shared__ int col_lds[kBlkCache];                  // output column | kFirst | kLast
   __shared__ int s_item;
   float *stage = stage_all[wave];
+  if (!kHalf && p.redo_mode == 2 && *p.redo_count == 0) return;   // uniform: the f16 pass declined nothing
   const int my_xcd = (int)(__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u);
   for (int hop = 0; hop < 8; hop++) {
     const int q = (my_xcd + hop) & 7;
@@ -622,6 +626,7 @@ __global__ __launch_bounds__(256, 2) void gmm_bf16_kernel(GmmParams p) {
       const int64_t f0 = p.frame_off[utt];
       const int T = (int)(p.frame_off[utt + 1] - f0);
       if (tl * kFramesPerTile >= T) continue;          // uniform over the workgroup
+      if (!kHalf && p.redo_mode == 2 && p.redo[(size_t)utt * p.tiles + tl] == 0) continue;   // only what the f16 pass left
       const int t_base = (tl * kWaves + wave) * kFramesPerWave;
       const bool active = t_base < T;                  // a wavefront past the end still helps move blocks and joins barriers
       const int64_t l0 = p.pdf_off[utt];
@@ -659,7 +664,8 @@ __global__ __launch_bounds__(256, 2) void gmm_bf16_kernel(GmmParams p) {
       float *out = p.out + p.ll_off[utt];
       if (n_entries > 0) {
         // ---- x̃ = [x, x²] of this wavefront's 64 frames, split into bf16 triples: b[tile][step][piece], lane (frame, half)
-        bf16x8 b[kNT][kSteps][3];
+        op8 b[kNT][kSteps][kPieces];
+        bool bad = false;                                  // kHalf: a scaled feature outside the f16 range (or NaN)
 #pragma unroll
         for (int n = 0; n < kNT; n++) {
           int t = t_base + 32 * n + col;
@@ -674,27 +680,44 @@ __global__ __launch_bounds__(256, 2) void gmm_bf16_kernel(GmmParams p) {
               const int idx = k < p.dim ? k : (k < 2 * p.dim ? k - p.dim : 0);
               const float xv = x[idx];
               const float v = k < p.dim ? xv : (k < 2 * p.dim ? xv * xv : 0.0f);
-              const __bf16 v1 = (__bf16)v;
-              const float r1 = v - (float)v1;
-              const __bf16 v2 = (__bf16)r1;
-              const float r2 = r1 - (float)v2;
-              b[n][s][0][e] = v1; b[n][s][1][e] = v2; b[n][s][2][e] = (__bf16)r2;
+              if constexpr (kHalf) {
+                const float sv = v * p.fscale[k];
+                bad |= !(fabsf(sv) <= 65000.0f);
+                const _Float16 v1 = (_Float16)sv;
+                b[n][s][0][e] = v1; b[n][s][1][e] = (_Float16)(sv - (float)v1);
+              } else {
+                const __bf16 v1 = (__bf16)v;
+                const float r1 = v - (float)v1;
+                const __bf16 v2 = (__bf16)r1;
+                const float r2 = r1 - (float)v2;
+                b[n][s][0][e] = v1; b[n][s][1][e] = v2; b[n][s][2][e] = (__bf16)r2;
+              }
             }
           }
         }
+        if constexpr (kHalf) {
+          if (__syncthreads_or(bad)) {                     // uniform: the whole tile goes to the bf16×3 pass
+            if (threadIdx.x == 0) { p.redo[(size_t)utt * p.tiles + tl] = 1; atomicAdd(p.redo_count, 1); }
+            continue;
+          }
+        }
+        const uint4 *wsrc = kHalf ? p.wh : p.wb;
+        const float *gsrc = kHalf ? p.gch : p.gc;
+        const float inv_s = kHalf ? p.acc_scale_inv : 1.0f;
+        const float l2e_s = 1.44269504088896341f * inv_s;  // inv_s is a power of two: scaling commutes with the rounding
         // Block copy global → registers (requested before block j is multiplied) → LDS (written after it).  The LDS-DMA form
         // (global_load_lds) measured the same when it overlapped and much worse when it did not: the compiler cannot tell the
         // two LDS buffers apart and drains vmcnt before every LDS read while a DMA write is in flight.
         uint4 mv[kLoads];
         float4 gmv = make_float4(0.f, 0.f, 0.f, 0.f);
         auto fetch = [&](int blk) {
-          const uint4 *src = p.wb + (size_t)blk * kUnits;
+          const uint4 *src = wsrc + (size_t)blk * kUnits;
 #pragma unroll
           for (int i = 0; i < kLoads; i++) {
             const int u = threadIdx.x + 256 * i;
             mv[i] = u < kUnits ? src[u] : make_uint4(0, 0, 0, 0);
           }
-          if (threadIdx.x < 8) gmv = *reinterpret_cast<const float4 *>(p.gc + (size_t)blk * 32 + 4 * threadIdx.x);
+          if (threadIdx.x < 8) gmv = *reinterpret_cast<const float4 *>(gsrc + (size_t)blk * 32 + 4 * threadIdx.x);
         };
         auto deposit = [&](int buf) {
 #pragma unroll
@@ -763,26 +786,31 @@ __global__ __launch_bounds__(256, 2) void gmm_bf16_kernel(GmmParams p) {
               for (int n = 0; n < kNT; n++) acc[n] = init;
             }
             // operand pieces of step s+1 are read from LDS while step s is multiplied
-            auto read_a = [&](int s, bf16x8 (&a)[3]) {
+            auto read_a = [&](int s, op8 (&a)[kPieces]) {
 #pragma unroll
-              for (int qq = 0; qq < 3; qq++)
-                a[qq] = __builtin_bit_cast(bf16x8, a_lds[buf][((s * 3 + qq) * 2 + h) * 32 + col]);
+              for (int qq = 0; qq < kPieces; qq++)
+                a[qq] = __builtin_bit_cast(op8, a_lds[buf][((s * kPieces + qq) * 2 + h) * 32 + col]);
             };
-            bf16x8 a_cur[3], a_nxt[3];
+            op8 a_cur[kPieces], a_nxt[kPieces];
             read_a(0, a_cur);
 #pragma unroll
             for (int s = 0; s < kSteps; s++) {
               if (s + 1 < kSteps) read_a(s + 1, a_nxt);
               // six products per 16 k-values, smallest terms first; the two tiles alternate so that consecutive MFMAs never
               // wait on each other's accumulator
-              constexpr int pa[6] = {2, 1, 0, 1, 0, 0}, pb[6] = {0, 1, 2, 0, 1, 0};
+              constexpr int kProd = kHalf ? 3 : 6;
+              constexpr int pa[6] = {kHalf ? 1 : 2, kHalf ? 0 : 1, 0, 1, 0, 0}, pb[6] = {0, 1, kHalf ? 0 : 2, 0, 1, 0};
 #pragma unroll
-              for (int t6 = 0; t6 < 6; t6++)
+              for (int t6 = 0; t6 < kProd; t6++)
 #pragma unroll
-                for (int n = 0; n < kNT; n++)
-                  acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[pa[t6]], b[n][s][pb[t6]], acc[n], 0, 0, 0);
+                for (int n = 0; n < kNT; n++) {
+                  if constexpr (kHalf)
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[pa[t6]], b[n][s][pb[t6]], acc[n], 0, 0, 0);
+                  else
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[pa[t6]], b[n][s][pb[t6]], acc[n], 0, 0, 0);
+                }
 #pragma unroll
-              for (int qq = 0; qq < 3; qq++) a_cur[qq] = a_nxt[qq];
+              for (int qq = 0; qq < kPieces; qq++) a_cur[qq] = a_nxt[qq];
             }
             // ---- log-sum-exp epilogue and LDS-staged, coalesced score stores: as in score_tile
             float mx[kNT], sum[kNT];
@@ -793,9 +821,9 @@ __global__ __launch_bounds__(256, 2) void gmm_bf16_kernel(GmmParams p) {
 #else
               float m = reg_max<0, 16>(acc[n]);
               m = fmaxf(m, swap32(m, h));
-              float sv = reg_expsum_fast(acc[n], m);
+              float sv = reg_expsum_fast(acc[n], m, l2e_s);
               sv += swap32(sv, h);
-              mx[n] = m; sum[n] = sv;
+              mx[n] = m; sum[n] = sv;                        // mx stays in accumulator units (× S) until the pdf's last block
 #endif
             }
             if (kMulti && !(ecol & kFirst)) {
@@ -803,8 +831,8 @@ __global__ __launch_bounds__(256, 2) void gmm_bf16_kernel(GmmParams p) {
 #pragma unroll
               for (int n = 0; n < kNT; n++) {
                 const float M = fmaxf(mx_run[n], mx[n]);
-                sum[n] = sum_run[n] * __builtin_amdgcn_exp2f((mx_run[n] - M) * 1.44269504088896341f) +
-                         sum[n] * __builtin_amdgcn_exp2f((mx[n] - M) * 1.44269504088896341f);
+                sum[n] = sum_run[n] * __builtin_amdgcn_exp2f((mx_run[n] - M) * l2e_s) +
+                         sum[n] * __builtin_amdgcn_exp2f((mx[n] - M) * l2e_s);
                 mx[n] = M;
               }
             }
@@ -817,7 +845,7 @@ __global__ __launch_bounds__(256, 2) void gmm_bf16_kernel(GmmParams p) {
 #else
             if (ecol & kLast) {
 #endif
-              const float v = finish(h ? mx[1] : mx[0], h ? sum[1] : sum[0]);
+              const float v = finish((h ? mx[1] : mx[0]) * inv_s, h ? sum[1] : sum[0]);
               if (staged > 0 && out_col != stage_col0 + staged) flush();   // a jump in the column sequence (class change)
               if (staged == 0) stage_col0 = out_col;
               stage[(32 * h + col) * 33 + staged] = v;
@@ -1696,7 +1724,7 @@ MFA_API int mfa_gmm_score_batch(mfa_ctx *c, const float *d_feats, const int64_t 
     constexpr int kFramesPerItem = 256;
     p.n_utt = n_utt;
     p.tiles = (max_frames + kFramesPerItem - 1) / kFramesPerItem;
-    constexpr int kQueueInts = 64 + 7 * 16;   // counters of the main launches + six small-slot launches + the multi-block one
+    constexpr int kQueueInts = 64 + 8 * 16;   // counters of the main launches + six small-slot launches + the multi-block one
     if (!c->d_gmm_queue) MFA_HIP_CHECK(c, hipMalloc((void **)&c->d_gmm_queue, kQueueInts * sizeof(int)));
     MFA_HIP_CHECK(c, hipMemsetAsync(c->d_gmm_queue, 0, kQueueInts * sizeof(int), c->stream));
     p.queue = c->d_gmm_queue;
@@ -1748,8 +1776,15 @@ MFA_API int mfa_gmm_score_batch(mfa_ctx *c, const float *d_feats, const int64_t 
         p.queue = c->d_gmm_queue + 64 + 6 * 16;
       }
       if (c->has_multi_block) {                           // pdfs of more than 32 Gaussians (and, without f16, the whole 32-row class)
-        if (m8 == 10) hipLaunchKernelGGL((gmm_bf16_kernel<5>), grid, dim3(256), 0, c->stream, p);
-        else hipLaunchKernelGGL((gmm_bf16_kernel<6>), grid, dim3(256), 0, c->stream, p);
+        if (f16_ok) {                                     // f16×2 pass, then the bf16×3 pass over the tiles it declined
+          if (m8 == 10) hipLaunchKernelGGL((gmm_bf16_kernel<5, 2>), grid, dim3(256), 0, c->stream, p);
+          else hipLaunchKernelGGL((gmm_bf16_kernel<6, 2>), grid, dim3(256), 0, c->stream, p);
+          p.redo_mode = 2;
+          p.queue = c->d_gmm_queue + 64 + 7 * 16;
+        }
+        if (m8 == 10) hipLaunchKernelGGL((gmm_bf16_kernel<5, 3>), grid, dim3(256), 0, c->stream, p);
+        else hipLaunchKernelGGL((gmm_bf16_kernel<6, 3>), grid, dim3(256), 0, c->stream, p);
+        p.redo_mode = 0;
       } else if (!use_f16 && c->has_single32) {
         if (m8 == 10) hipLaunchKernelGGL((gmm_split_single_kernel<5, 3>), grid, dim3(256), 0, c->stream, p);
         else hipLaunchKernelGGL((gmm_split_single_kernel<6, 3>), grid, dim3(256), 0, c->stream, p);
