@@ -390,6 +390,7 @@ def test_gmm_f16_split_kernel_within_tolerance_and_range_fallback(engine, dim, m
     2e-5 × scale of the oracle per (frame, pdf) cell — north_star allows 1e-3 on a log-likelihood — and a 256-frame tile
     holding a feature value that leaves the f16 range after scaling is scored by the bf16×3 kernel instead: its cells are
     bit-identical to a run with MFA_GMM_F16=0."""
+    monkeypatch.delenv("MFA_GMM_BF16", raising=False)   # this test is about the default path, whatever the caller's shell says
     rng = np.random.default_rng(300 + dim)
     sizes = [32] * 40 + [17, 20, 31, 32, 29] + [1, 4, 8, 16]
     am = helpers.random_gmm(rng, dim, sizes)
