@@ -586,6 +586,46 @@ __global__ __launch_bounds__(64 * kWaves, kMinWaves) void gmm_kernel(GmmParams p
 // registers: 120 VGPRs) share every 32-row block through LDS, double-buffered — while block j is multiplied out of one
 // buffer, block j+1 travels global → registers → the other buffer; one barrier per block.
 // General form (models that contain multi-block pdfs); gmm_bf16_single_kernel below is the lean form for models that do not.
+// x̃ = [x, x²] of a wavefront's two 32-frame tiles (frames t_base + 32 n + col, clamped into the utterance), split into
+// the MFMA's B operands: b[tile][step][piece], lane = (frame col, k-half h).  kPieces = 3: bf16 triples (v = v1 + v2 + v3,
+// round to nearest even each).  kPieces = 2: f16 pairs of the column-scaled value; returns true when a scaled value
+// leaves the f16 range (or is NaN) — the caller then hands the whole tile to the bf16×3 pass.
+template <int kSteps, int kPieces, typename Op8>
+__device__ __forceinline__ bool split_features(const GmmParams &p, int64_t f0, int T, int t_base, int col, int h,
+                                               Op8 (&b)[2][kSteps][kPieces]) {
+  bool bad = false;
+#pragma unroll
+  for (int n = 0; n < 2; n++) {
+    int t = t_base + 32 * n + col;
+    t = t < T ? t : T - 1;
+    t = t < 0 ? 0 : t;
+    const float *x = p.feats + (f0 + t) * p.dim;
+#pragma unroll
+    for (int s = 0; s < kSteps; s++) {
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        const int k = 16 * s + 8 * h + e;
+        const int idx = k < p.dim ? k : (k < 2 * p.dim ? k - p.dim : 0);
+        const float xv = x[idx];
+        const float v = k < p.dim ? xv : (k < 2 * p.dim ? xv * xv : 0.0f);
+        if constexpr (kPieces == 2) {
+          const float sv = v * p.fscale[k];
+          bad |= !(fabsf(sv) <= 65000.0f);
+          const _Float16 v1 = (_Float16)sv;
+          b[n][s][0][e] = v1; b[n][s][1][e] = (_Float16)(sv - (float)v1);
+        } else {
+          const __bf16 v1 = (__bf16)v;
+          const float r1 = v - (float)v1;
+          const __bf16 v2 = (__bf16)r1;
+          const float r2 = r1 - (float)v2;
+          b[n][s][0][e] = v1; b[n][s][1][e] = v2; b[n][s][2][e] = (__bf16)r2;
+        }
+      }
+    }
+  }
+  return bad;
+}
+
 // kPieces = 3: bf16 triples; kPieces = 2: scaled f16 pairs with the per-tile range fallback (see gmm_split_single_kernel).
 template <int kSteps, int kPieces>   // 16-k steps per row: 5 for D ≤ 40, 6 for D ≤ 48
 __global__ __launch_bounds__(256, 2) void gmm_bf16_kernel(GmmParams p) {
@@ -665,36 +705,8 @@ __global__ __launch_bounds__(256, 2) void gmm_bf16_kernel(GmmParams p) {
       if (n_entries > 0) {
         // ---- x̃ = [x, x²] of this wavefront's 64 frames, split into bf16 triples: b[tile][step][piece], lane (frame, half)
         op8 b[kNT][kSteps][kPieces];
-        bool bad = false;                                  // kHalf: a scaled feature outside the f16 range (or NaN)
-#pragma unroll
-        for (int n = 0; n < kNT; n++) {
-          int t = t_base + 32 * n + col;
-          t = t < T ? t : T - 1;
-          t = t < 0 ? 0 : t;
-          const float *x = p.feats + (f0 + t) * p.dim;
-#pragma unroll
-          for (int s = 0; s < kSteps; s++) {
-#pragma unroll
-            for (int e = 0; e < 8; e++) {
-              const int k = 16 * s + 8 * h + e;
-              const int idx = k < p.dim ? k : (k < 2 * p.dim ? k - p.dim : 0);
-              const float xv = x[idx];
-              const float v = k < p.dim ? xv : (k < 2 * p.dim ? xv * xv : 0.0f);
-              if constexpr (kHalf) {
-                const float sv = v * p.fscale[k];
-                bad |= !(fabsf(sv) <= 65000.0f);
-                const _Float16 v1 = (_Float16)sv;
-                b[n][s][0][e] = v1; b[n][s][1][e] = (_Float16)(sv - (float)v1);
-              } else {
-                const __bf16 v1 = (__bf16)v;
-                const float r1 = v - (float)v1;
-                const __bf16 v2 = (__bf16)r1;
-                const float r2 = r1 - (float)v2;
-                b[n][s][0][e] = v1; b[n][s][1][e] = v2; b[n][s][2][e] = (__bf16)r2;
-              }
-            }
-          }
-        }
+        // kHalf: `bad` = a scaled feature outside the f16 range (or NaN)
+        const bool bad = split_features<kSteps, kPieces>(p, f0, T, t_base, col, h, b);
         if constexpr (kHalf) {
           if (__syncthreads_or(bad)) {                     // uniform: the whole tile goes to the bf16×3 pass
             if (threadIdx.x == 0) { p.redo[(size_t)utt * p.tiles + tl] = 1; atomicAdd(p.redo_count, 1); }
@@ -936,36 +948,8 @@ __global__ __launch_bounds__(256, 2) void gmm_split_single_kernel(GmmParams p) {
       if (n_single > 0) {
         // ---- x̃ = [x, x²] of this wavefront's 64 frames, split into bf16 triples: b[tile][step][piece], lane (frame, half)
         op8 b[kNT][kSteps][kPieces];
-        bool bad = false;                                  // kHalf: a scaled feature outside the f16 range (or NaN)
-#pragma unroll
-        for (int n = 0; n < kNT; n++) {
-          int t = t_base + 32 * n + col;
-          t = t < T ? t : T - 1;
-          t = t < 0 ? 0 : t;
-          const float *x = p.feats + (f0 + t) * p.dim;
-#pragma unroll
-          for (int s = 0; s < kSteps; s++) {
-#pragma unroll
-            for (int e = 0; e < 8; e++) {
-              const int k = 16 * s + 8 * h + e;
-              const int idx = k < p.dim ? k : (k < 2 * p.dim ? k - p.dim : 0);
-              const float xv = x[idx];
-              const float v = k < p.dim ? xv : (k < 2 * p.dim ? xv * xv : 0.0f);
-              if constexpr (kHalf) {
-                const float sv = v * p.fscale[k];
-                bad |= !(fabsf(sv) <= 65000.0f);
-                const _Float16 v1 = (_Float16)sv;
-                b[n][s][0][e] = v1; b[n][s][1][e] = (_Float16)(sv - (float)v1);
-              } else {
-                const __bf16 v1 = (__bf16)v;
-                const float r1 = v - (float)v1;
-                const __bf16 v2 = (__bf16)r1;
-                const float r2 = r1 - (float)v2;
-                b[n][s][0][e] = v1; b[n][s][1][e] = v2; b[n][s][2][e] = (__bf16)r2;
-              }
-            }
-          }
-        }
+        // kHalf: `bad` = a scaled feature outside the f16 range (or NaN)
+        const bool bad = split_features<kSteps, kPieces>(p, f0, T, t_base, col, h, b);
         if constexpr (kHalf) {
           if (__syncthreads_or(bad)) {                     // uniform: the whole tile goes to the bf16×3 pass
             if (threadIdx.x == 0) { p.redo[(size_t)utt * p.tiles + tl] = 1; atomicAdd(p.redo_count, 1); }
@@ -1229,36 +1213,8 @@ __global__ __launch_bounds__(256, 2) void gmm_split_small_kernel(GmmParams p) {
       if (n_single > 0) {
         // ---- x̃ = [x, x²] of this wavefront's 64 frames, split into bf16 triples: b[tile][step][piece], lane (frame, half)
         op8 b[kNT][kSteps][kPieces];
-        bool bad = false;                                  // kHalf: a scaled feature outside the f16 range (or NaN)
-#pragma unroll
-        for (int n = 0; n < kNT; n++) {
-          int t = t_base + 32 * n + col;
-          t = t < T ? t : T - 1;
-          t = t < 0 ? 0 : t;
-          const float *x = p.feats + (f0 + t) * p.dim;
-#pragma unroll
-          for (int s = 0; s < kSteps; s++) {
-#pragma unroll
-            for (int e = 0; e < 8; e++) {
-              const int k = 16 * s + 8 * h + e;
-              const int idx = k < p.dim ? k : (k < 2 * p.dim ? k - p.dim : 0);
-              const float xv = x[idx];
-              const float v = k < p.dim ? xv : (k < 2 * p.dim ? xv * xv : 0.0f);
-              if constexpr (kHalf) {
-                const float sv = v * p.fscale[k];
-                bad |= !(fabsf(sv) <= 65000.0f);
-                const _Float16 v1 = (_Float16)sv;
-                b[n][s][0][e] = v1; b[n][s][1][e] = (_Float16)(sv - (float)v1);
-              } else {
-                const __bf16 v1 = (__bf16)v;
-                const float r1 = v - (float)v1;
-                const __bf16 v2 = (__bf16)r1;
-                const float r2 = r1 - (float)v2;
-                b[n][s][0][e] = v1; b[n][s][1][e] = v2; b[n][s][2][e] = (__bf16)r2;
-              }
-            }
-          }
-        }
+        // kHalf: `bad` = a scaled feature outside the f16 range (or NaN)
+        const bool bad = split_features<kSteps, kPieces>(p, f0, T, t_base, col, h, b);
         if constexpr (kHalf) {
           if (__syncthreads_or(bad)) {                     // uniform: the whole tile goes to the bf16×3 pass
             if (threadIdx.x == 0) { p.redo[(size_t)utt * p.tiles + tl] = 1; atomicAdd(p.redo_count, 1); }
