@@ -626,6 +626,44 @@ __device__ __forceinline__ bool split_features(const GmmParams &p, int64_t f0, i
   return bad;
 }
 
+// One 32-row model block (split operands in LDS: [step][piece][half][row] 16-byte units; its 32 gconsts) times a
+// wavefront's two frame tiles → acc.  Operand pieces of step s+1 are read from LDS while step s is multiplied; six (three)
+// products per 16 k-values, smallest terms first; the two tiles alternate so that consecutive MFMAs never wait on each
+// other's accumulator; the gconsts enter as the first MFMA's addend.
+template <int kSteps, int kPieces, typename Op8>
+__device__ __forceinline__ void multiply_block(const uint4 *a_blk, const float *gc_blk, const Op8 (&b)[2][kSteps][kPieces],
+                                               f32x16 (&acc)[2], int col, int h) {
+  constexpr bool kHalf = kPieces == 2;
+  f32x16 init;
+#pragma unroll
+  for (int qq = 0; qq < 4; qq++) {
+    const float4 gq = *reinterpret_cast<const float4 *>(&gc_blk[8 * qq + 4 * h]);
+    init[4 * qq] = gq.x; init[4 * qq + 1] = gq.y; init[4 * qq + 2] = gq.z; init[4 * qq + 3] = gq.w;
+  }
+  auto read_a = [&](int s, Op8 (&a)[kPieces]) {
+#pragma unroll
+    for (int qq = 0; qq < kPieces; qq++) a[qq] = __builtin_bit_cast(Op8, a_blk[((s * kPieces + qq) * 2 + h) * 32 + col]);
+  };
+  Op8 a_cur[kPieces], a_nxt[kPieces];
+  read_a(0, a_cur);
+  constexpr int kProd = kHalf ? 3 : 6;
+  constexpr int pa[6] = {kHalf ? 1 : 2, kHalf ? 0 : 1, 0, 1, 0, 0}, pb[6] = {0, 1, kHalf ? 0 : 2, 0, 1, 0};
+#pragma unroll
+  for (int s = 0; s < kSteps; s++) {
+    if (s + 1 < kSteps) read_a(s + 1, a_nxt);
+#pragma unroll
+    for (int t6 = 0; t6 < kProd; t6++)
+#pragma unroll
+      for (int n = 0; n < 2; n++) {
+        const f32x16 &cin = (s == 0 && t6 == 0) ? init : acc[n];
+        if constexpr (kHalf) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[pa[t6]], b[n][s][pb[t6]], cin, 0, 0, 0);
+        else acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[pa[t6]], b[n][s][pb[t6]], cin, 0, 0, 0);
+      }
+#pragma unroll
+    for (int qq = 0; qq < kPieces; qq++) a_cur[qq] = a_nxt[qq];
+  }
+}
+
 // kPieces = 3: bf16 triples; kPieces = 2: scaled f16 pairs with the per-tile range fallback (see gmm_split_single_kernel).
 template <int kSteps, int kPieces>   // 16-k steps per row: 5 for D ≤ 40, 6 for D ≤ 48
 __global__ __launch_bounds__(256, 2) void gmm_bf16_kernel(GmmParams p) {
@@ -787,43 +825,7 @@ __global__ __launch_bounds__(256, 2) void gmm_bf16_kernel(GmmParams p) {
           const bool mine = out_col < cc0 ? out_col < n0_mine : out_col - cc0 < n1_mine;
           if (active && mine) {
             f32x16 acc[kNT];
-            {
-              f32x16 init;
-#pragma unroll
-              for (int qq = 0; qq < 4; qq++) {
-                const float4 gq = *reinterpret_cast<const float4 *>(&gc_lds[buf][8 * qq + 4 * h]);
-                init[4 * qq] = gq.x; init[4 * qq + 1] = gq.y; init[4 * qq + 2] = gq.z; init[4 * qq + 3] = gq.w;
-              }
-#pragma unroll
-              for (int n = 0; n < kNT; n++) acc[n] = init;
-            }
-            // operand pieces of step s+1 are read from LDS while step s is multiplied
-            auto read_a = [&](int s, op8 (&a)[kPieces]) {
-#pragma unroll
-              for (int qq = 0; qq < kPieces; qq++)
-                a[qq] = __builtin_bit_cast(op8, a_lds[buf][((s * kPieces + qq) * 2 + h) * 32 + col]);
-            };
-            op8 a_cur[kPieces], a_nxt[kPieces];
-            read_a(0, a_cur);
-#pragma unroll
-            for (int s = 0; s < kSteps; s++) {
-              if (s + 1 < kSteps) read_a(s + 1, a_nxt);
-              // six products per 16 k-values, smallest terms first; the two tiles alternate so that consecutive MFMAs never
-              // wait on each other's accumulator
-              constexpr int kProd = kHalf ? 3 : 6;
-              constexpr int pa[6] = {kHalf ? 1 : 2, kHalf ? 0 : 1, 0, 1, 0, 0}, pb[6] = {0, 1, kHalf ? 0 : 2, 0, 1, 0};
-#pragma unroll
-              for (int t6 = 0; t6 < kProd; t6++)
-#pragma unroll
-                for (int n = 0; n < kNT; n++) {
-                  if constexpr (kHalf)
-                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[pa[t6]], b[n][s][pb[t6]], acc[n], 0, 0, 0);
-                  else
-                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[pa[t6]], b[n][s][pb[t6]], acc[n], 0, 0, 0);
-                }
-#pragma unroll
-              for (int qq = 0; qq < kPieces; qq++) a_cur[qq] = a_nxt[qq];
-            }
+            multiply_block<kSteps, kPieces>(a_lds[buf], gc_lds[buf], b, acc, col, h);
             // ---- log-sum-exp epilogue and LDS-staged, coalesced score stores: as in score_tile
             float mx[kNT], sum[kNT];
 #pragma unroll
@@ -1293,37 +1295,7 @@ __global__ __launch_bounds__(256, 2) void gmm_split_small_kernel(GmmParams p) {
           fetch(min(jb + 1, jb1 - 1), buf ^ 1, c0, c1);
           if (active && jb < nb_mine) {
             f32x16 acc[kNT];
-            f32x16 init;
-#pragma unroll
-            for (int qq = 0; qq < 4; qq++) {
-              const float4 gq = *reinterpret_cast<const float4 *>(&gc_lds[buf][8 * qq + 4 * h]);
-              init[4 * qq] = gq.x; init[4 * qq + 1] = gq.y; init[4 * qq + 2] = gq.z; init[4 * qq + 3] = gq.w;
-            }
-            auto read_a = [&](int s, op8 (&a)[kPieces]) {
-#pragma unroll
-              for (int qq = 0; qq < kPieces; qq++)
-                a[qq] = __builtin_bit_cast(op8, a_lds[buf][((s * kPieces + qq) * 2 + h) * 32 + col]);
-            };
-            op8 a_cur[kPieces], a_nxt[kPieces];
-            read_a(0, a_cur);
-            constexpr int kProd = kHalf ? 3 : 6;
-            constexpr int pa[6] = {kHalf ? 1 : 2, kHalf ? 0 : 1, 0, 1, 0, 0}, pb[6] = {0, 1, kHalf ? 0 : 2, 0, 1, 0};
-#pragma unroll
-            for (int s = 0; s < kSteps; s++) {
-              if (s + 1 < kSteps) read_a(s + 1, a_nxt);
-#pragma unroll
-              for (int t6 = 0; t6 < kProd; t6++)
-#pragma unroll
-                for (int n = 0; n < kNT; n++) {
-                  const f32x16 &cin = (s == 0 && t6 == 0) ? init : acc[n];
-                  if constexpr (kHalf)
-                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[pa[t6]], b[n][s][pb[t6]], cin, 0, 0, 0);
-                  else
-                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[pa[t6]], b[n][s][pb[t6]], cin, 0, 0, 0);
-                }
-#pragma unroll
-              for (int qq = 0; qq < kPieces; qq++) a_cur[qq] = a_nxt[qq];
-            }
+            multiply_block<kSteps, kPieces>(a_lds[buf], gc_lds[buf], b, acc, col, h);
             // ---- per-pdf log-sum-exp.  Accumulator register r of half-wave h is row (r & 3) + 8 (r >> 2) + 4 h.
             const int colbase = (jb * kPdfs) & 31;           // first staging column of this block
 #pragma unroll
