@@ -337,7 +337,7 @@ def main():
                 if os.environ.get("MFA_GMM_BF16", "1") == "0":
                     d_ = ks_["gmm_kernel"]["derived"]
                 elif os.environ.get("MFA_GMM_F16", "1") == "0":
-                    d_ = (ks_.get("gmm_bf16_single_kernel") or ks_["gmm_bf16_kernel"])["derived"]
+                    d_ = (ks_.get("gmm_split_single_kernel_bf16") or ks_.get("gmm_bf16_single_kernel") or ks_["gmm_bf16_kernel"])["derived"]
                 else:
                     d_ = ks_["gmm_split_single_kernel_f16"]["derived"]
             traffic = float(d_["fetch_bytes_per_dispatch_raw"] + d_["write_bytes_per_dispatch"])

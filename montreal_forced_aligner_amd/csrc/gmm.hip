@@ -1,4 +1,11 @@
-// Diagonal-GMM acoustic scoring on gfx950 with exact-f32 MFMA (v_mfma_f32_32x32x2_f32).
+// Diagonal-GMM acoustic scoring on gfx950's matrix pipe.  Four kernel families in this file:
+//   gmm_kernel               exact-f32 MFMA (v_mfma_f32_32x32x2_f32): single-Gaussian pdfs, and everything under
+//                            MFA_GMM_BF16=0 — the description below is this kernel's;
+//   gmm_split_single_kernel  pdfs that are one 32-row block (17–32 Gaussians): float32 products from two f16 (or three
+//                            bf16) operand pieces on v_mfma_f32_32x32x16_{f16,bf16}, blocks shared through LDS;
+//   gmm_split_small_kernel   the 16-, 8- and 4-row slot classes as gathered virtual 32-row blocks on the same pipe;
+//   gmm_bf16_kernel          pdfs of more than 32 Gaussians: runs of blocks merged by an online log-sum-exp.
+// mfa_gmm_score_batch (end of file) decides which launches a model and the environment call for.
 // Replaces DecodableAmDiagGmmScaled::LogLikelihood / gmm_compute_likes (MFA/alignment/multiprocessing.py:846-853, :1415;
 // Kaldi gmm/decodable-am-diag-gmm.cc, VectorBase<float>::LogSumExp).
 //
@@ -585,7 +592,7 @@ __global__ __launch_bounds__(64 * kWaves, kMinWaves) void gmm_kernel(GmmParams p
 // unit time), so the kernel is organised like a GEMM: the workgroup's four wavefronts (64 frames each, x̃ split once into
 // registers: 120 VGPRs) share every 32-row block through LDS, double-buffered — while block j is multiplied out of one
 // buffer, block j+1 travels global → registers → the other buffer; one barrier per block.
-// General form (models that contain multi-block pdfs); gmm_bf16_single_kernel below is the lean form for models that do not.
+// General form (models that contain multi-block pdfs); gmm_split_single_kernel below is the lean form for single-block pdfs.
 // x̃ = [x, x²] of a wavefront's two 32-frame tiles (frames t_base + 32 n + col, clamped into the utterance), split into
 // the MFMA's B operands: b[tile][step][piece], lane = (frame col, k-half h).  kPieces = 3: bf16 triples (v = v1 + v2 + v3,
 // round to nearest even each).  kPieces = 2: f16 pairs of the column-scaled value; returns true when a scaled value
