@@ -225,11 +225,26 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
   int t = 0;
   for (; t < T && status == ST_OK; t++) {
     const float *llt = ll + (size_t)t * P;
+    // The frame's score row moves registers → LDS right before its first use, not here: on this target stores count in
+    // vmcnt like loads and retire in order, so a wait for the row (requested during the previous frame) at the top of the
+    // frame would also sit out the previous frame's back-pointer stores.  By the arc gather's wait they have long landed
+    // (5.91 → 5.80 ms per 2 048 utterances; -DVIT_STAGE_ROW_AT_TOP restores the old place).
+    auto stage_row = [&]() {
+#ifndef VIT_STAGE_ROW_AT_TOP
+      if (row_cached) {
+#pragma unroll
+        for (int r = 0; r < kPre; r++) if (lane + 64 * r < P) ll_row[lane + 64 * r] = pre[r];
+        WSYNC();
+      }
+#endif
+    };
+#ifdef VIT_STAGE_ROW_AT_TOP
     if (row_cached) {
 #pragma unroll
       for (int r = 0; r < kPre; r++) if (lane + 64 * r < P) ll_row[lane + 64 * r] = pre[r];
       WSYNC();
     }
+#endif
 #ifdef VIT_STAMPS
     stamp_acc[10] += (unsigned long long)n;   // tokens entering the frame
 #endif
@@ -357,6 +372,7 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
         const u32 a = (tan >> 7) + k;
         float w = 0.0f; int col = 0; u32 nx = 0u, nan_ = 0u;
         if (valid) { const uint4 rec = a_rec[a]; nx = rec.x; nan_ = rec.y; col = (int)rec.z; w = __uint_as_float(rec.w); }
+        stage_row();
         const double nw = valid ? cand_cost(w, tcost, score(col), p.scale) : INFINITY;
         STAMP(3);   // arc gather + score + cost
         const double seed = wave_min_f64((valid && tok == best_i) ? nw : INFINITY);  // the best token's candidates
@@ -375,6 +391,7 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
       }
     }
     if (!fast) {
+      stage_row();
       // ---------------- seed of the running cutoff: the best token's cheapest candidate.  With a single chunk it is
       // taken from the expansion's registers below; otherwise computed here.
       const bool single = n <= 64;
