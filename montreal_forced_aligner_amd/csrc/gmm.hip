@@ -1067,6 +1067,12 @@ __global__ __launch_bounds__(256, 2) void gmm_split_single_kernel(GmmParams p) {
         auto trip = [&](auto par_c, int j) {
           constexpr int par = decltype(par_c)::value;
           constexpr int buf = par;
+#if !defined(BF16_DIAG_NO_FLUSH) && !defined(GMM_FLUSH_AT_END)
+          // A full window of 32 staged columns (its last one, block j-2's, was written during the previous trip) goes to
+          // HBM at the START of a trip: stores share vmcnt with the block copy, and this way they have a whole trip to be
+          // acknowledged before landed() waits on the counter — issued at the end of a trip they were waited for at once.
+          if (active && j < n_mine && j > 1 && ((j - 2) & 31) == 31) flush(j - 2);
+#endif
 #ifndef BF16_DIAG_NO_FETCH   // timing-only builds (tools/gmm_ablation.sh): results are wrong by construction
           fetch(block_of(j + 1), buf ^ 1);                 // block j+1 (the chunk's last trip re-fetches its last block: harmless)
 #endif
@@ -1117,7 +1123,9 @@ __global__ __launch_bounds__(256, 2) void gmm_split_single_kernel(GmmParams p) {
 #ifdef BF16_DIAG_NO_FLUSH
             if (smv[0] == 12345.678f) flush(j - 1);          // timing-only build: keeps the staged values alive
 #else
+#ifdef GMM_FLUSH_AT_END
             if (j > 0 && ((j - 1) & 31) == 31) flush(j - 1);
+#endif
 #endif
           }
           landed();
@@ -1132,6 +1140,9 @@ __global__ __launch_bounds__(256, 2) void gmm_split_single_kernel(GmmParams p) {
         }
         if (active && n_mine > 0) {                          // drain: the last block's epilogue and the open columns
           const int jp = n_mine - 1;
+#if !defined(BF16_DIAG_NO_FLUSH) && !defined(GMM_FLUSH_AT_END)
+          if (jp > 0 && ((jp - 1) & 31) == 31) flush(jp - 1);   // a window completed by the last trip is still staged
+#endif
           if (jp & 1) {
 #pragma unroll
             for (int c = 0; c < kChunks; c++) epi(c, acc2[1], jp & 31);
