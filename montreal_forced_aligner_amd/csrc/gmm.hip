@@ -1299,6 +1299,7 @@ __global__ __launch_bounds__(256, 2) void gmm_split_small_kernel(GmmParams p) {
             for (int r = 0; r + w < cnt; r += 2 * w) e[r] += e[r + w];
           return e[0];
         };
+        int pending = -1;                                  // last column of a staged window waiting to be written out
         for (int c0 = 0; c0 < n_single; c0 += kBlkCache) {
         const int c1 = min(n_single, c0 + kBlkCache);
         __syncthreads();                                   // previous chunk's table is no longer read
@@ -1310,6 +1311,7 @@ __global__ __launch_bounds__(256, 2) void gmm_split_small_kernel(GmmParams p) {
         __syncthreads();
         for (int jb = jb0; jb < jb1; jb++) {
           const int buf = (jb - jb0) & 1;
+          if (pending >= 0) { flush(pending); pending = -1; }   // a block early: see "score stores" in gmm_split_single_kernel
           fetch(min(jb + 1, jb1 - 1), buf ^ 1, c0, c1);
           if (active && jb < nb_mine) {
             f32x16 acc[kNT];
@@ -1352,12 +1354,13 @@ __global__ __launch_bounds__(256, 2) void gmm_split_small_kernel(GmmParams p) {
               }
             }
             const int col_last = min((jb + 1) * kPdfs, n_mine) - 1;   // last valid column this block produced
-            if ((col_last & 31) == 31 || jb == nb_mine - 1) flush(col_last);
+            if ((col_last & 31) == 31 || jb == nb_mine - 1) pending = col_last;
           }
           landed();
           __syncthreads();                                 // block jb+1 is in place; everybody is done with block jb
         }
         }
+        if (pending >= 0) flush(pending);
       }
     }
   }
