@@ -194,6 +194,59 @@ MFA_API int mfa_align_batch(mfa_ctx *ctx, const mfa_graph_batch *graphs, const f
 /* Bytes of device workspace mfa_align_batch will hold for a batch shape (so callers can budget HBM). */
 MFA_API size_t mfa_align_workspace_bytes(mfa_ctx *ctx, int32_t n_utt, int64_t total_frames, const mfa_align_opts *opts);
 
+/* ---- Alignment from features, acoustic scores evaluated LAZILY: the same replacement as mfa_align_batch, but it takes the
+ *      features GmmAligner.align_utterance(fst, feats) takes (MFA/alignment/multiprocessing.py:846-853;
+ *      MFA/online/alignment.py:107) and scores only what Kaldi's lazy decodable would be asked for — a superset of it:
+ *      the utterance is decoded in windows of `window` frames; before a window is decoded, the pdfs that arcs within
+ *      `window` arcs of the live tokens can emit are scored for the window's frames (split-operand MFMA kernels as in
+ *      mfa_gmm_score_batch); everything else in the score matrix is left untouched and never read.  Results are those of
+ *      mfa_gmm_score_batch + mfa_align_batch bit for bit (same kernels' arithmetic per cell, same decoder).
+ * plan: the utterances' pdf lists as for mfa_gmm_score_batch plus two depth keys per pdf and per graph state
+ *   d_pdf_first_frame[j] = smallest BFS depth of a source state of the column's arcs
+ *   d_pdf_last_depth[j]  = running max, inside the column's class in list order, of the largest such depth
+ *   d_state_depth[global state][2] = {BFS depth, smallest BFS depth reachable from the state}
+ * — all three come out of mfa_build_score_plan (one call per utterance).
+ * d_loglikes [sum T_u * P_u] is caller-provided scratch for the scores (d_ll_off, d_ll_cols as for mfa_align_batch). */
+typedef struct {
+  const int32_t *d_pdf_list;
+  const int64_t *d_pdf_off;
+  const int32_t *d_class_counts;
+  const int32_t *d_pdf_first_frame;
+  const int32_t *d_pdf_last_depth;
+  const int32_t *d_state_depth;
+} mfa_score_plan;
+
+MFA_API int mfa_align_features_batch(mfa_ctx *ctx, const mfa_graph_batch *graphs, const mfa_score_plan *plan,
+                                     const float *d_feats, const int64_t *d_frame_off, int32_t max_frames,
+                                     int64_t total_frames, int64_t total_arcs, int32_t max_states, int32_t max_arcs,
+                                     const mfa_align_opts *opts, int32_t window, float *d_loglikes, const int64_t *d_ll_off,
+                                     const int32_t *d_ll_cols, int32_t *d_ali, int32_t *d_words, int32_t *d_n_words,
+                                     float *d_like, float *d_frame_like, int32_t *d_status);
+/* Host helper: h_depth[s] = the smallest BFS depth (h_bfs_depth, from mfa_fst_first_frames) among the states reachable
+ * from s, s included — computed on the graph's condensation, so self-loops and the small cycles of an ergodic silence
+ * topology are fine.  It never decreases along an arc, and it is <= the BFS depth of everything reachable from s: a state
+ * whose BFS depth is below h_depth[l] of every live token l can never be visited again.  Returns 0 for a graph that is
+ * acyclic apart from self-loops, 1 if larger components were contracted, <0 if malformed. */
+MFA_API int mfa_fst_last_depths(int32_t n_states, const int32_t *h_arc_off, const int32_t *h_arc_next, int32_t start,
+                                const int32_t *h_bfs_depth, int32_t *h_depth);
+/* Host helper: the score columns of ONE utterance's graph, in the order the scoring kernels require.
+ * In: the graph in CSR form with the pdf id of every arc (h_arc_pdf = pdf of the arc's transition-id) and the slot class
+ * of every pdf of the model, h_pdf_class[num_pdfs] in 0..5 = {32 rows single block, 32 rows multi-block, 16, 8, 4, 1}
+ * (from mfa_gmm_slot and the pdf's Gaussian count).  Returns 0, -1 for a malformed graph, -2 for a pdf id out of range.
+ * A column is a pdf restricted to a cluster of its occurrences: arcs emitting the pdf whose source states' BFS depths lie
+ * within cluster_span of the cluster's first (cluster_span <= 0: one column per pdf).  The same phone in two words thus gets
+ * two columns, and the lazy-scoring band — a range of graph depths — need not keep it alive in between.
+ * Out: h_state_depth[n_states][2] = {BFS depth, mfa_fst_last_depths value}; h_arc_col[n_arcs] = column of every arc;
+ * per column (capacity n_arcs each): h_col_pdf, h_col_first = smallest BFS depth of a source, h_col_last = running max
+ * (inside the column's slot class, in list order) of the largest BFS depth of a source; h_class_counts[6]; *h_n_cols.
+ * Band rule (mfa_align_features_batch): with lo = min over live tokens of h_state_depth[.][1] and hi = max over live
+ * tokens of h_state_depth[.][0] + window - 1, the columns a window can ask for are, in every class, the index range
+ * [count(h_col_last < lo), count(h_col_first <= hi)). */
+MFA_API int mfa_build_score_plan(int32_t n_states, const int32_t *h_arc_off, const int32_t *h_arc_next,
+                                 const int32_t *h_arc_pdf, int32_t start, int32_t num_pdfs, const int32_t *h_pdf_class,
+                                 int32_t cluster_span, int32_t *h_state_depth, int32_t *h_arc_col, int32_t *h_col_pdf,
+                                 int32_t *h_col_first, int32_t *h_col_last, int32_t *h_class_counts, int32_t *h_n_cols);
+
 /* ---- fMLLR statistics: replaces the accumulation of CalcFmllrFunction / kalpy FmllrComputer
  *      (MFA/corpus/features.py:506-527; Kaldi FmllrDiagGmmAccs) between the two alignment passes
  *      (MFA/alignment/base.py:510-539).  d_feats [total_frames][dim]: the features the transform will be applied to;

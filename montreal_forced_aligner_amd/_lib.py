@@ -39,6 +39,13 @@ class GraphBatch(C.Structure):
     ]
 
 
+class ScorePlan(C.Structure):
+    _fields_ = [
+        ("d_pdf_list", C.c_void_p), ("d_pdf_off", C.c_void_p), ("d_class_counts", C.c_void_p),
+        ("d_pdf_first_frame", C.c_void_p), ("d_pdf_last_depth", C.c_void_p), ("d_state_depth", C.c_void_p),
+    ]
+
+
 class AlignOpts(C.Structure):
     _fields_ = [
         ("beam", C.c_float), ("retry_beam", C.c_float), ("acoustic_scale", C.c_float),
@@ -95,6 +102,10 @@ SIGNATURES = {
     "mfa_gmm_score_batch": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mfa_align_batch": (C.c_int, [_vp, C.POINTER(GraphBatch), _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, C.POINTER(AlignOpts),
                                   _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mfa_align_features_batch": (C.c_int, [_vp, C.POINTER(GraphBatch), C.POINTER(ScorePlan), _vp, _vp, _i32, _i64, _i64, _i32, _i32,
+                                           C.POINTER(AlignOpts), _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mfa_fst_last_depths": (C.c_int, [_i32, _vp, _vp, _i32, _vp, _vp]),
+    "mfa_build_score_plan": (C.c_int, [_i32, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mfa_fmllr_acc_batch": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
     "mfa_align_workspace_bytes": (C.c_size_t, [_vp, _i32, _i64, C.POINTER(AlignOpts)]),
 }

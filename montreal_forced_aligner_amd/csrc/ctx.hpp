@@ -96,6 +96,22 @@ struct mfa_ctx {
     if (_e != hipSuccess) return (ctx)->fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
   } while (0)
 
+// Debug aid (environment MFA_DEBUG_SYNC=1): name every launch on stderr, wait for it and report the first failing one.
+#include <cstdlib>
+inline bool mfa_debug_sync_enabled() {
+  static const bool on = [] { const char *e = getenv("MFA_DEBUG_SYNC"); return e && e[0] == '1'; }();
+  return on;
+}
+#define MFA_DEBUG_POINT(ctx, ...)                                                                         \
+  do {                                                                                                    \
+    if (mfa_debug_sync_enabled()) {                                                                       \
+      fprintf(stderr, "[mfa] " __VA_ARGS__); fprintf(stderr, "\n"); fflush(stderr);                       \
+      hipError_t _e = hipStreamSynchronize((ctx)->stream);                                                \
+      if (_e == hipSuccess) _e = hipGetLastError();                                                       \
+      if (_e != hipSuccess) return (ctx)->fail("launch failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__); \
+    }                                                                                                     \
+  } while (0)
+
 // Scoped per-kernel timing (HIP events on the ctx stream, resolved lazily).
 struct KernelTimer {
   mfa_ctx *c; int which; hipEvent_t a = nullptr, b = nullptr;
@@ -116,3 +132,24 @@ struct KernelTimer {
 };
 
 int mfa_resolve_timers(mfa_ctx *ctx);
+
+// ---- lazy (windowed) scoring: internal interface between the decoder driver (viterbi.hip) and the scoring kernels
+// (gmm.hip).  Not part of the ABI.
+struct MfaLazyScoring {
+  mfa_score_plan plan;
+  const float *d_feats;
+  int max_frames;
+  int window;        // frames per window of the first-beam pass (multiple of 64)
+};
+struct MfaWindowScore {
+  int t_begin, window;          // frames [t_begin, t_begin + window) of every listed utterance
+  const int32_t *band;          // [n_utt][2] {min longest-path depth, max BFS depth reachable in the window}; ignored at t_begin 0
+  const int32_t *utt_list;      // utterances of this pass (NULL: all) and their count (device scalar, or NULL)
+  const int32_t *n_list;
+  const int32_t *done;          // per-utterance "finished" word: done[utt * done_stride + done_word] != 0 → skip
+  int done_stride, done_word;
+};
+int mfa_gmm_lazy_supported(mfa_ctx *ctx);   // the loaded model fits the MFMA kernels (dim <= 48)
+// Score, for every listed utterance, the (frame, pdf) cells of the window that lie inside the band.  Enqueues on ctx->stream.
+int mfa_gmm_score_window(mfa_ctx *ctx, const MfaLazyScoring *lazy, const MfaWindowScore *ws, const int64_t *d_frame_off,
+                         int n_utt, const int64_t *d_ll_off, float *d_loglikes);

@@ -71,7 +71,37 @@ struct GmmParams {
   int n_utt, tiles;    // tiles = 256-frame tiles per utterance (ceil(max_frames / 256)); items = (utterance, tile)
   int *queue;          // [0..8) phase-1 and [8..16) phase-2 per-XCD item counters; zeroed per launch
   const int *max_ff;   // largest first_frame of the batch (device scalar)
+  // ---- lazy (windowed) scoring, mfa_gmm_score_window: one wavefront scores the 64 frames [b_t_begin + 64 r, +64) of one
+  // utterance for the pdfs inside the band the decoder published for this window
+  int b_mode;                  // 1: band mode
+  int b_t_begin, b_sub;        // window start; 64-frame sub-tiles per window
+  const int32_t *b_band;       // [n_utt][2] {min longest-path depth of a live token, max BFS depth reachable in the window}
+  const int32_t *b_utt_list; const int32_t *b_n_list;
+  const int32_t *b_done; int b_done_stride, b_done_word;
+  const int32_t *last_depth;   // parallel to pdf_list: running max (inside a class) of the longest-path depth of the pdf's sources
+  int b_skip0;                 // f32 band kernel: the single-block 32-row class was scored by gmm_band_kernel
 };
+
+// Band of one (utterance, window): pdf j of a class is needed iff first_frame[j] <= hi and last_depth[j] >= lo; both keys
+// are non-decreasing along a class, so the needed pdfs are the index range [count(last_depth < lo), count(first_frame <= hi)).
+struct Band { int lo, hi; };
+__device__ __forceinline__ Band band_of(const GmmParams &p, int utt) {
+  Band b;
+  if (p.b_t_begin == 0) { b.lo = 0; b.hi = 64 * p.b_sub - 1; }   // only the start state is live: BFS depth 0
+  else { b.lo = p.b_band[2 * utt]; b.hi = p.b_band[2 * utt + 1]; }
+  return b;
+}
+// wavefront → (utterance, 64-frame sub-tile) of a band-mode launch; false: nothing to do
+__device__ __forceinline__ bool band_item(const GmmParams &p, int wave, int &utt, int &r) {
+  const int witem = blockIdx.x * 4 + wave;
+  const int item = witem / p.b_sub;
+  r = witem - item * p.b_sub;
+  const int n_items = p.b_n_list ? *p.b_n_list : p.n_utt;
+  if (item >= n_items) return false;
+  utt = p.b_utt_list ? p.b_utt_list[item] : item;
+  if (p.b_t_begin > 0 && p.b_done && p.b_done[(size_t)utt * p.b_done_stride + p.b_done_word] != 0) return false;
+  return true;
+}
 
 // row index (within a 32-row MFMA block) held by accumulator register r of a lane in half h
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
@@ -233,28 +263,31 @@ __device__ __forceinline__ void score_tile(const GmmParams &p, int utt, int t_ba
   const int32_t *list = p.pdf_list + l0;
   const int32_t *cc6 = p.class_counts + (size_t)utt * 6;
   // class_counts[u] = {32-row single-block, 32-row multi-block, 16, 8, 4, 1}
-  constexpr int first32 = 0;
   const int32_t cc[5] = {cc6[0] + cc6[1], cc6[2], cc6[3], cc6[4], cc6[5]};
   // need[c]: how many pdfs of class c this wavefront's frames can be asked for.  Without reachability information that
   // is all of them; with it, the pdfs whose first possible frame lies at or before the tile's last frame — a prefix of
   // the class, because the host ordered each class by that frame.
-  int need[6];
+  int need[6], lo_[6];
   {
-    const int t_last = min(T, t_base + kFramesPerWave) - 1 + p.ff_bias;
+    int t_last = min(T, t_base + kFramesPerWave) - 1 + p.ff_bias;
+    int d_lo = 0;
+    if (p.b_mode) { const Band bd = band_of(p, utt); t_last = bd.hi; d_lo = bd.lo; }
     int off = 0;
 #pragma unroll
     for (int cls = 0; cls < 6; cls++) {
       const int cnt = cc6[cls];
-      int nd = cnt;
+      int nd = cnt, lw = 0;
       if (p.first_frame) {
         nd = 0;
         for (int i0 = 0; i0 < cnt; i0 += 64) {
           const int i = i0 + lane;
           const bool ok = i < cnt && p.first_frame[l0 + off + i] <= t_last;
           nd += __popcll(__ballot(ok));
+          if (p.b_mode) lw += __popcll(__ballot(i < cnt && p.last_depth[l0 + off + i] < d_lo));
         }
       }
       need[cls] = nd;
+      lo_[cls] = min(lw, nd);
       off += cnt;
     }
   }
@@ -263,11 +296,13 @@ __device__ __forceinline__ void score_tile(const GmmParams &p, int utt, int t_ba
   // left for this launch
   if (p.skip_single >= 2) { need[2] = 0; need[3] = 0; need[4] = 0; }   // slots 16 / 8 / 4 went to gmm_split_small_kernel
   if (p.skip_single && need[2] + need[3] + need[4] + need[5] == 0) return;
+  if (p.b_skip0 && (need[1] - lo_[1]) + (need[2] - lo_[2]) + (need[3] - lo_[3]) + (need[4] - lo_[4]) + (need[5] - lo_[5]) == 0) return;
 
   Tile<M8, kNT> tile;
   tile.load_b(p, f0, T, t_base, lane);
   f32x16 acc[kNT];
-  const int n_single = p.skip_single ? 0 : need[0];
+  const int n_single = (p.skip_single || p.b_skip0) ? 0 : need[0];
+  const int first32 = lo_[0];   // band mode: the class-0 range starts here (0 otherwise)
 
   // ---- single-block 32-row pdfs (the bulk of a context-dependent model): one pdf per MFMA block.
   // Software pipeline, no extra registers: as soon as the MFMAs that read operand group a[m] of block j have been issued,
@@ -378,7 +413,7 @@ __device__ __forceinline__ void score_tile(const GmmParams &p, int utt, int t_ba
 
   // ---- 32-row pdfs with more than 32 Gaussians: several blocks, two passes (max, then the sum against that max)
   const int n32 = cc[0];
-  for (int j = max(first32, cc6[0]); j < cc6[0] + (p.skip_single ? 0 : need[1]); j++) {
+  for (int j = cc6[0] + lo_[1]; j < cc6[0] + (p.skip_single ? 0 : need[1]); j++) {
     const int pdf = list[j];
     const int r0 = p.row0[pdf], nb = p.nblk[pdf];
     float mx[kNT], sum[kNT];
@@ -414,7 +449,7 @@ __device__ __forceinline__ void score_tile(const GmmParams &p, int utt, int t_ba
   // ---- smaller slots: 32/slot pdfs share one MFMA block
   int base = n32;
   // slot 16
-  for (int j = 0; j < need[2]; j += 2) {
+  for (int j = lo_[2] & ~1; j < need[2]; j += 2) {
     const int which = col >> 4, within = col & 15;
     const int idx = j + which;
     const int row = idx < cc[1] ? p.row0[list[base + idx]] + within : p.num_rows;
@@ -434,7 +469,7 @@ __device__ __forceinline__ void score_tile(const GmmParams &p, int utt, int t_ba
   }
   base += cc[1];
   // slot 8
-  for (int j = 0; j < need[3]; j += 4) {
+  for (int j = lo_[3] & ~3; j < need[3]; j += 4) {
     const int which = col >> 3, within = col & 7;
     const int idx = j + which;
     const int row = idx < cc[2] ? p.row0[list[base + idx]] + within : p.num_rows;
@@ -459,7 +494,7 @@ __device__ __forceinline__ void score_tile(const GmmParams &p, int utt, int t_ba
   }
   base += cc[2];
   // slot 4: rows 8q+4h..8q+4h+3 live in registers 4q..4q+3 of one lane → pdf index 2q+h, no shuffle
-  for (int j = 0; j < need[4]; j += 8) {
+  for (int j = lo_[4] & ~7; j < need[4]; j += 8) {
     const int which = col >> 2, within = col & 3;
     const int idx = j + which;
     const int row = idx < cc[3] ? p.row0[list[base + idx]] + within : p.num_rows;
@@ -482,7 +517,7 @@ __device__ __forceinline__ void score_tile(const GmmParams &p, int utt, int t_ba
   }
   base += cc[3];
   // slot 1: every row is its own single-Gaussian pdf: LL = ll (max + log(1) exactly)
-  for (int j = 0; j < need[5]; j += 32) {
+  for (int j = lo_[5] & ~31; j < need[5]; j += 32) {
     const int idx = j + col;
     const int row = idx < cc[4] ? p.row0[list[base + idx]] : p.num_rows;
     tile.block(row_ptr(p.w, p.kpad, row, h), p.gc[row], lane, acc);
@@ -1366,6 +1401,145 @@ __global__ __launch_bounds__(256, 2) void gmm_split_small_kernel(GmmParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Lazy (windowed) scoring — mfa_gmm_score_window.  Kaldi evaluates its decodable lazily: a score exists only if a live
+// token's arc asked for it.  The dense kernels above score every pdf of the utterance's graph for every frame from the
+// pdf's first reachable frame on — measured, ≈9× more cells than the decoder reads.  Here the decoder runs in windows of
+// K frames and publishes, at each window end, the band of graph depths its live tokens can reach within K arcs; the
+// kernel below scores, for the window's frames, only the pdfs whose arcs leave states inside that band.
+//
+// With so few frames per (utterance, pdf) there is nothing to share a model block across: one wavefront owns one
+// (utterance, 64-frame sub-tile), keeps its x̃ operands in registers (as above) and streams the band's model blocks
+// straight from L2 / Infinity Cache into its A registers — 10 coalesced 1 KiB loads per 32-row block, each operand
+// register re-loaded for the next block as soon as the MFMAs that read it have been issued.  Per block: 30 (60) MFMAs,
+// the log-sum-exp, one staged score column.  Arithmetic per cell is that of gmm_split_single_kernel exactly (same operand
+// split, same product order, same epilogue expressions): a cell scored here is bit-identical to the dense kernel's.
+// Bound: the 10 KiB (15 KiB) of operands per block and 64 frames — fabric bandwidth, not the matrix pipe.
+template <int kSteps, int kPieces>
+__global__ __launch_bounds__(256, 2) void gmm_band_kernel(GmmParams p) {
+  constexpr bool kHalf = kPieces == 2;
+  using op8 = std::conditional_t<kHalf, f16x8, bf16x8>;
+  constexpr int kUnits = kSteps * kPieces * 2 * 32;    // 16-byte units per block
+  __shared__ float stage_all[4][64 * 33];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float *stage = stage_all[wave];
+  int utt, r;
+  if (!band_item(p, wave, utt, r)) return;
+  const int64_t f0 = p.frame_off[utt];
+  const int T = (int)(p.frame_off[utt + 1] - f0);
+  const int t_base = p.b_t_begin + 64 * r;
+  if (t_base >= T) return;
+  int *redo_flag = p.redo + (size_t)utt * p.b_sub + r;
+  if (!kHalf && p.redo_mode == 2 && *redo_flag == 0) return;          // only what the f16 pass declined
+  const int col = lane & 31, h = lane >> 5;
+  const int64_t l0 = p.pdf_off[utt];
+  const int P = (int)(p.pdf_off[utt + 1] - l0);
+  const int32_t *list = p.pdf_list + l0;
+  const int n_all = p.class_counts[(size_t)utt * 6];
+  const Band bd = band_of(p, utt);
+  int hi = 0, lo = 0;
+  for (int i0 = 0; i0 < n_all; i0 += 64) {
+    const int i = i0 + lane;
+    hi += __popcll(__ballot(i < n_all && p.first_frame[l0 + i] <= bd.hi));
+    lo += __popcll(__ballot(i < n_all && p.last_depth[l0 + i] < bd.lo));
+  }
+  if (lo >= hi) { if (kHalf && lane == 0) *redo_flag = 0; return; }
+  op8 b[2][kSteps][kPieces];
+  const bool bad = split_features<kSteps, kPieces>(p, f0, T, t_base, col, h, b);
+  if constexpr (kHalf) {
+    const bool any_bad = __ballot(bad) != 0ull;
+    if (lane == 0) *redo_flag = any_bad ? 1 : 0;
+    if (any_bad) return;                                               // a scaled feature left the f16 range: bf16×3 pass
+  }
+  const uint4 *wsrc = (kHalf ? p.wh : p.wb) + lane;
+  const float *gsrc = (kHalf ? p.gch : p.gc) + 4 * h;
+  const float inv_s = kHalf ? p.acc_scale_inv : 1.0f;
+  const float l2e_s = 1.44269504088896341f * inv_s;
+  float *out = p.out + p.ll_off[utt];
+  const int last = hi - 1;
+  auto block_at = [&](int jj) { return __builtin_amdgcn_readfirstlane(p.row0[list[min(jj, last)]]) >> 5; };
+  op8 a[kSteps][kPieces];
+  f32x4 g[4];
+  {
+    const int blk = block_at(lo);
+    const uint4 *src = wsrc + (size_t)blk * kUnits;
+#pragma unroll
+    for (int q = 0; q < 4; q++) g[q] = *reinterpret_cast<const f32x4 *>(gsrc + (size_t)blk * 32 + 8 * q);
+#pragma unroll
+    for (int s_ = 0; s_ < kSteps; s_++)
+#pragma unroll
+      for (int q = 0; q < kPieces; q++) a[s_][q] = __builtin_bit_cast(op8, src[(s_ * kPieces + q) * 64]);
+  }
+  int blk_next = block_at(lo + 1);
+  constexpr int kProd = kHalf ? 3 : 6;
+  constexpr int pa[6] = {kHalf ? 1 : 2, kHalf ? 0 : 1, 0, 1, 0, 0}, pb[6] = {0, 1, kHalf ? 0 : 2, 0, 1, 0};
+  auto flush = [&](int jdone) {                        // columns [jdone − (jdone − lo)%32, jdone] of the staged scores → HBM
+    const int jj = (jdone - lo) & 31;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int j0 = jdone - jj, cnt = jj + 1;
+#pragma unroll 4
+    for (int i = 0; i < 32; i++) {
+      const int rr = h + 2 * i, t = t_base + rr;
+      if (col < cnt && t < T) __builtin_nontemporal_store(stage[rr * 33 + col], &out[(size_t)t * P + j0 + col]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
+  for (int j = lo; j < hi; j++) {
+    const int x_next2 = p.row0[list[min(j + 2, last)]];        // lookup two blocks ahead (oldest entry of the vmcnt queue)
+    f32x16 init, acc[2];
+#pragma unroll
+    for (int rr = 0; rr < 16; rr++) init[rr] = g[rr >> 2][rr & 3];
+    const uint4 *src = wsrc + (size_t)blk_next * kUnits;
+    const float *gn = gsrc + (size_t)blk_next * 32;
+#pragma unroll
+    for (int s_ = 0; s_ < kSteps; s_++) {
+#pragma unroll
+      for (int t6 = 0; t6 < kProd; t6++)
+#pragma unroll
+        for (int n = 0; n < 2; n++) {
+          const f32x16 &cin = (s_ == 0 && t6 == 0) ? init : acc[n];
+          if constexpr (kHalf) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s_][pa[t6]], b[n][s_][pb[t6]], cin, 0, 0, 0);
+          else acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s_][pa[t6]], b[n][s_][pb[t6]], cin, 0, 0, 0);
+        }
+      // this step's operand registers (and, after the first step, the gconst registers) are free: next block's rows
+      if (s_ == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) g[q] = *reinterpret_cast<const f32x4 *>(gn + 8 * q);
+      }
+#pragma unroll
+      for (int q = 0; q < kPieces; q++) a[s_][q] = __builtin_bit_cast(op8, src[(s_ * kPieces + q) * 64]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    blk_next = __builtin_amdgcn_readfirstlane(x_next2) >> 5;
+    float mx[2], sum[2];
+#pragma unroll
+    for (int n = 0; n < 2; n++) {
+      float m = reg_max<0, 16>(acc[n]);
+      m = fmaxf(m, swap32(m, h));
+      float sv = reg_expsum_fast(acc[n], m, l2e_s);
+      sv += swap32(sv, h);
+      mx[n] = m; sum[n] = sv;
+    }
+    const int jj = (j - lo) & 31;
+    stage[(32 * h + col) * 33 + jj] = finish((h ? mx[1] : mx[0]) * inv_s, h ? sum[1] : sum[0]);
+    if (jj == 31 || j == last) flush(j);
+  }
+}
+
+// Band-mode launch of the f32 kernel's tile walk: whatever slot classes gmm_band_kernel does not cover (single-Gaussian
+// pdfs — bit-exact —, the 16/8/4-row classes, pdfs of more than 32 Gaussians; everything under MFA_GMM_BF16=0).
+template <int M8>
+__global__ __launch_bounds__(256, 2) void gmm_band_f32_kernel(GmmParams p) {
+  __shared__ float stage_all[4][64 * 33];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int utt, r;
+  if (!band_item(p, wave, utt, r)) return;
+  score_tile<M8, 2>(p, utt, p.b_t_begin + 64 * r, lane, stage_all[wave], 0);
+}
+
 // max over the batch of the pdfs' first possible frames → *max_ff (the persistent kernel derives its phase split from it)
 __global__ void gmm_max_first_frame_kernel(const int32_t *first_frame, const int64_t *pdf_off, int n_utt, int *out) {
   const int64_t n = pdf_off[n_utt];
@@ -1636,6 +1810,136 @@ MFA_API int mfa_fst_first_frames(int32_t n_states, const int32_t *h_arc_off, con
   return 0;
 }
 
+MFA_API int mfa_fst_last_depths(int32_t n_states, const int32_t *h_arc_off, const int32_t *h_arc_next, int32_t start,
+                                const int32_t *h_bfs_depth, int32_t *h_depth) {
+  if (n_states <= 0 || start < 0 || start >= n_states) return -1;
+  for (int a = 0; a < h_arc_off[n_states]; a++)
+    if (h_arc_next[a] < 0 || h_arc_next[a] >= n_states) return -1;
+  // h_depth[s] = the smallest BFS depth among the states reachable from s (s included).  Computed over the graph's
+  // condensation: strongly connected components (self-loops, the small cycles of an ergodic silence topology) come out of
+  // Tarjan's algorithm (iterative) in reverse topological order, i.e. sinks first — exactly the order this needs.
+  std::vector<int32_t> index(n_states, -1), low(n_states, 0), comp(n_states, -1), stack, next_arc(n_states, 0);
+  std::vector<char> on_stack(n_states, 0);
+  std::vector<int32_t> call;   // DFS stack of states
+  int32_t counter = 0, n_comp = 0;
+  call.push_back(start);
+  index[start] = low[start] = counter++;
+  stack.push_back(start); on_stack[start] = 1;
+  next_arc[start] = h_arc_off[start];
+  std::vector<int32_t> comp_first;   // members of component k: comp_members[comp_first[k] .. comp_first[k+1])
+  std::vector<int32_t> comp_members;
+  while (!call.empty()) {
+    const int s = call.back();
+    if (next_arc[s] < h_arc_off[s + 1]) {
+      const int d = h_arc_next[next_arc[s]++];
+      if (index[d] < 0) {
+        index[d] = low[d] = counter++;
+        stack.push_back(d); on_stack[d] = 1;
+        next_arc[d] = h_arc_off[d];
+        call.push_back(d);
+      } else if (on_stack[d]) {
+        low[s] = std::min(low[s], index[d]);
+      }
+    } else {
+      call.pop_back();
+      if (!call.empty()) low[call.back()] = std::min(low[call.back()], low[s]);
+      if (low[s] == index[s]) {
+        comp_first.push_back((int32_t)comp_members.size());
+        for (;;) {
+          const int v = stack.back(); stack.pop_back(); on_stack[v] = 0;
+          comp[v] = n_comp;
+          comp_members.push_back(v);
+          if (v == s) break;
+        }
+        n_comp++;
+      }
+    }
+  }
+  comp_first.push_back((int32_t)comp_members.size());
+  // an arc s -> d between different components has comp[d] < comp[s]: ascending component order visits successors first
+  std::vector<int32_t> cmin(n_comp, INT32_MAX);
+  bool cyclic = false;
+  for (int k = 0; k < n_comp; k++) {
+    if (comp_first[k + 1] - comp_first[k] > 1) cyclic = true;
+    int32_t m = INT32_MAX;
+    for (int i = comp_first[k]; i < comp_first[k + 1]; i++) {
+      const int s = comp_members[i];
+      m = std::min(m, h_bfs_depth[s]);
+      for (int a = h_arc_off[s]; a < h_arc_off[s + 1]; a++) {
+        const int cd = comp[h_arc_next[a]];
+        if (cd != k) m = std::min(m, cmin[cd]);
+      }
+    }
+    cmin[k] = m;
+  }
+  for (int s = 0; s < n_states; s++) h_depth[s] = comp[s] >= 0 ? cmin[comp[s]] : 0;
+  return cyclic ? 1 : 0;
+}
+
+// Score columns of one utterance for mfa_align_features_batch / mfa_gmm_score_batch — see include/mfa_hip.h.
+MFA_API int mfa_build_score_plan(int32_t n_states, const int32_t *h_arc_off, const int32_t *h_arc_next,
+                                 const int32_t *h_arc_pdf, int32_t start, int32_t num_pdfs, const int32_t *h_pdf_class,
+                                 int32_t cluster_span, int32_t *h_state_depth, int32_t *h_arc_col, int32_t *h_col_pdf,
+                                 int32_t *h_col_first, int32_t *h_col_last, int32_t *h_class_counts, int32_t *h_n_cols) {
+  if (n_states <= 0 || start < 0 || start >= n_states) return -1;
+  const int n_arcs = h_arc_off[n_states];
+  std::vector<int32_t> bfs(n_states), low(n_states);
+  if (mfa_fst_first_frames(n_states, h_arc_off, h_arc_next, start, bfs.data()) != 0) return -1;
+  if (mfa_fst_last_depths(n_states, h_arc_off, h_arc_next, start, bfs.data(), low.data()) < 0) return -1;
+  for (int s = 0; s < n_states; s++) {
+    h_state_depth[2 * s] = bfs[s] == INT32_MAX ? 0 : bfs[s];
+    h_state_depth[2 * s + 1] = bfs[s] == INT32_MAX ? 0 : low[s];
+  }
+  // arcs by (pdf, BFS depth of the source state); a column = a run of one pdf's arcs whose depths stay within
+  // cluster_span of the run's first (cluster_span <= 0: one column per pdf)
+  std::vector<int32_t> src(n_arcs), order(n_arcs);
+  for (int s = 0; s < n_states; s++)
+    for (int a = h_arc_off[s]; a < h_arc_off[s + 1]; a++) src[a] = s;
+  for (int a = 0; a < n_arcs; a++) {
+    order[a] = a;
+    if (h_arc_pdf[a] < 0 || h_arc_pdf[a] >= num_pdfs) return -2;
+    if (h_pdf_class[h_arc_pdf[a]] < 0 || h_pdf_class[h_arc_pdf[a]] > 5) return -2;
+  }
+  std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
+    if (h_arc_pdf[x] != h_arc_pdf[y]) return h_arc_pdf[x] < h_arc_pdf[y];
+    return bfs[src[x]] < bfs[src[y]];
+  });
+  struct Col { int32_t pdf, first, last, cls; };
+  std::vector<Col> cols;
+  std::vector<int32_t> col_of_arc(n_arcs);
+  for (int i = 0; i < n_arcs; i++) {
+    const int a = order[i], pdf = h_arc_pdf[a], d = bfs[src[a]];
+    const bool fresh = cols.empty() || cols.back().pdf != pdf ||
+                       (cluster_span > 0 && ((int64_t)d - cols.back().first > cluster_span));
+    if (fresh) cols.push_back({pdf, d, d, h_pdf_class[pdf]});
+    cols.back().last = std::max(cols.back().last, d);
+    col_of_arc[a] = (int32_t)cols.size() - 1;
+  }
+  // kernel order: slot class, then ascending first depth (ties: pdf id, then depth — the creation order)
+  const int n_cols = (int)cols.size();
+  std::vector<int32_t> perm(n_cols), rank(n_cols);
+  for (int i = 0; i < n_cols; i++) perm[i] = i;
+  std::stable_sort(perm.begin(), perm.end(), [&](int32_t x, int32_t y) {
+    if (cols[x].cls != cols[y].cls) return cols[x].cls < cols[y].cls;
+    return cols[x].first < cols[y].first;
+  });
+  for (int k = 0; k < 6; k++) h_class_counts[k] = 0;
+  int32_t run_cls = -1, run_max = 0;
+  for (int i = 0; i < n_cols; i++) {
+    const Col &cl = cols[perm[i]];
+    rank[perm[i]] = i;
+    h_col_pdf[i] = cl.pdf;
+    h_col_first[i] = cl.first;
+    if (cl.cls != run_cls) { run_cls = cl.cls; run_max = cl.last; }
+    run_max = std::max(run_max, cl.last);
+    h_col_last[i] = run_max;            // running max inside the class: non-decreasing along the list
+    h_class_counts[cl.cls]++;
+  }
+  for (int a = 0; a < n_arcs; a++) h_arc_col[a] = rank[col_of_arc[a]];
+  *h_n_cols = n_cols;
+  return 0;
+}
+
 MFA_API int mfa_debug_gmm_trace(mfa_ctx *c, void *d_trace) {
   c->gmm_trace = d_trace;
   return 0;
@@ -1649,6 +1953,7 @@ MFA_API int mfa_gmm_score_batch(mfa_ctx *c, const float *d_feats, const int64_t 
   if (n_utt <= 0 || max_frames <= 0) return 0;
   if (n_utt > 65535) return c->fail("at most 65535 utterances per scoring launch (got %d)", n_utt);
   GmmParams p;
+  memset(&p, 0, sizeof(p));   // every field this function does not set (the band-mode ones) must read as "off"
   p.dim = c->dim; p.kpad = c->kpad; p.num_rows = c->num_rows;
   p.w = c->d_w; p.gc = c->d_gc; p.row0 = c->d_row0; p.nblk = c->d_nblk; p.slot = c->d_slot;
   p.feats = d_feats; p.frame_off = d_frame_off; p.pdf_list = d_pdf_list; p.pdf_off = d_pdf_off;
@@ -1771,7 +2076,66 @@ MFA_API int mfa_gmm_score_batch(mfa_ctx *c, const float *d_feats, const int64_t 
     else hipLaunchKernelGGL((gmm_kernel<12, 2, 2, 4>), grid, dim3(256), 0, c->stream, p);
   }
   MFA_HIP_CHECK(c, hipGetLastError());
+  MFA_DEBUG_POINT(c, "dense scoring of %d utterances", n_utt);
   return 0;
 }
 
 }  // extern "C"
+
+int mfa_gmm_lazy_supported(mfa_ctx *c) { return c->gmm_ready && (c->kpad == 80 || c->kpad == 96); }
+
+int mfa_gmm_score_window(mfa_ctx *c, const MfaLazyScoring *lazy, const MfaWindowScore *ws, const int64_t *d_frame_off,
+                         int n_utt, const int64_t *d_ll_off, float *d_loglikes) {
+  if (!c->gmm_ready) return c->fail("mfa_load_gmm has not been called");
+  if (!mfa_gmm_lazy_supported(c)) return c->fail("lazy scoring needs a model of at most 48 dimensions");
+  if (ws->window <= 0 || ws->window % 64 != 0) return c->fail("scoring window must be a multiple of 64 frames");
+  GmmParams p;
+  memset(&p, 0, sizeof(p));
+  p.dim = c->dim; p.kpad = c->kpad; p.num_rows = c->num_rows;
+  p.w = c->d_w; p.gc = c->d_gc; p.row0 = c->d_row0; p.nblk = c->d_nblk; p.slot = c->d_slot;
+  p.feats = lazy->d_feats; p.frame_off = d_frame_off; p.pdf_list = lazy->plan.d_pdf_list; p.pdf_off = lazy->plan.d_pdf_off;
+  p.class_counts = lazy->plan.d_class_counts; p.ll_off = d_ll_off; p.out = d_loglikes;
+  p.min_log_diff = logf(1.1920928955078125e-07f);
+  p.first_frame = lazy->plan.d_pdf_first_frame; p.last_depth = lazy->plan.d_pdf_last_depth;
+  p.n_utt = n_utt; p.tiles = 0;
+  p.acc_scale_inv = 1.0f;
+  p.b_mode = 1; p.b_t_begin = ws->t_begin; p.b_sub = ws->window / 64; p.b_band = ws->band;
+  p.b_utt_list = ws->utt_list; p.b_n_list = ws->n_list;
+  p.b_done = ws->done; p.b_done_stride = ws->done_stride; p.b_done_word = ws->done_word;
+  const int64_t waves = (int64_t)n_utt * p.b_sub;
+  const dim3 grid((unsigned)((waves + 3) / 4));
+  const int m8 = c->kpad / 8;
+  const char *bf = getenv("MFA_GMM_BF16");
+  const char *hf = getenv("MFA_GMM_F16");
+  KernelTimer kt(c, MFA_K_GMM);
+  if (!(bf && bf[0] == '0') && c->d_wb && c->has_single32) {
+    const bool f16_ok = !(hf && hf[0] == '0') && c->d_wh;
+    if (c->gmm_redo_cap < waves) {
+      if (c->d_gmm_redo) { MFA_HIP_CHECK(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->d_gmm_redo); }
+      c->d_gmm_redo = nullptr; c->gmm_redo_cap = 0;
+      MFA_HIP_CHECK(c, hipMalloc((void **)&c->d_gmm_redo, waves * sizeof(int)));
+      c->gmm_redo_cap = waves;
+    }
+    p.redo = c->d_gmm_redo;
+    p.wb = (const uint4 *)c->d_wb;
+    if (f16_ok) {
+      p.wh = (const uint4 *)c->d_wh; p.gch = c->d_gch; p.fscale = c->d_fscale;
+      p.acc_scale_inv = 1.0f / c->gmm_acc_scale;
+      p.redo_mode = 0;
+      if (m8 == 10) hipLaunchKernelGGL((gmm_band_kernel<5, 2>), grid, dim3(256), 0, c->stream, p);
+      else hipLaunchKernelGGL((gmm_band_kernel<6, 2>), grid, dim3(256), 0, c->stream, p);
+      p.redo_mode = 2;   // the sub-tiles the f16 pass flagged
+    }
+    if (m8 == 10) hipLaunchKernelGGL((gmm_band_kernel<5, 3>), grid, dim3(256), 0, c->stream, p);
+    else hipLaunchKernelGGL((gmm_band_kernel<6, 3>), grid, dim3(256), 0, c->stream, p);
+    p.redo_mode = 0;
+    p.b_skip0 = 1;
+  }
+  const bool only_single32 = c->all_single_block && !c->has_multi_block;
+  if (!(p.b_skip0 && only_single32)) {
+    if (m8 <= 10) hipLaunchKernelGGL((gmm_band_f32_kernel<10>), grid, dim3(256), 0, c->stream, p);
+    else hipLaunchKernelGGL((gmm_band_f32_kernel<12>), grid, dim3(256), 0, c->stream, p);
+  }
+  MFA_HIP_CHECK(c, hipGetLastError());
+  return 0;
+}

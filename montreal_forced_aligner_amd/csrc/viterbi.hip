@@ -19,6 +19,7 @@
 // per-utterance HBM workspace (288 GB lets every in-flight utterance keep its own).  No MFMA: this is min-plus DP.
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 
 #include <algorithm>
 #include <vector>
@@ -41,6 +42,9 @@ constexpr int kMaxArcsPerState = 1 << kArcBits;
 
 enum { ST_OK = 0, ST_RETRIED = 1, ST_FAILED = 2, ST_TOKEN_OVERFLOW = 3, ST_BP_OVERFLOW = 4, ST_UNSUPPORTED = 5, ST_INTERNAL = 6, ST_PENDING = -1, ST_GROW = -2 };
 
+// decoder state of one utterance between two windows (the token list itself is parked in w_state / w_cost)
+struct VitState { int32_t n, cur, done, pad0; u32 H, pad1; u64 bp_used; };
+
 struct VitParams {
   mfa_graph_batch g;
   const float *ll; const int64_t *ll_off; const int32_t *ll_cols; const int64_t *frame_off;
@@ -60,6 +64,12 @@ struct VitParams {
   const uint4 *w_arcnext;              // [total_arcs] {next, (arc_off[next] << 7) | out-degree(next), col, weight}, built once per call
   unsigned long long *stamps;          // -DVIT_STAMPS builds: per-utterance phase cycles (mfa_debug_viterbi_stamps) or NULL
   int llcap;                           // score-row cache capacity in LDS (floats); rows longer than this are read from HBM
+  // windowed (resumable) decoding — mfa_align_features_batch: one launch decodes frames [t_begin, t_end) of every utterance,
+  // parks the live token list in the HBM workspace and leaves the band of graph depths the NEXT window can touch
+  int windowed, t_begin, t_end, next_window;
+  VitState *w_vstate;                  // [n_utt]
+  const int32_t *state_depth;          // [total_states][2] {fewest arcs from start, most arcs from start} (mfa_score_plan)
+  int32_t *band;                       // [n_utt][2] out: {min longest-path depth of a live token, max BFS depth + next_window - 1}
   // outputs
   int32_t *ali; int32_t *words; int32_t *n_words; float *like; float *frame_like; int32_t *status;
 };
@@ -201,29 +211,48 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
   int status = ST_OK;
   const int start = p.g.d_start[utt];
   if (S <= 0 || start < 0 || start >= S || T <= 0) status = ST_FAILED;
-  // InitDecoding: one token at the start state with cost 0 (graphs are epsilon-free: ProcessNonemitting is a no-op)
+  const bool resume = p.windowed && p.t_begin > 0;
   int cur = 0, n = 1;
-  if (lane == 0) {
-    const int s0 = start < 0 || start >= S ? 0 : start;
-    l_state0[0] = (u32)s0; l_cost0[0] = 0.0;
-    l_an0[0] = S > 0 ? ((u32)arc_off[s0] << 7) | (u32)(arc_off[s0 + 1] - arc_off[s0]) : 0u;
+  u32 H = p.pass == 0 ? 1000u : p.w_hash[utt];
+  u64 bp_used = 0;
+  int t = 0;
+  // token lists parked in HBM between windows (the kListsInLds = false variant keeps them there all the time)
+  u32 *park_state = p.w_state + (size_t)utt * 2 * N;
+  u32 *park_an = p.w_state + (size_t)p.g.n_utt * 2 * N + (size_t)utt * 2 * N;
+  double *park_cost = p.w_cost + (size_t)utt * 2 * N;
+  if (!resume) {
+    // InitDecoding: one token at the start state with cost 0 (graphs are epsilon-free: ProcessNonemitting is a no-op)
+    if (lane == 0) {
+      const int s0 = start < 0 || start >= S ? 0 : start;
+      l_state0[0] = (u32)s0; l_cost0[0] = 0.0;
+      l_an0[0] = S > 0 ? ((u32)arc_off[s0] << 7) | (u32)(arc_off[s0 + 1] - arc_off[s0]) : 0u;
+    }
+  } else {
+    const VitState vs = p.w_vstate[utt];
+    if (vs.done) return;                           // finished (or failed) in an earlier window: outputs are final
+    n = vs.n; H = vs.H; bp_used = vs.bp_used; t = p.t_begin;
+    if (n < 0 || n > N) { n = 0; status = ST_INTERNAL; }
+    if (kListsInLds) {
+      cur = 0;
+      for (int i = lane; i < n; i += 64) { l_state0[i] = park_state[i]; l_an0[i] = park_an[i]; l_cost0[i] = park_cost[i]; }
+    } else {
+      cur = vs.cur & 1;
+    }
   }
+  const int t_stop = p.windowed ? min(T, p.t_end) : T;
   // score rows are staged through LDS one frame ahead (registers hold row t+1 while frame t is processed)
   constexpr int kPre = 8;
   const bool row_cached = P <= p.llcap && P <= 64 * kPre;
   float pre[kPre];
 #pragma unroll
-  for (int r = 0; r < kPre; r++) pre[r] = (row_cached && T > 0 && lane + 64 * r < P) ? ll[lane + 64 * r] : 0.0f;
-  u32 H = p.pass == 0 ? 1000u : p.w_hash[utt];
-  u64 bp_used = 0;
+  for (int r = 0; r < kPre; r++) pre[r] = (row_cached && t < T && lane + 64 * r < P) ? ll[(size_t)t * P + lane + 64 * r] : 0.0f;
   WSYNC();
 
 #ifdef VIT_STAMPS
   unsigned long long stamp_acc[12] = {0}, stamp_last;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
 #endif
-  int t = 0;
-  for (; t < T && status == ST_OK; t++) {
+  for (; t < t_stop && status == ST_OK; t++) {
     const float *llt = ll + (size_t)t * P;
     // The frame's score row moves registers → LDS right before its first use, not here: on this target stores count in
     // vmcnt like loads and retire in order, so a wait for the row (requested during the previous frame) at the top of the
@@ -261,7 +290,7 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
     // prefetch issued before the arc gather would have to land before the gather's wait returns); it then has the
     // claim / order / write phases and the next GetCutoff to arrive.
     auto prefetch_next_row = [&]() {
-      if (row_cached && t + 1 < T) {
+      if (row_cached && t + 1 < t_stop) {   // (rows past the window are not scored yet)
         const float *nx_row = llt + P;
 #pragma unroll
         for (int r = 0; r < kPre; r++) if (lane + 64 * r < P) pre[r] = nx_row[lane + 64 * r];
@@ -584,9 +613,44 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
   if (lane == 0 && p.pass == 0 && p.stamps) for (int k = 0; k < 12; k++) p.stamps[(size_t)utt * 12 + k] = stamp_acc[k];
 #endif
   __threadfence_block();  // back-pointer records (HBM) are read back by the traceback below
-  if (p.pass == 0 && lane == 0) p.w_hash[utt] = H;
   u32 *c_state = l_state0 + cur * N;
   double *c_cost = l_cost0 + cur * N;
+  if (p.windowed && status == ST_OK && t < T && n > 0) {
+    // ---------------- end of a window, utterance not finished: park the token list and publish the band of depths the
+    // next window's frames can reach.  A token on state s at frame t' >= t descends from a live token l of frame t, so
+    //   bfs_depth(s) <= bfs_depth(l) + (t' - t)   and   longest_depth(s) >= longest_depth(l):
+    // a pdf can be asked for in [t, t + K) only if some arc emitting it leaves a state inside those two bounds.
+    const u32 *c_an = l_an0 + cur * N;
+    u32 dmax = 0, dmin_inv = 0;   // max of bfs depth; max of ~longest (= min of longest)
+    for (int i = lane; i < n; i += 64) {
+      const u32 s_ = c_state[i];
+      if (kListsInLds) { park_state[i] = s_; park_an[i] = c_an[i]; park_cost[i] = c_cost[i]; }
+      if (p.state_depth) {
+        const int32_t *sd = p.state_depth + 2 * (so + (int64_t)s_);
+        dmax = max(dmax, (u32)sd[0]);
+        dmin_inv = max(dmin_inv, ~(u32)sd[1]);
+      }
+    }
+    dmax = wave_max_u32(dmax);
+    dmin_inv = wave_max_u32(dmin_inv);
+    if (lane == 0) {
+      VitState vs;
+      vs.n = n; vs.cur = kListsInLds ? 0 : cur; vs.done = 0; vs.pad0 = 0; vs.H = H; vs.pad1 = 0; vs.bp_used = bp_used;
+      p.w_vstate[utt] = vs;
+      if (p.band) {
+        const long long hi = (long long)dmax + (long long)p.next_window - 1;
+        p.band[2 * utt] = p.state_depth ? (int32_t)~dmin_inv : 0;
+        p.band[2 * utt + 1] = p.state_depth ? (int32_t)min(hi, (long long)INT32_MAX) : INT32_MAX;
+      }
+    }
+    return;
+  }
+  if (p.windowed && lane == 0) {   // finished one way or the other: later windows of this pass skip the utterance
+    VitState vs;
+    vs.n = 0; vs.cur = 0; vs.done = 1; vs.pad0 = 0; vs.H = H; vs.pad1 = 0; vs.bp_used = bp_used;
+    p.w_vstate[utt] = vs;
+  }
+  if (p.pass == 0 && lane == 0) p.w_hash[utt] = H;
 
   // ---------------- ReachedFinal / best final token (first in list order on ties)
   int32_t out_status = status;
@@ -710,7 +774,7 @@ size_t lds_bytes(int S, int N, int C, bool lists_in_lds) {
 constexpr size_t kLdsLimit = 160 * 1024;
 
 struct WsLayout {
-  size_t arcnext, state, cost, sta, stb, stkey, bp, tokoff, hash, list, count, total;
+  size_t arcnext, state, cost, sta, stb, stkey, bp, tokoff, hash, list, count, vstate, band, total;
 };
 WsLayout ws_layout(int n_utt, int64_t total_frames, int N, int C, int bpf, int64_t total_arcs) {
   WsLayout w; size_t o = 0;
@@ -726,6 +790,8 @@ WsLayout ws_layout(int n_utt, int64_t total_frames, int N, int C, int bpf, int64
   w.hash = take((size_t)n_utt * 4);
   w.list = take((size_t)n_utt * 4);
   w.count = take(256);
+  w.vstate = take((size_t)n_utt * sizeof(VitState));
+  w.band = take((size_t)n_utt * 2 * 4);
   w.total = o;
   return w;
 }
@@ -762,10 +828,16 @@ MFA_API size_t mfa_align_workspace_bytes(mfa_ctx *c, int32_t n_utt, int64_t tota
                    (int64_t)n_utt * 8 * N).total;
 }
 
-MFA_API int mfa_align_batch(mfa_ctx *c, const mfa_graph_batch *g, const float *d_loglikes, const int64_t *d_ll_off,
-                            const int32_t *d_ll_cols, const int64_t *d_frame_off, int64_t total_frames,
-                            int64_t total_arcs, int32_t max_states, int32_t max_arcs, const mfa_align_opts *o, int32_t *d_ali, int32_t *d_words, int32_t *d_n_words,
-                            float *d_like, float *d_frame_like, int32_t *d_status) {
+}  // extern "C"
+
+namespace {
+
+// Shared driver of mfa_align_batch (scores given) and mfa_align_features_batch (lazy: `lazy` non-NULL — every pass is a
+// loop over windows of `window` frames: score the cells the live tokens can reach, then decode the window).
+int align_impl(mfa_ctx *c, const mfa_graph_batch *g, const float *d_loglikes, const int64_t *d_ll_off,
+               const int32_t *d_ll_cols, const int64_t *d_frame_off, int64_t total_frames,
+               int64_t total_arcs, int32_t max_states, int32_t max_arcs, const mfa_align_opts *o, int32_t *d_ali, int32_t *d_words, int32_t *d_n_words,
+               float *d_like, float *d_frame_like, int32_t *d_status, const MfaLazyScoring *lazy) {
   MFA_HIP_CHECK(c, hipSetDevice(c->device));
   const int n_utt = g->n_utt;
   if (n_utt <= 0) return 0;
@@ -816,6 +888,7 @@ MFA_API int mfa_align_batch(mfa_ctx *c, const mfa_graph_batch *g, const float *d
     size_t lds = lds_bytes(max_states, L.N, L.C, lists_in_lds);
     if (lds > kLdsLimit) return c->fail("Viterbi tables need %zu bytes of LDS (> 160 KiB): %d states, %d tokens", lds, max_states, L.N);
     VitParams p;
+    memset(&p, 0, sizeof(p));
     p.g = *g; p.ll = d_loglikes; p.ll_off = d_ll_off; p.ll_cols = d_ll_cols; p.frame_off = d_frame_off;
     p.beam = ps == 0 ? o->beam : o->retry_beam; p.scale = o->acoustic_scale;
     p.nmax = L.N; p.cmax = L.C; p.bpf = bpf; p.pass = ps; p.grow = L.grow;
@@ -836,14 +909,33 @@ MFA_API int mfa_align_batch(mfa_ctx *c, const mfa_graph_batch *g, const float *d
       hipLaunchKernelGGL(collect_pending_kernel, dim3((n_utt + 255) / 256), dim3(256), 0, c->stream, d_status, n_utt, L.code, d_list, d_count);
       p.utt_list = d_list; p.n_list = d_count;
     }
-    {
+    p.windowed = 0; p.t_begin = 0; p.t_end = 0x7fffffff; p.next_window = 0;
+    p.w_vstate = (VitState *)(base + w.vstate); p.state_depth = nullptr; p.band = nullptr;
+    if (lists_in_lds) MFA_HIP_CHECK(c, hipFuncSetAttribute((const void *)viterbi_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    else MFA_HIP_CHECK(c, hipFuncSetAttribute((const void *)viterbi_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    auto launch_decoder = [&]() {
       KernelTimer kt(c, MFA_K_VITERBI);
-      if (lists_in_lds) {
-        MFA_HIP_CHECK(c, hipFuncSetAttribute((const void *)viterbi_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(viterbi_kernel<true>, dim3(n_utt), dim3(64), lds, c->stream, p);
-      } else {
-        MFA_HIP_CHECK(c, hipFuncSetAttribute((const void *)viterbi_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(viterbi_kernel<false>, dim3(n_utt), dim3(64), lds, c->stream, p);
+      if (lists_in_lds) hipLaunchKernelGGL(viterbi_kernel<true>, dim3(n_utt), dim3(64), lds, c->stream, p);
+      else hipLaunchKernelGGL(viterbi_kernel<false>, dim3(n_utt), dim3(64), lds, c->stream, p);
+    };
+    if (!lazy) {
+      launch_decoder();
+      MFA_DEBUG_POINT(c, "decoded pass=%d code=%d N=%d C=%d lds=%zu in_lds=%d", ps, L.code, L.N, L.C, lds, (int)lists_in_lds);
+    } else {
+      // The rare passes (table growth, retry beam) keep far more of the graph alive, so a narrow band buys little there:
+      // they take wide windows and few launches.
+      const int K = L.code == 0 ? lazy->window : std::max(lazy->window, 256);
+      p.windowed = 1; p.next_window = K;
+      p.state_depth = lazy->plan.d_state_depth; p.band = (int32_t *)(base + w.band);
+      for (int t0 = 0; t0 < lazy->max_frames; t0 += K) {
+        MfaWindowScore ws;
+        ws.t_begin = t0; ws.window = K; ws.band = p.band; ws.utt_list = p.utt_list; ws.n_list = p.n_list;
+        ws.done = (const int32_t *)(base + w.vstate); ws.done_stride = (int)(sizeof(VitState) / 4); ws.done_word = 2;
+        if (mfa_gmm_score_window(c, lazy, &ws, d_frame_off, n_utt, d_ll_off, (float *)d_loglikes) != 0) return -1;
+        MFA_DEBUG_POINT(c, "scored window t0=%d K=%d pass=%d code=%d N=%d C=%d", t0, K, ps, L.code, L.N, L.C);
+        p.t_begin = t0; p.t_end = t0 + K;
+        launch_decoder();
+        MFA_DEBUG_POINT(c, "decoded window t0=%d K=%d pass=%d code=%d N=%d C=%d lds=%zu in_lds=%d", t0, K, ps, L.code, L.N, L.C, lds, (int)lists_in_lds);
       }
     }
     MFA_HIP_CHECK(c, hipGetLastError());
@@ -851,6 +943,42 @@ MFA_API int mfa_align_batch(mfa_ctx *c, const mfa_graph_batch *g, const float *d
   hipLaunchKernelGGL(finalize_pending_kernel, dim3((n_utt + 255) / 256), dim3(256), 0, c->stream, d_status, n_utt);
   MFA_HIP_CHECK(c, hipGetLastError());
   return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+MFA_API int mfa_align_batch(mfa_ctx *c, const mfa_graph_batch *g, const float *d_loglikes, const int64_t *d_ll_off,
+                            const int32_t *d_ll_cols, const int64_t *d_frame_off, int64_t total_frames,
+                            int64_t total_arcs, int32_t max_states, int32_t max_arcs, const mfa_align_opts *o, int32_t *d_ali, int32_t *d_words, int32_t *d_n_words,
+                            float *d_like, float *d_frame_like, int32_t *d_status) {
+  return align_impl(c, g, d_loglikes, d_ll_off, d_ll_cols, d_frame_off, total_frames, total_arcs, max_states, max_arcs, o,
+                    d_ali, d_words, d_n_words, d_like, d_frame_like, d_status, nullptr);
+}
+
+MFA_API int mfa_align_features_batch(mfa_ctx *c, const mfa_graph_batch *g, const mfa_score_plan *plan, const float *d_feats,
+                                     const int64_t *d_frame_off, int32_t max_frames, int64_t total_frames, int64_t total_arcs,
+                                     int32_t max_states, int32_t max_arcs, const mfa_align_opts *o, int32_t window,
+                                     float *d_loglikes, const int64_t *d_ll_off, const int32_t *d_ll_cols, int32_t *d_ali,
+                                     int32_t *d_words, int32_t *d_n_words, float *d_like, float *d_frame_like,
+                                     int32_t *d_status) {
+  if (!plan || !plan->d_pdf_list || !plan->d_pdf_off || !plan->d_class_counts || !plan->d_pdf_first_frame ||
+      !plan->d_pdf_last_depth || !plan->d_state_depth)
+    return c->fail("mfa_align_features_batch: incomplete score plan");
+  if (window <= 0 || window % 64 != 0) return c->fail("mfa_align_features_batch: window must be a positive multiple of 64 frames (got %d)", window);
+  if (max_frames <= 0) return c->fail("mfa_align_features_batch: max_frames must be positive");
+  if (!mfa_gmm_lazy_supported(c)) {
+    // feature dimensions beyond the MFMA kernels' instantiations: dense scoring (naive kernel), then the decoder
+    if (mfa_gmm_score_batch(c, d_feats, d_frame_off, g->n_utt, max_frames, plan->d_pdf_list, plan->d_pdf_off,
+                            plan->d_class_counts, plan->d_pdf_first_frame, d_ll_off, d_loglikes) != 0) return -1;
+    return align_impl(c, g, d_loglikes, d_ll_off, d_ll_cols, d_frame_off, total_frames, total_arcs, max_states, max_arcs, o,
+                      d_ali, d_words, d_n_words, d_like, d_frame_like, d_status, nullptr);
+  }
+  MfaLazyScoring lazy;
+  lazy.plan = *plan; lazy.d_feats = d_feats; lazy.max_frames = max_frames; lazy.window = window;
+  return align_impl(c, g, d_loglikes, d_ll_off, d_ll_cols, d_frame_off, total_frames, total_arcs, max_states, max_arcs, o,
+                    d_ali, d_words, d_n_words, d_like, d_frame_like, d_status, &lazy);
 }
 
 }  // extern "C"

@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import AlignOpts, GraphBatch, MfccOpts, check
+from ._lib import AlignOpts, GraphBatch, MfccOpts, ScorePlan, check
 from .kaldi_io import Fst
 from .model import DiagGmmModel, TransitionModel
 
@@ -47,6 +47,16 @@ class PackedGraphs:
     pdf_lists_host: List[np.ndarray]
     pdf_first_frame: Optional[torch.Tensor] = None        # int32 [ΣP_u]: first frame a pdf can be asked for
     pdf_first_frame_host: Optional[List[np.ndarray]] = None
+    # lazy (windowed) scoring keys — mfa_score_plan: running max inside each class of the longest-path depth of a pdf's
+    # source states, and {BFS depth, longest-path depth} of every graph state
+    pdf_last_depth: Optional[torch.Tensor] = None         # int32 [ΣP_u]
+    state_depth: Optional[torch.Tensor] = None            # int32 [ΣS_u, 2]
+
+    def plan(self) -> ScorePlan:
+        if self.pdf_last_depth is None or self.state_depth is None or self.pdf_first_frame is None:
+            raise _lib.MfaHipError("these graphs were packed without depth keys (lazy scoring needs them)")
+        return ScorePlan(self.pdf_list.data_ptr(), self.pdf_off.data_ptr(), self.class_counts.data_ptr(),
+                         self.pdf_first_frame.data_ptr(), self.pdf_last_depth.data_ptr(), self.state_depth.data_ptr())
 
     def struct(self) -> GraphBatch:
         t = self.tensors
@@ -206,6 +216,18 @@ class AlignmentEngine:
             raise _lib.MfaHipError("mfa_fst_first_frames: malformed graph")
         return depth
 
+    def state_last_depths(self, fst: Fst, bfs_depth: Optional[np.ndarray] = None) -> np.ndarray:
+        """m[s] = smallest BFS depth among the states reachable from s (mfa_fst_last_depths): non-decreasing along every
+        arc — the lower bound of the lazy-scoring band."""
+        arc_off = np.ascontiguousarray(fst.arc_offsets, dtype=np.int32)
+        nxt = np.ascontiguousarray(fst.arcs["nextstate"], dtype=np.int32)
+        bfs = np.ascontiguousarray(self.state_first_frames(fst) if bfs_depth is None else bfs_depth, dtype=np.int32)
+        depth = np.zeros(fst.num_states, dtype=np.int32)
+        if self.lib.mfa_fst_last_depths(fst.num_states, arc_off.ctypes.data, nxt.ctypes.data, int(fst.start), bfs.ctypes.data,
+                                        depth.ctypes.data) < 0:
+            raise _lib.MfaHipError("mfa_fst_last_depths: malformed graph")
+        return depth
+
     def score(self, feats: torch.Tensor, frame_off: np.ndarray, pdf_list: torch.Tensor, pdf_off_host: np.ndarray,
               class_counts: torch.Tensor, pdf_first_frame: Optional[torch.Tensor] = None):
         """Returns (loglikes float32 flat, ll_off host int64 [n+1], ll_cols int32 tensor).  With ``pdf_first_frame``
@@ -223,8 +245,15 @@ class AlignmentEngine:
                                                      _ptr(out)), "mfa_gmm_score_batch")
         return out, ll_off, self._dev(P.astype(np.int32))
 
-    def pack_graphs(self, fsts: Sequence[Fst], tm: TransitionModel) -> PackedGraphs:
-        """Concatenate per-utterance graphs (with transition probabilities already applied) into the device layout."""
+    def pack_graphs(self, fsts: Sequence[Fst], tm: TransitionModel, cluster_gap: Optional[int] = 32) -> PackedGraphs:
+        """Concatenate per-utterance graphs (with transition probabilities already applied) into the device layout.
+
+        Score columns: one per (pdf, depth cluster) of the utterance.  A pdf whose arcs leave states far apart in the graph
+        (the same phone in two words) gets one column per cluster of occurrences — occurrences whose BFS depths differ by
+        more than ``cluster_gap``, or lie in different ``cluster_gap``-wide depth ranges, start a new column — so that the
+        lazy-scoring band, which is a range of graph depths, does not have to keep the pdf alive for everything in
+        between (optional silence after every word would otherwise chain into one column spanning the utterance).
+        ``cluster_gap=None``: one column per pdf."""
         n = len(fsts)
         S = np.array([f.num_states for f in fsts], dtype=np.int64)
         A = np.array([f.num_arcs for f in fsts], dtype=np.int64)
@@ -240,23 +269,38 @@ class AlignmentEngine:
             raise _lib.MfaHipError(f"a graph state has {max_deg} arcs; the device decoder supports at most 64")
         pdf_of_arc = tm.id2pdf[arcs["ilabel"]]
         cols = np.empty(arcs.shape[0], dtype=np.int32)
-        pdf_lists, counts, first_frames = [], [], []
-        lut = np.full(tm.num_pdfs, -1, dtype=np.int32)
+        pdf_lists, counts, first_frames, last_depths, state_depths = [], [], [], [], []
+        span = 0 if cluster_gap is None else int(cluster_gap)
+        n_cols = C.c_int32(0)
+        if self.slot_class is None:
+            raise _lib.MfaHipError("pack_graphs needs the acoustic model's slot classes: call load_gmm first")
+        pdf_class = np.ascontiguousarray(self.slot_class, dtype=np.int32)
         for u in range(n):
             a0, a1 = int(arc_base[u]), int(arc_base[u + 1])
             f = fsts[u]
-            # first frame each pdf can be asked for = fewest arcs from the start state to the source of an arc emitting it
-            depth = self.state_first_frames(f)
-            src = np.repeat(np.arange(f.num_states, dtype=np.int64), np.diff(f.arc_offsets))
-            upl, inv = np.unique(pdf_of_arc[a0:a1], return_inverse=True)
-            ff = np.full(upl.shape[0], np.iinfo(np.int32).max, dtype=np.int32)
-            np.minimum.at(ff, inv, depth[src])
-            pl, cc, ff = self.sort_pdf_list(upl, ff)
-            lut[pl] = np.arange(pl.shape[0], dtype=np.int32)
-            cols[a0:a1] = lut[pdf_of_arc[a0:a1]]
-            pdf_lists.append(pl)
+            na = a1 - a0
+            f_off = np.ascontiguousarray(f.arc_offsets, dtype=np.int32)
+            f_nxt = np.ascontiguousarray(arcs["nextstate"][a0:a1], dtype=np.int32)
+            f_pdf = np.ascontiguousarray(pdf_of_arc[a0:a1], dtype=np.int32)
+            sd = np.empty((f.num_states, 2), dtype=np.int32)
+            col = np.empty(na, dtype=np.int32)
+            cp, cf, cl = np.empty(na, dtype=np.int32), np.empty(na, dtype=np.int32), np.empty(na, dtype=np.int32)
+            cc = np.zeros(6, dtype=np.int32)
+            # columns (pdf, depth cluster) in kernel order, their depth keys, and every arc's column: one host call
+            rc = self.lib.mfa_build_score_plan(f.num_states, f_off.ctypes.data, f_nxt.ctypes.data, f_pdf.ctypes.data,
+                                               int(f.start), int(pdf_class.shape[0]), pdf_class.ctypes.data, span,
+                                               sd.ctypes.data, col.ctypes.data, cp.ctypes.data, cf.ctypes.data,
+                                               cl.ctypes.data, cc.ctypes.data, C.byref(n_cols))
+            if rc != 0:
+                raise _lib.MfaHipError(f"mfa_build_score_plan: utterance {u}: " +
+                                       ("a pdf id outside the loaded model" if rc == -2 else "malformed graph"))
+            k = int(n_cols.value)
+            cols[a0:a1] = col
+            pdf_lists.append(cp[:k].copy())
             counts.append(cc)
-            first_frames.append(ff)
+            first_frames.append(cf[:k].copy())
+            last_depths.append(cl[:k].copy())
+            state_depths.append(sd)
         pdf_off = np.concatenate([[0], np.cumsum([len(p) for p in pdf_lists])]).astype(np.int64)
         t = dict(
             state_off=self._dev(state_off), arc_base=self._dev(arc_base),
@@ -268,7 +312,9 @@ class AlignmentEngine:
         )
         return PackedGraphs(n, int(S.max()) if n else 0, int(A.max()) if n else 0, int(A.sum()), t, self._dev(np.concatenate(pdf_lists).astype(np.int32)),
                             self._dev(pdf_off), self._dev(np.stack(counts).astype(np.int32)), pdf_off, pdf_lists,
-                            self._dev(np.concatenate(first_frames).astype(np.int32)), first_frames)
+                            self._dev(np.concatenate(first_frames).astype(np.int32)), first_frames,
+                            self._dev(np.concatenate(last_depths).astype(np.int32)),
+                            self._dev(np.concatenate(state_depths).astype(np.int32)))
 
     def align(self, graphs: PackedGraphs, loglikes: torch.Tensor, ll_off: np.ndarray, ll_cols: torch.Tensor,
               frame_off: np.ndarray, beam: float = 10.0, retry_beam: float = 40.0, acoustic_scale: float = 0.1,
@@ -290,6 +336,38 @@ class AlignmentEngine:
                                                  total, graphs.total_arcs, graphs.max_states, graphs.max_arcs, C.byref(opts), _ptr(ali), _ptr(words),
                                                  _ptr(n_words), _ptr(like), _ptr(flike), _ptr(status)), "mfa_align_batch")
         return dict(ali=ali, words=words, n_words=n_words, like=like, status=status, frame_like=flike)
+
+    def align_features(self, graphs: PackedGraphs, feats: torch.Tensor, frame_off: np.ndarray, beam: float = 10.0,
+                       retry_beam: float = 40.0, acoustic_scale: float = 0.1, max_tokens: int = 1024,
+                       bp_tokens_per_frame: int = 512, want_frame_likes: bool = False, window: int = 64,
+                       loglikes: Optional[torch.Tensor] = None):
+        """features + graphs → alignments with acoustic scores evaluated lazily, window by window, for the pdfs live tokens
+        can reach (mfa_align_features_batch) — the shape of GmmAligner.align_utterance(fst, feats)
+        (MFA/alignment/multiprocessing.py:846-853).  Same results as ``score`` + ``align``.  ``loglikes``: optional scratch
+        [Σ T·P] (zero-filled here when omitted, so tests can see which cells were written)."""
+        n = graphs.n_utt
+        total = int(frame_off[-1])
+        dev = self.device
+        T = np.diff(frame_off)
+        P = np.diff(graphs.pdf_off_host)
+        ll_off = np.concatenate([[0], np.cumsum(T * P)]).astype(np.int64)
+        if loglikes is None:
+            loglikes = torch.zeros(int(ll_off[-1]), dtype=torch.float32, device=dev)
+        ali = torch.zeros(total, dtype=torch.int32, device=dev)
+        words = torch.zeros(total, dtype=torch.int32, device=dev)
+        n_words = torch.zeros(n, dtype=torch.int32, device=dev)
+        like = torch.zeros(n, dtype=torch.float32, device=dev)
+        status = torch.full((n,), -1, dtype=torch.int32, device=dev)
+        flike = torch.zeros(total, dtype=torch.float32, device=dev) if want_frame_likes else None
+        opts = AlignOpts(beam, retry_beam, acoustic_scale, max_tokens, bp_tokens_per_frame)
+        gs, plan = graphs.struct(), graphs.plan()
+        d_lo, d_fo, d_cols = self._dev(ll_off), self._dev(frame_off), self._dev(P.astype(np.int32))
+        check(self.ctx, self.lib.mfa_align_features_batch(
+            self.ctx, C.byref(gs), C.byref(plan), _ptr(feats), _ptr(d_fo), int(T.max()) if n else 0, total, graphs.total_arcs,
+            graphs.max_states, graphs.max_arcs, C.byref(opts), int(window), _ptr(loglikes), _ptr(d_lo), _ptr(d_cols), _ptr(ali),
+            _ptr(words), _ptr(n_words), _ptr(like), _ptr(flike), _ptr(status)), "mfa_align_features_batch")
+        return dict(ali=ali, words=words, n_words=n_words, like=like, status=status, frame_like=flike, loglikes=loglikes,
+                    ll_off=ll_off)
 
     # ------------------------------------------------------------------ timing helpers (bench.py)
     def kernel_timing(self, enable: bool) -> None:
@@ -318,8 +396,13 @@ class Pipeline:
     def __init__(self, engine: AlignmentEngine, pcm: torch.Tensor, sample_off: np.ndarray, utt2spk: np.ndarray,
                  graphs: PackedGraphs, lda: Optional[torch.Tensor] = None, fmllr: Optional[torch.Tensor] = None,
                  splice_context: int = 3, beam: float = 10.0, retry_beam: float = 40.0, acoustic_scale: float = 0.1,
-                 max_tokens: int = 1024, bp_tokens_per_frame: int = 256, reachability: bool = True):
+                 max_tokens: int = 1024, bp_tokens_per_frame: int = 256, reachability: bool = True, lazy: bool = True,
+                 window: int = 64):
         e = self.e = engine
+        # lazy: scores are evaluated window by window for the pdfs live decoder tokens can reach
+        # (mfa_align_features_batch); otherwise the (reachability-bounded) matrix is scored first, then decoded
+        self.lazy = bool(lazy) and graphs.pdf_last_depth is not None
+        self.window = int(window)
         # reachability: score a pdf only from the first frame a decoder token can ask for it (Kaldi evaluates its
         # decodable lazily; the dense score matrix here skips the cells that provably are never read)
         self.reachability = bool(reachability) and graphs.pdf_first_frame is not None
@@ -372,8 +455,97 @@ class Pipeline:
 
     def step(self) -> None:
         self.front()
-        self.score()
-        self.decode()
+        if self.lazy:
+            self.score_and_decode()
+        else:
+            self.score()
+            self.decode()
+
+    def score_and_decode(self) -> None:
+        """features + graphs → alignments, scores evaluated lazily per window (mfa_align_features_batch)."""
+        L, c, g = self.e.lib, self.e.ctx, self.graphs
+        if not hasattr(self, "_plan"):
+            self._plan = g.plan()
+        check(c, L.mfa_align_features_batch(
+            c, C.byref(self.gstruct), C.byref(self._plan), _ptr(self.feats), _ptr(self.d_frame_off), self.max_frames,
+            self.total_frames, g.total_arcs, g.max_states, g.max_arcs, C.byref(self.opts), self.window, _ptr(self.loglikes),
+            _ptr(self.d_ll_off), _ptr(self.d_ll_cols), _ptr(self.ali), _ptr(self.words), _ptr(self.n_words), _ptr(self.like),
+            None, _ptr(self.status)), "mfa_align_features_batch")
+
+    # ---- host side of the boundary: alignments land in (pinned) host memory
+    def host_output_buffers(self, pinned: bool = True) -> Dict[str, torch.Tensor]:
+        out = {}
+        for name in ("ali", "words", "n_words", "like", "status"):
+            t = getattr(self, name)
+            out[name] = torch.empty(t.shape, dtype=t.dtype, pin_memory=pinned)
+        return out
+
+    def outputs_to_host(self, host: Dict[str, torch.Tensor]) -> None:
+        """Asynchronous D2H of ali / words / n_words / like / status on the engine's stream."""
+        for name, dst in host.items():
+            dst.copy_(getattr(self, name), non_blocking=True)
+
+    # ---- bench.py reporting helpers
+    def scores_string(self) -> str:
+        if self.lazy:
+            return (f"lazy: per {self.window}-frame window, only the pdfs arcs within {self.window} arcs of the live tokens "
+                    "can emit (a superset of what Kaldi's lazy decodable evaluates)")
+        return "reachable cells only (pdf j from its first possible frame on)" if self.reachability else "dense T x P"
+
+    def dtype_string(self, mono: bool, gauss_per_pdf: int) -> str:
+        import os
+        split = os.environ.get("MFA_GMM_BF16", "1") != "0" and not mono and gauss_per_pdf != 1
+        f16 = split and os.environ.get("MFA_GMM_F16", "1") != "0"
+        if f16:
+            return "f32 scores from 2-way f16-split products (3*2^-22 per term worst case), f64 path costs"
+        if split:
+            return "f32 scores from 3-way bf16-split products (2^-24 per term), f64 path costs"
+        return "f32 (scores), f64 (path costs)"
+
+    def algorithmic_bytes(self) -> Dict[str, float]:
+        """SURVEY §8(d) staged-pipeline bytes of one step, per stage (each tensor written once and read once)."""
+        T = np.diff(self.frame_off).astype(np.float64)
+        P = np.diff(self.graphs.pdf_off_host).astype(np.float64)
+        n_samples = float(self.pcm.numel())
+        A = float(self.graphs.total_arcs)
+        S = float(self.graphs.tensors["final"].numel())
+        D = float(self.feat_dim)
+        tot = float(T.sum())
+        return {
+            "mfcc": 2.0 * n_samples + 4.0 * self.num_ceps * tot,
+            "feats": 4.0 * self.num_ceps * tot + 4.0 * D * tot,
+            "gmm": 4.0 * D * tot + 4.0 * float((P * T).sum()),            # model slice cache-resident (SURVEY's 6.0 MB variant)
+            "viterbi": 4.0 * float((P * T).sum()) + 16.0 * A + 2.0 * float((T * np.diff(self.graphs.tensors["state_off"].cpu().numpy())).sum()) + 6.0 * tot,
+            "states": S,
+        }
+
+    def roofline(self, dominant: str, ktimes: Dict[str, Dict[str, float]], steps: int, mono: bool, gauss_per_pdf: int) -> Dict:
+        """Roofline object for the dominant stage of the step (bench.py): per-step stage time from the HIP-event timers."""
+        import os
+        ms = ktimes[dominant]["ms"] / max(1, steps)
+        launches = ktimes[dominant]["launches"] / max(1, steps)
+        if dominant == "gmm":
+            split = os.environ.get("MFA_GMM_BF16", "1") != "0" and not mono and gauss_per_pdf != 1
+            f16 = split and os.environ.get("MFA_GMM_F16", "1") != "0"
+            mult = 3.0 if f16 else (6.0 if split else 1.0)
+            peak = 2500.0 if split else 157.3
+            ach = self.gmm_flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            return {"kernel": "diagonal-GMM scoring (" + ("f16x2" if f16 else "bf16x3" if split else "f32") + " MFMA)",
+                    "kernel_key": "gmm", "bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 4), "traffic": None,
+                    "algorithmic_flops_per_step": self.gmm_flops, "mfma_flops_per_algorithmic_flop": int(mult),
+                    "executed_mfma_frac_of_peak": round(mult * ach / peak, 4), "ms_per_step": round(ms, 4),
+                    "launches_per_step": launches,
+                    "note": "algorithmic flops = 4*D*g per (frame, pdf) cell of the reachability-bounded matrix (SURVEY 8d)"}
+        by = self.algorithmic_bytes()
+        b = by.get(dominant, 0.0)
+        gbs = b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        names = {"viterbi": "viterbi_kernel (beam Viterbi, one wavefront per utterance)", "mfcc": "mfcc_kernel",
+                 "feats": "feats_lda_kernel / feats_kernel", "cmvn": "cmvn kernels"}
+        return {"kernel": names.get(dominant, dominant), "kernel_key": dominant, "bound": "hbm", "achieved": round(gbs, 2),
+                "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 5), "traffic": None,
+                "algorithmic_bytes_per_step": b, "ms_per_step": round(ms, 4), "launches_per_step": launches,
+                "note": "algorithmic bytes = SURVEY 8(d) staged-pipeline bytes of this stage (each tensor written once, read once)"}
 
     def front(self) -> None:
         """PCM → MFCC → CMVN statistics → final features (three launches on the engine's stream)."""

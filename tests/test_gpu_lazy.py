@@ -1,0 +1,193 @@
+"""Lazy (windowed) scoring — mfa_align_features_batch — against the dense path and the oracle.
+
+Kaldi's decodable is lazy: a score exists only if a live token's arc asked for it (GmmAligner.align_utterance,
+MFA/alignment/multiprocessing.py:846-853).  The device path decodes in windows of K frames and, before each window,
+scores only the pdfs that arcs within K arcs of the live tokens can emit.  That must change NOTHING:
+  * every output (transition-ids, words, likelihood, per-frame likelihoods, status) equals the dense path's bit for bit,
+  * every cell it writes carries exactly the dense kernel's bits,
+  * and it writes far fewer cells.
+The dense path itself is checked against the oracle in test_gpu_parity.py / test_gpu_headline_config.py; the last test
+here closes the loop directly (lazy path vs oracle from PCM)."""
+import numpy as np
+import pytest
+import torch
+
+from montreal_forced_aligner_amd import graph as G
+from oracle import oracle as O
+from tests import helpers, synth
+from tests.test_gpu_parity import _random_graph
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(e, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(e.device)
+
+
+def _both(engine, graphs, feats, frame_off, window=64, **kw):
+    ll, ll_off, ll_cols = engine.score(feats, frame_off, graphs.pdf_list, graphs.pdf_off_host, graphs.class_counts)
+    dense = engine.align(graphs, ll, ll_off, ll_cols, frame_off, want_frame_likes=True, **kw)
+    lazy = engine.align_features(graphs, feats, frame_off, want_frame_likes=True, window=window, **kw)
+    torch.cuda.synchronize()
+    for k in ("status", "ali", "words", "n_words", "like", "frame_like"):
+        assert torch.equal(dense[k], lazy[k]), f"{k} differs between lazy and dense scoring"
+    d, s = ll.cpu().numpy(), lazy["loglikes"].cpu().numpy()
+    written = s != 0.0
+    assert np.array_equal(d[written], s[written]), "a lazily scored cell differs from the dense kernel's value"
+    return dense, lazy, float(written.mean())
+
+
+@pytest.fixture(scope="module")
+def tri(engine):
+    world = synth.SynthWorld.build()
+    engine.configure_mfcc()
+    lda = synth.seeded_lda()
+    fm = synth.seeded_fmllr(16)
+    d_lda = torch.from_numpy(lda).to(engine.device)
+
+    def feats_of(pcm_list, spks):
+        so = np.concatenate([[0], np.cumsum([len(p) for p in pcm_list])]).astype(np.int64)
+        mfcc, fo = engine.mfcc(torch.from_numpy(np.concatenate(pcm_list)).to(engine.device), so)
+        own = np.arange(len(pcm_list), dtype=np.int32)
+        stats = engine.cmvn_stats(mfcc, fo, own, len(pcm_list))
+        per_utt = torch.from_numpy(fm[np.asarray(spks) % 16]).to(engine.device)
+        return engine.features(mfcc, fo, own, stats, lda=d_lda, fmllr=per_utt), fo
+
+    model = synth.train_triphone(world, lambda pcm, spk: feats_of([pcm], [spk])[0].cpu().numpy(), n_train=40, n_gauss=32,
+                                 n_classes=2)
+    return world, model, lda, fm, feats_of
+
+
+@pytest.mark.parametrize("window", [64, 128])
+def test_lazy_equals_dense_headline_shape(engine, tri, window):
+    """configs[2] shape (32-Gaussian pdfs → f16×2 band kernel), ragged lengths incl. < 1 window and a non-multiple."""
+    world, model, lda, fm, feats_of = tri
+    engine.load_gmm(model.am)
+    shapes = [(30, 160000), (30, 160000), (3, 16000), (8, 43200), (1, 8000), (30, 160001), (45, 240000)]
+    utts = [world.utterance(7100 + i, n_words=nw, samples=ns) for i, (nw, ns) in enumerate(shapes)]
+    gc = G.TrainingGraphCompiler(model.tm, model.tree, world.lexicon)
+    scaled = model.tm.scaled_log_probs(1.0, 0.1)
+    fsts = [G.add_transition_probs(gc.compile_fst(u[1]), scaled) for u in utts]
+    feats, fo = feats_of([u[0] for u in utts], [u[3] for u in utts])
+    graphs = engine.pack_graphs(fsts, model.tm)
+    dense, lazy, fill = _both(engine, graphs, feats, fo, window=window, beam=10.0, retry_beam=40.0, max_tokens=1024,
+                              bp_tokens_per_frame=256)
+    assert set(dense["status"].cpu().tolist()) <= {0, 1}
+    assert fill < 0.45, f"lazy scoring wrote {fill:.2f} of the matrix"
+
+
+def test_lazy_small_tables_growth_and_retry_passes(engine, tri):
+    """The rare passes run the same windowed loop: token-capacity growth (tiny first-tier tables) and the retry beam (a beam
+    so narrow that the first pass fails)."""
+    world, model, lda, fm, feats_of = tri
+    engine.load_gmm(model.am)
+    utts = [world.utterance(7200 + i) for i in range(4)]
+    gc = G.TrainingGraphCompiler(model.tm, model.tree, world.lexicon)
+    scaled = model.tm.scaled_log_probs(1.0, 0.1)
+    fsts = [G.add_transition_probs(gc.compile_fst(u[1]), scaled) for u in utts]
+    feats, fo = feats_of([u[0] for u in utts], [u[3] for u in utts])
+    graphs = engine.pack_graphs(fsts, model.tm)
+    # (min_active = 20 keeps a narrow beam from failing on these graphs; the retry pass proper is exercised on the
+    #  reference's recording below, where beam 10 does fail)
+    _both(engine, graphs, feats, fo, beam=0.05, retry_beam=40.0, max_tokens=1024, bp_tokens_per_frame=256)
+    dense, _, _ = _both(engine, graphs, feats, fo, beam=60.0, retry_beam=0.0, max_tokens=2048, bp_tokens_per_frame=1024)
+    assert set(dense["status"].cpu().tolist()) <= {0, 4}   # beam 60 keeps > 128 tokens alive: the growth pass ran
+
+
+def test_lazy_single_gaussian_model_and_real_audio(engine, fx):
+    """mono_model (single-Gaussian pdfs → bit-exact f32 band kernel) on the reference's recording, beam 100/400 as the
+    reference's own tests use, and beam 10/40 (first pass fails on this plumbing model: retry / failure statuses)."""
+    tm, am = fx.mono_tm, fx.mono_am
+    sr = 16000
+    cuts = [(0.0, 4.2), (4.0, 6.5), (0.0, 26.72), (23.5, 26.72)]
+    texts = ["this is the acoustic corpus i'm talking pretty fast here", "there's nothing going else going on", fx.text,
+             "um and that should be all thanks"]
+    segs = [fx.pcm[int(a * sr): int(b * sr)] for a, b in cuts]
+    engine.configure_mfcc()
+    engine.load_gmm(am)
+    so = np.concatenate([[0], np.cumsum([len(s) for s in segs])]).astype(np.int64)
+    mfcc, fo = engine.mfcc(_dev(engine, np.concatenate(segs)), so)
+    u2s = np.arange(len(segs), dtype=np.int32)
+    feats = engine.features(mfcc, fo, u2s, engine.cmvn_stats(mfcc, fo, u2s, len(segs)))
+    fsts = [fx.mono_graph(t) for t in texts]
+    graphs = engine.pack_graphs(fsts, tm)
+    seen = set()
+    for beam, retry in ((100.0, 400.0), (10.0, 40.0)):
+        dense, _, _ = _both(engine, graphs, feats, fo, beam=beam, retry_beam=retry, max_tokens=2048, bp_tokens_per_frame=1024)
+        seen |= set(dense["status"].cpu().tolist())
+    assert 1 in seen                                        # the retry-beam pass really ran (windowed, on its own list)
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_lazy_random_graphs_all_slot_classes(engine, fx, seed, monkeypatch):
+    """Graphs with cycles, skips, dead ends and unreachable states over a model with every slot class (1, 4, 8, 16, 32 rows,
+    multi-block) — both band kernels at once.  (The band rule itself is brute-forced on such graphs on the CPU:
+    tests/test_score_plan_cpu.py.)"""
+    rng = np.random.default_rng(4000 + seed)
+    tm = fx.mono_tm
+    sizes = [int(x) for x in rng.choice([1, 2, 3, 4, 5, 8, 9, 12, 16, 17, 26, 32, 40, 70], size=tm.num_pdfs)]
+    am = helpers.random_gmm(rng, 39, sizes)
+    engine.load_gmm(am)
+    fsts, feats = [], []
+    for u in range(12):
+        S = int(rng.choice([3, 8, 40, 150, 400, 1100]))
+        fsts.append(_random_graph(rng, tm, S))
+        T = int(rng.integers(2, 300))
+        feats.append(rng.normal(0, 3.0, size=(T, 39)).astype(np.float32))
+    fo = np.concatenate([[0], np.cumsum([f.shape[0] for f in feats])]).astype(np.int64)
+    graphs = engine.pack_graphs(fsts, tm)
+    beam, retry = [(8.0, 32.0), (30.0, 0.0)][seed]
+    d_feats = _dev(engine, np.concatenate(feats))
+    kw = dict(beam=beam, retry_beam=retry, max_tokens=2048, bp_tokens_per_frame=1100, acoustic_scale=0.1)
+    # Same arithmetic on both sides → bit-identical: with MFA_GMM_BF16=0 every class is scored by the f32 kernels, dense and
+    # lazy alike.  (By default the lazy path scores the single-block 32-row class with the f16×2 band kernel — identical to
+    # the dense kernel's bits, see the headline-shape test — and all other classes with the f32 band kernel, whereas the
+    # dense path has split-operand kernels for them: same scores to ≤ 2e-5·scale, not the same bits.)
+    monkeypatch.setenv("MFA_GMM_BF16", "0")
+    _both(engine, graphs, d_feats, fo, **kw)
+    monkeypatch.delenv("MFA_GMM_BF16")
+    ll, ll_off, ll_cols = engine.score(d_feats, fo, graphs.pdf_list, graphs.pdf_off_host, graphs.class_counts)
+    dense = engine.align(graphs, ll, ll_off, ll_cols, fo, **kw)
+    lazy = engine.align_features(graphs, d_feats, fo, **kw)
+    d, s_ = ll.cpu().numpy(), lazy["loglikes"].cpu().numpy()
+    w = s_ != 0.0
+    assert w.any() and np.abs(d[w] - s_[w]).max() <= 1e-4 * max(1.0, float(np.abs(d[w]).max()))
+    same = 0
+    for u in range(len(fsts)):
+        a, b = int(fo[u]), int(fo[u + 1])
+        if int(dense["status"][u]) == int(lazy["status"][u]) and torch.equal(dense["ali"][a:b], lazy["ali"][a:b]):
+            same += 1
+            if int(dense["status"][u]) in (0, 1):
+                assert abs(float(dense["like"][u]) - float(lazy["like"][u])) / (b - a) < 1e-3
+    assert same >= len(fsts) - 1
+
+
+def test_lazy_path_matches_oracle_from_pcm(engine, tri):
+    """The default product path (front end → mfa_align_features_batch) against the oracle's whole path from the same PCM:
+    boundaries frame-identical; log-likelihood within 1e-3 per frame (the value MFA stores, MFA/alignment/mixins.py:351-357)
+    and the total difference reported."""
+    world, model, lda, fm, feats_of = tri
+    engine.load_gmm(model.am)
+    utts = [world.utterance(7400 + i) for i in range(4)]
+    gc = G.TrainingGraphCompiler(model.tm, model.tree, world.lexicon)
+    scaled = model.tm.scaled_log_probs(1.0, 0.1)
+    fsts = [G.add_transition_probs(gc.compile_fst(u[1]), scaled) for u in utts]
+    feats, fo = feats_of([u[0] for u in utts], [u[3] for u in utts])
+    graphs = engine.pack_graphs(fsts, model.tm)
+    res = engine.align_features(graphs, feats, fo, beam=10.0, retry_beam=40.0, max_tokens=256, bp_tokens_per_frame=128)
+    res = {k: v.cpu().numpy() for k, v in res.items() if isinstance(v, torch.Tensor)}
+    am = model.am
+    for u, (pcm, text, segs, spk) in enumerate(utts):
+        pl = graphs.pdf_lists_host[u]
+        mf = O.mfcc(pcm.astype(np.float32), O.default_mfcc_opts())
+        x = O.affine(O.affine(O.splice(O.cmvn_apply(O.cmvn_stats([mf]), mf)), lda), fm[spk % 16])
+        ll = O.gmm_loglikes(x, am.gconsts, am.means_invvars, am.inv_vars, am.pdf_offsets, pl)
+        ref = helpers.oracle_align(model.tm, fsts[u], ll, pl, beam=10.0, retry_beam=40.0)
+        a, b = fo[u], fo[u + 1]
+        assert res["status"][u] == ref["status"] == 0
+        assert np.array_equal(res["ali"][a:b], ref["ali"])
+        nw = int(res["n_words"][u])
+        assert np.array_equal(res["words"][a: a + nw], ref["words"])
+        total = abs(float(res["like"][u]) - ref["like"])
+        print(f"utterance {u}: |delta log-likelihood| total {total:.4f}, per frame {total / (b - a):.2e}")
+        assert total / (b - a) < 1e-3

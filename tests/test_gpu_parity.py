@@ -482,7 +482,7 @@ def test_reachability_bounded_scoring_changes_nothing(engine, fx):
     utt2spk = np.arange(3, dtype=np.int32)
     feats = engine.features(mfcc, frame_off, utt2spk, engine.cmvn_stats(mfcc, frame_off, utt2spk, 3))
     fsts = [fx.mono_graph(t) for t in texts]
-    graphs = engine.pack_graphs(fsts, tm)
+    graphs = engine.pack_graphs(fsts, tm, cluster_gap=None)   # one column per pdf: the key check below assumes it
     dense, ll_off, ll_cols = engine.score(feats, frame_off, graphs.pdf_list, graphs.pdf_off_host, graphs.class_counts)
     sparse, _, _ = engine.score(feats, frame_off, graphs.pdf_list, graphs.pdf_off_host, graphs.class_counts,
                                 pdf_first_frame=graphs.pdf_first_frame)

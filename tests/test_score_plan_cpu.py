@@ -1,0 +1,119 @@
+"""Host side of lazy scoring (no GPU): mfa_build_score_plan's columns and depth keys, and the claim the device path rests
+on — for ANY set of live states and any window length K, every arc a token can take within the window (an arc leaving a
+state reachable in fewer than K arcs) has its column inside the index range the band rule selects.  Brute force on random
+graphs (cycles, skips, dead ends, unreachable states) and on a real training graph."""
+import ctypes as C
+
+import numpy as np
+
+from montreal_forced_aligner_amd import _lib
+from tests.test_gpu_parity import _random_graph  # plain numpy graph generator (module import needs no GPU)
+
+
+def _plan(f, pdf_of_arc, pdf_class, span):
+    lib = _lib.lib()
+    na = f.num_arcs
+    off = np.ascontiguousarray(f.arc_offsets, dtype=np.int32)
+    nxt = np.ascontiguousarray(f.arcs["nextstate"], dtype=np.int32)
+    pdf = np.ascontiguousarray(pdf_of_arc, dtype=np.int32)
+    cls = np.ascontiguousarray(pdf_class, dtype=np.int32)
+    sd = np.empty((f.num_states, 2), np.int32)
+    col, cp, cf, cl = (np.empty(max(na, 1), np.int32) for _ in range(4))
+    cc = np.zeros(6, np.int32)
+    n = C.c_int32(0)
+    rc = lib.mfa_build_score_plan(f.num_states, off.ctypes.data, nxt.ctypes.data, pdf.ctypes.data, int(f.start), len(cls),
+                                  cls.ctypes.data, span, sd.ctypes.data, col.ctypes.data, cp.ctypes.data, cf.ctypes.data,
+                                  cl.ctypes.data, cc.ctypes.data, C.byref(n))
+    assert rc == 0
+    k = n.value
+    return sd, col[:na], cp[:k], cf[:k], cl[:k], cc
+
+
+def _check_graph(rng, f, pdf_of_arc, pdf_class, span, trials=30):
+    sd, col, cp, cf, cl, cc = _plan(f, pdf_of_arc, pdf_class, span)
+    S = f.num_states
+    src = np.repeat(np.arange(S), np.diff(f.arc_offsets))
+    nxt = f.arcs["nextstate"].astype(np.int64)
+    # columns: right pdf, class-sorted, keys non-decreasing inside a class, first = min depth of the column's sources
+    assert np.array_equal(cp[col], pdf_of_arc)
+    assert cc.sum() == len(cp)
+    bounds = np.concatenate([[0], np.cumsum(cc)])
+    for k in range(6):
+        seg = slice(bounds[k], bounds[k + 1])
+        assert np.all(pdf_class[cp[seg]] == k)
+        assert np.all(np.diff(cf[seg]) >= 0) and np.all(np.diff(cl[seg]) >= 0)
+    # BFS depth by relaxation; reachable set of the start state
+    INF = 1 << 30
+    d = np.full(S, INF, np.int64)
+    d[f.start] = 0
+    for _ in range(S + 1):
+        nd = d.copy()
+        np.minimum.at(nd, nxt, d[src] + 1)
+        if np.array_equal(nd, d):
+            break
+        d = nd
+    reach0 = d < INF
+    assert np.array_equal(sd[reach0, 0], d[reach0])
+    first = np.full(len(cp), INF, np.int64)
+    np.minimum.at(first, col, np.where(reach0[src], d[src], INF))
+    live_cols = first < INF
+    assert np.array_equal(cf[live_cols], first[live_cols])
+    # m = smallest depth reachable: non-decreasing along arcs between reachable states, and <= own depth
+    m = sd[:, 1].astype(np.int64)
+    ok = reach0[src]
+    assert np.all(m[nxt[ok]] >= m[src[ok]]) and np.all(m[reach0] <= d[reach0])
+    # brute force: random live sets, random K
+    adj = [nxt[f.arc_offsets[s]: f.arc_offsets[s + 1]] for s in range(S)]
+    cls_of_col = pdf_class[cp]
+    pos_in_cls = np.arange(len(cp)) - bounds[cls_of_col]
+    states = np.nonzero(reach0)[0]
+    for _ in range(trials):
+        K = int(rng.choice([1, 2, 5, 16, 64]))
+        live = rng.choice(states, size=min(len(states), int(rng.integers(1, 12))), replace=False)
+        lo, hi = int(m[live].min()), int(d[live].max()) + K - 1
+        frontier, seen = set(int(x) for x in live), set(int(x) for x in live)
+        for _step in range(K - 1):            # states a token can sit on at frames t0 .. t0+K-1
+            nf = set()
+            for s in frontier:
+                for t in adj[s]:
+                    if int(t) not in seen:
+                        seen.add(int(t)); nf.add(int(t))
+            frontier = nf
+        need = set()
+        for s in seen:
+            need.update(int(c) for c in col[f.arc_offsets[s]: f.arc_offsets[s + 1]])
+        for k in range(6):
+            seg = slice(bounds[k], bounds[k + 1])
+            lo_idx = int((cl[seg] < lo).sum())
+            hi_idx = int((cf[seg] <= hi).sum())
+            for c_ in need:
+                if cls_of_col[c_] == k:
+                    assert lo_idx <= pos_in_cls[c_] < hi_idx, (K, lo, hi, c_, cf[c_], cl[c_])
+
+
+def test_band_rule_is_a_superset_on_random_graphs(fx):
+    rng = np.random.default_rng(77)
+    tm = fx.mono_tm
+    pdf_class = rng.integers(0, 6, size=tm.num_pdfs).astype(np.int32)
+    for trial in range(25):
+        f = _random_graph(rng, tm, int(rng.choice([3, 8, 40, 150])))
+        pdf_of_arc = tm.id2pdf[f.arcs["ilabel"]].astype(np.int32)
+        _check_graph(rng, f, pdf_of_arc, pdf_class, span=int(rng.choice([0, 2, 8, 32])))
+
+
+def test_band_rule_on_a_training_graph_and_column_clusters(fx):
+    rng = np.random.default_rng(5)
+    tm = fx.mono_tm
+    f = fx.mono_graph("this is the acoustic corpus i'm talking pretty fast here this is the acoustic corpus")
+    pdf_of_arc = tm.id2pdf[f.arcs["ilabel"]].astype(np.int32)
+    pdf_class = np.full(tm.num_pdfs, 5, np.int32)
+    _check_graph(rng, f, pdf_of_arc, pdf_class, span=32, trials=60)
+    # one column per pdf without clustering; more columns, each of bounded depth extent, with it
+    sd, col, cp0, cf0, cl0, cc0 = _plan(f, pdf_of_arc, pdf_class, 0)
+    assert len(cp0) == len(np.unique(pdf_of_arc))
+    sd, col, cp, cf, cl, cc = _plan(f, pdf_of_arc, pdf_class, 32)
+    assert len(cp) > len(cp0)                       # the text repeats its words: repeated pdfs got their own columns
+    src = np.repeat(np.arange(f.num_states), np.diff(f.arc_offsets))
+    ext_lo = np.full(len(cp), 1 << 30); ext_hi = np.zeros(len(cp), np.int64)
+    np.minimum.at(ext_lo, col, sd[src, 0]); np.maximum.at(ext_hi, col, sd[src, 0])
+    assert np.all(ext_hi - ext_lo <= 32)
