@@ -60,6 +60,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-loops", action="store_true", help="skip the host-fed and strict-precision loops")
     ap.add_argument("--cpu-sample", type=int, default=0, help="utterances for the CPU baseline (0 = 8 per core)")
+    ap.add_argument("--beam", type=float, default=10.0)
+    ap.add_argument("--retry-beam", type=float, default=40.0, help="0 = no retry pass (diagnostic; not the headline config)")
     ap.add_argument("--max-tokens", type=int, default=256)
     ap.add_argument("--bp-tokens", type=int, default=128)
     ap.add_argument("--reachability", type=int, default=1,
@@ -258,7 +260,7 @@ def main():
     ids_k, inv_k = np.unique(utt_spk, return_inverse=True)
     fm_k = None if mono else torch.from_numpy(fm_np[ids_k % n_spk_total]).to(dev)
     pipe = Pipeline(eng, pcm_all, sample_off, inv_k.astype(np.int32), graphs, lda=d_lda, fmllr=fm_k,
-                    max_tokens=args.max_tokens, bp_tokens_per_frame=args.bp_tokens,
+                    beam=args.beam, retry_beam=args.retry_beam, max_tokens=args.max_tokens, bp_tokens_per_frame=args.bp_tokens,
                     reachability=bool(args.reachability), lazy=bool(args.lazy), window=args.window)
     torch.cuda.synchronize()
     log(rank, f"setup {time.time() - t_setup:.1f}s; HBM in use {torch.cuda.memory_allocated(dev) / 2**30:.1f} GiB "

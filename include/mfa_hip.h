@@ -214,6 +214,7 @@ typedef struct {
   const int32_t *d_pdf_first_frame;
   const int32_t *d_pdf_last_depth;
   const int32_t *d_state_depth;
+  int32_t max_cols;                 /* largest column count of an utterance of the batch (host value) */
 } mfa_score_plan;
 
 MFA_API int mfa_align_features_batch(mfa_ctx *ctx, const mfa_graph_batch *graphs, const mfa_score_plan *plan,

@@ -43,6 +43,7 @@ class ScorePlan(C.Structure):
     _fields_ = [
         ("d_pdf_list", C.c_void_p), ("d_pdf_off", C.c_void_p), ("d_class_counts", C.c_void_p),
         ("d_pdf_first_frame", C.c_void_p), ("d_pdf_last_depth", C.c_void_p), ("d_state_depth", C.c_void_p),
+        ("max_cols", C.c_int32),
     ]
 
 

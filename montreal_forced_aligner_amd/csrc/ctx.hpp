@@ -148,6 +148,7 @@ struct MfaWindowScore {
   const int32_t *n_list;
   const int32_t *done;          // per-utterance "finished" word: done[utt * done_stride + done_word] != 0 → skip
   int done_stride, done_word;
+  int cols_per_wave;            // 0: one wavefront walks a sub-tile's whole band; n: one wavefront per n columns of it
 };
 int mfa_gmm_lazy_supported(mfa_ctx *ctx);   // the loaded model fits the MFMA kernels (dim <= 48)
 // Score, for every listed utterance, the (frame, pdf) cells of the window that lie inside the band.  Enqueues on ctx->stream.

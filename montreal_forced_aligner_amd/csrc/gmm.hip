@@ -80,6 +80,7 @@ struct GmmParams {
   const int32_t *b_done; int b_done_stride, b_done_word;
   const int32_t *last_depth;   // parallel to pdf_list: running max (inside a class) of the longest-path depth of the pdf's sources
   int b_skip0;                 // f32 band kernel: the single-block 32-row class was scored by gmm_band_kernel
+  int b_chunk, b_nchunk;       // gmm_band_kernel: columns per wavefront (0 = the whole band) and chunks per sub-tile
 };
 
 // Band of one (utterance, window): pdf j of a class is needed iff first_frame[j] <= hi and last_depth[j] >= lo; both keys
@@ -92,8 +93,9 @@ __device__ __forceinline__ Band band_of(const GmmParams &p, int utt) {
   return b;
 }
 // wavefront → (utterance, 64-frame sub-tile) of a band-mode launch; false: nothing to do
-__device__ __forceinline__ bool band_item(const GmmParams &p, int wave, int &utt, int &r) {
-  const int witem = blockIdx.x * 4 + wave;
+__device__ __forceinline__ bool band_item(const GmmParams &p, int wave, int &utt, int &r, int *chunk = nullptr) {
+  int witem = blockIdx.x * 4 + wave;
+  if (chunk) { const int q = witem / p.b_nchunk; *chunk = witem - q * p.b_nchunk; witem = q; }
   const int item = witem / p.b_sub;
   r = witem - item * p.b_sub;
   const int n_items = p.b_n_list ? *p.b_n_list : p.n_utt;
@@ -1423,13 +1425,13 @@ __global__ __launch_bounds__(256, 2) void gmm_band_kernel(GmmParams p) {
   __shared__ float stage_all[4][64 * 33];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float *stage = stage_all[wave];
-  int utt, r;
-  if (!band_item(p, wave, utt, r)) return;
+  int utt, r, chunk = 0;
+  if (!band_item(p, wave, utt, r, &chunk)) return;
   const int64_t f0 = p.frame_off[utt];
   const int T = (int)(p.frame_off[utt + 1] - f0);
   const int t_base = p.b_t_begin + 64 * r;
   if (t_base >= T) return;
-  int *redo_flag = p.redo + (size_t)utt * p.b_sub + r;
+  int *redo_flag = p.redo + ((size_t)utt * p.b_sub + r) * p.b_nchunk + chunk;
   if (!kHalf && p.redo_mode == 2 && *redo_flag == 0) return;          // only what the f16 pass declined
   const int col = lane & 31, h = lane >> 5;
   const int64_t l0 = p.pdf_off[utt];
@@ -1443,6 +1445,7 @@ __global__ __launch_bounds__(256, 2) void gmm_band_kernel(GmmParams p) {
     hi += __popcll(__ballot(i < n_all && p.first_frame[l0 + i] <= bd.hi));
     lo += __popcll(__ballot(i < n_all && p.last_depth[l0 + i] < bd.lo));
   }
+  if (p.b_chunk > 0) { lo += chunk * p.b_chunk; hi = min(hi, lo + p.b_chunk); }   // this wavefront's share of the band
   if (lo >= hi) { if (kHalf && lane == 0) *redo_flag = 0; return; }
   op8 b[2][kSteps][kPieces];
   const bool bad = split_features<kSteps, kPieces>(p, f0, T, t_base, col, h, b);
@@ -2104,17 +2107,21 @@ int mfa_gmm_score_window(mfa_ctx *c, const MfaLazyScoring *lazy, const MfaWindow
   p.b_done = ws->done; p.b_done_stride = ws->done_stride; p.b_done_word = ws->done_word;
   const int64_t waves = (int64_t)n_utt * p.b_sub;
   const dim3 grid((unsigned)((waves + 3) / 4));
+  p.b_chunk = ws->cols_per_wave > 0 ? ws->cols_per_wave : 0;
+  p.b_nchunk = p.b_chunk > 0 ? (lazy->plan.max_cols + p.b_chunk - 1) / p.b_chunk : 1;
+  const int64_t split_waves = waves * p.b_nchunk;
+  const dim3 split_grid((unsigned)((split_waves + 3) / 4));
   const int m8 = c->kpad / 8;
   const char *bf = getenv("MFA_GMM_BF16");
   const char *hf = getenv("MFA_GMM_F16");
   KernelTimer kt(c, MFA_K_GMM);
   if (!(bf && bf[0] == '0') && c->d_wb && c->has_single32) {
     const bool f16_ok = !(hf && hf[0] == '0') && c->d_wh;
-    if (c->gmm_redo_cap < waves) {
+    if (c->gmm_redo_cap < split_waves) {
       if (c->d_gmm_redo) { MFA_HIP_CHECK(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->d_gmm_redo); }
       c->d_gmm_redo = nullptr; c->gmm_redo_cap = 0;
-      MFA_HIP_CHECK(c, hipMalloc((void **)&c->d_gmm_redo, waves * sizeof(int)));
-      c->gmm_redo_cap = waves;
+      MFA_HIP_CHECK(c, hipMalloc((void **)&c->d_gmm_redo, split_waves * sizeof(int)));
+      c->gmm_redo_cap = split_waves;
     }
     p.redo = c->d_gmm_redo;
     p.wb = (const uint4 *)c->d_wb;
@@ -2122,12 +2129,12 @@ int mfa_gmm_score_window(mfa_ctx *c, const MfaLazyScoring *lazy, const MfaWindow
       p.wh = (const uint4 *)c->d_wh; p.gch = c->d_gch; p.fscale = c->d_fscale;
       p.acc_scale_inv = 1.0f / c->gmm_acc_scale;
       p.redo_mode = 0;
-      if (m8 == 10) hipLaunchKernelGGL((gmm_band_kernel<5, 2>), grid, dim3(256), 0, c->stream, p);
-      else hipLaunchKernelGGL((gmm_band_kernel<6, 2>), grid, dim3(256), 0, c->stream, p);
+      if (m8 == 10) hipLaunchKernelGGL((gmm_band_kernel<5, 2>), split_grid, dim3(256), 0, c->stream, p);
+      else hipLaunchKernelGGL((gmm_band_kernel<6, 2>), split_grid, dim3(256), 0, c->stream, p);
       p.redo_mode = 2;   // the sub-tiles the f16 pass flagged
     }
-    if (m8 == 10) hipLaunchKernelGGL((gmm_band_kernel<5, 3>), grid, dim3(256), 0, c->stream, p);
-    else hipLaunchKernelGGL((gmm_band_kernel<6, 3>), grid, dim3(256), 0, c->stream, p);
+    if (m8 == 10) hipLaunchKernelGGL((gmm_band_kernel<5, 3>), split_grid, dim3(256), 0, c->stream, p);
+    else hipLaunchKernelGGL((gmm_band_kernel<6, 3>), split_grid, dim3(256), 0, c->stream, p);
     p.redo_mode = 0;
     p.b_skip0 = 1;
   }

@@ -879,8 +879,10 @@ int align_impl(mfa_ctx *c, const mfa_graph_batch *g, const float *d_loglikes, co
     const int ps = L.pass;
     // token lists in LDS when everything fits comfortably; in HBM for big graphs / the wide retry beam; and if even the
     // atomically updated tables do not fit, shrink the token capacity (an overflow is then reported per utterance)
+    // (the list passes — table growth, retry beam — hold a handful of utterances: occupancy does not matter there, the
+    //  per-frame latency of HBM-resident lists does)
     bool lists_in_lds = lds_bytes(max_states, L.N, L.C, true) <= kLdsLimit / 2 ||
-                        (ps == 0 && lds_bytes(max_states, L.N, L.C, true) <= kLdsLimit);
+                        ((ps == 0 || L.code != 0) && lds_bytes(max_states, L.N, L.C, true) <= kLdsLimit);
     while (lds_bytes(max_states, L.N, L.C, lists_in_lds) > kLdsLimit && L.N > 64) {
       L.N = (L.N / 2 + 63) & ~63;
       if (L.C > 8 * L.N) L.C = 8 * L.N;
@@ -930,6 +932,7 @@ int align_impl(mfa_ctx *c, const mfa_graph_batch *g, const float *d_loglikes, co
       for (int t0 = 0; t0 < lazy->max_frames; t0 += K) {
         MfaWindowScore ws;
         ws.t_begin = t0; ws.window = K; ws.band = p.band; ws.utt_list = p.utt_list; ws.n_list = p.n_list;
+        ws.cols_per_wave = L.code == 0 ? 0 : 32;   // list passes: few utterances, wide bands — spread the columns over wavefronts
         ws.done = (const int32_t *)(base + w.vstate); ws.done_stride = (int)(sizeof(VitState) / 4); ws.done_word = 2;
         if (mfa_gmm_score_window(c, lazy, &ws, d_frame_off, n_utt, d_ll_off, (float *)d_loglikes) != 0) return -1;
         MFA_DEBUG_POINT(c, "scored window t0=%d K=%d pass=%d code=%d N=%d C=%d", t0, K, ps, L.code, L.N, L.C);
@@ -975,6 +978,7 @@ MFA_API int mfa_align_features_batch(mfa_ctx *c, const mfa_graph_batch *g, const
     return align_impl(c, g, d_loglikes, d_ll_off, d_ll_cols, d_frame_off, total_frames, total_arcs, max_states, max_arcs, o,
                       d_ali, d_words, d_n_words, d_like, d_frame_like, d_status, nullptr);
   }
+  if (plan->max_cols <= 0) return c->fail("mfa_align_features_batch: plan.max_cols must be the largest column count of the batch");
   MfaLazyScoring lazy;
   lazy.plan = *plan; lazy.d_feats = d_feats; lazy.max_frames = max_frames; lazy.window = window;
   return align_impl(c, g, d_loglikes, d_ll_off, d_ll_cols, d_frame_off, total_frames, total_arcs, max_states, max_arcs, o,

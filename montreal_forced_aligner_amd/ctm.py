@@ -132,46 +132,141 @@ def generate_ctm(alignment: Sequence[int], tm, phone_table, frame_shift: float =
     return out
 
 
+def _position_labels(phones: Sequence[str]) -> List[str]:
+    """Word-position suffixes as MFA's position-dependent phone sets carry them: a one-phone word is ``_S``; otherwise the
+    first phone ``_B``, the last ``_E``, the rest ``_I`` (MFA/dictionary/mixins.py position handling; cf. the expected
+    lexicon in tests/data/dictionaries/expected/lexicon.text.fst)."""
+    if len(phones) == 1:
+        return [phones[0] + "_S"]
+    return [phones[0] + "_B"] + [p + "_I" for p in phones[1:-1]] + [phones[-1] + "_E"]
+
+
 def phones_to_pronunciations(lexicon, word_ids: Sequence[int], intervals: Sequence[CtmInterval], transcription: bool = False,
                              text: Optional[str] = None) -> HierarchicalCtm:
-    """Group phone intervals into the aligned word sequence.
+    """Group phone intervals into the aligned word sequence (MFA/alignment/multiprocessing.py:1741-1747).
 
-    The reference composes the phone string with the align lexicon FST; here the same constraint is solved directly:
-    walk the word-id sequence the decoder emitted, and for each word take the pronunciation variant whose phones match the
-    next non-silence intervals (position-independent comparison); optional-silence intervals between words become
-    ``silence_word`` entries, as MFA stores them."""
+    The reference composes the phone string with the align lexicon FST (kalpy LexiconCompiler.phones_to_pronunciations);
+    here the same constraint — the word-id sequence the decoder emitted, each word spelt by one of its pronunciation
+    variants, optional-silence intervals in between — is solved as a search over (word index, interval index) with
+    backtracking, so a variant that is a prefix of another cannot steal the following word's phones.  With
+    position-dependent phones the aligned labels carry ``_B/_I/_E/_S`` and a variant must match them exactly (the word-end
+    evidence decides between "a b" + "c" and "a" + "b c"); silence phones never carry a position.  Optional-silence
+    intervals between words become ``silence_word`` entries, as MFA stores them."""
     sil = lexicon.silence_phone
-    strip = (lambda s: s.rsplit("_", 1)[0] if lexicon.position_dependent_phones and s[-2:] in ("_B", "_E", "_I", "_S") else s)
-    labels = [strip(str(iv.label)) for iv in intervals]
-    out: List[WordCtmInterval] = []
-    k = 0
+    pos_dep = bool(lexicon.position_dependent_phones)
+    labels = [str(iv.label) for iv in intervals]
     n = len(intervals)
     sil_id = lexicon.word_table.find(lexicon.silence_word)
+    words = [lexicon.word_table.find(int(w)) for w in word_ids]
 
-    def take_silence():
-        nonlocal k
-        while k < n and labels[k] == sil:
-            out.append(WordCtmInterval(lexicon.silence_word, sil_id, sil, [intervals[k]]))
-            k += 1
-
-    for wid in word_ids:
-        take_silence()
-        word = lexicon.word_table.find(int(wid))
+    def variants(word: str) -> List[List[str]]:
         prons = lexicon.word_pronunciations(word) if word != lexicon.oov_word else lexicon.word_pronunciations("\0oov\0")
-        chosen = None
-        for p in sorted(prons, key=lambda p: -len(p.pronunciation.split())):
-            ph = p.pronunciation.split()
-            if labels[k: k + len(ph)] == ph:
-                chosen = ph
-                break
-        if chosen is None:
-            raise CtmError(f"no pronunciation of {word!r} matches the aligned phones at interval {k}")
-        out.append(WordCtmInterval(word, int(wid), " ".join(chosen), list(intervals[k: k + len(chosen)])))
-        k += len(chosen)
-    take_silence()
-    if k != n:
-        raise CtmError(f"{n - k} aligned phones are not covered by the word sequence")
+        seen, out = set(), []
+        for p in sorted(prons, key=lambda p: -len(p.pronunciation.split())):   # longest first: the greedy choice when unambiguous
+            ph = tuple(p.pronunciation.split())
+            if ph not in seen:
+                seen.add(ph)
+                out.append(list(ph))
+        return out
+
+    def expected(ph: List[str]) -> List[str]:
+        if not pos_dep:
+            return ph
+        plain = [q for q in ph]
+        if any(q == sil or q == getattr(lexicon, "oov_phone", None) for q in plain):   # silence-type phones carry no position
+            return [q if (q == sil or q == getattr(lexicon, "oov_phone", None)) else lab
+                    for q, lab in zip(plain, _position_labels(plain))]
+        return _position_labels(plain)
+
+    var_cache = [[(ph, expected(ph)) for ph in variants(w)] for w in words]
+    dead = set()          # (word index, interval index) states known to have no completion
+
+    def solve(i: int, k: int):
+        """Segmentation of intervals[k:] into words[i:] (+ inter-word silence), or None."""
+        if (i, k) in dead:
+            return None
+        if i == len(words):
+            if all(labels[j] == sil for j in range(k, n)):
+                return [("sil", j) for j in range(k, n)]
+            dead.add((i, k))
+            return None
+        # a word first (its variants may themselves start with the silence phone), then "this interval is inter-word silence"
+        for ph, exp in var_cache[i]:
+            m = len(exp)
+            if k + m <= n and labels[k: k + m] == exp:
+                rest = solve(i + 1, k + m)
+                if rest is not None:
+                    return [("word", i, k, ph)] + rest
+        if k < n and labels[k] == sil:
+            rest = solve(i, k + 1)
+            if rest is not None:
+                return [("sil", k)] + rest
+        dead.add((i, k))
+        return None
+
+    import sys
+    limit = sys.getrecursionlimit()
+    if limit < 4 * (n + len(words)) + 100:
+        sys.setrecursionlimit(4 * (n + len(words)) + 100)
+    try:
+        plan = solve(0, 0)
+    finally:
+        sys.setrecursionlimit(limit)
+    if plan is None:
+        raise CtmError("the aligned phones cannot be spelt by any combination of the aligned words' pronunciations")
+    out: List[WordCtmInterval] = []
+    for step in plan:
+        if step[0] == "sil":
+            out.append(WordCtmInterval(lexicon.silence_word, sil_id, sil, [intervals[step[1]]]))
+        else:
+            _, i, k, ph = step
+            out.append(WordCtmInterval(words[i], int(word_ids[i]), " ".join(ph), list(intervals[k: k + len(ph)])))
     return HierarchicalCtm(out, text=text)
+
+
+def fix_unk_words(ref: Sequence[str], test: Sequence[WordCtmInterval], lexicon) -> List[WordCtmInterval]:
+    """Give out-of-vocabulary word intervals the spelling they have in the transcript (MFA/helper.py:772-833, called at
+    MFA/alignment/multiprocessing.py:1749-1751): global alignment of the transcript's words against the aligned word
+    intervals with the reference's scores — identical labels or identical word ids 0, anything against the silence word
+    -10, other mismatches -2, gaps -2 per position — then every aligned ``<unk>`` interval takes the transcript word it
+    is paired with; intervals paired with a gap (silences) are kept, transcript words paired with a gap are dropped.
+    (The reference delegates to Bio.pairwise2 with one_alignment_only; among equally scored alignments this takes the one
+    that pairs items as late as possible — tie order of pairwise2 itself is unpinned here.)"""
+    sil_word, oov_word = lexicon.silence_word, lexicon.oov_word
+
+    def score(r: str, t: WordCtmInterval) -> float:
+        if r == t.label:
+            return 0.0
+        if r == sil_word or t.label == sil_word:
+            return -10.0
+        if lexicon.to_int(r) == lexicon.to_int(t.label):
+            return 0.0
+        return -2.0
+
+    n, m = len(ref), len(test)
+    gap = -2.0
+    S = np.full((n + 1, m + 1), -np.inf)
+    S[0, :] = gap * np.arange(m + 1)
+    S[:, 0] = gap * np.arange(n + 1)
+    for i in range(1, n + 1):
+        for j in range(1, m + 1):
+            S[i, j] = max(S[i - 1, j - 1] + score(ref[i - 1], test[j - 1]), S[i - 1, j] + gap, S[i, j - 1] + gap)
+    out: List[WordCtmInterval] = []
+    i, j = n, m
+    while i > 0 or j > 0:
+        if i > 0 and j > 0 and S[i, j] == S[i - 1, j - 1] + score(ref[i - 1], test[j - 1]):
+            t = test[j - 1]
+            if ref[i - 1] != t.label and t.label == oov_word:
+                t.label = ref[i - 1]
+            out.append(t)
+            i, j = i - 1, j - 1
+        elif j > 0 and S[i, j] == S[i, j - 1] + gap:
+            out.append(test[j - 1])      # aligned interval without a transcript word (silence): kept
+            j -= 1
+        else:
+            i -= 1                        # transcript word without an interval: dropped
+    out.reverse()
+    return out
 
 
 # --------------------------------------------------------------------------------------------------- TextGrid

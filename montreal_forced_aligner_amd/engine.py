@@ -56,7 +56,8 @@ class PackedGraphs:
         if self.pdf_last_depth is None or self.state_depth is None or self.pdf_first_frame is None:
             raise _lib.MfaHipError("these graphs were packed without depth keys (lazy scoring needs them)")
         return ScorePlan(self.pdf_list.data_ptr(), self.pdf_off.data_ptr(), self.class_counts.data_ptr(),
-                         self.pdf_first_frame.data_ptr(), self.pdf_last_depth.data_ptr(), self.state_depth.data_ptr())
+                         self.pdf_first_frame.data_ptr(), self.pdf_last_depth.data_ptr(), self.state_depth.data_ptr(),
+                         int(np.diff(self.pdf_off_host).max()) if self.n_utt else 0)
 
     def struct(self) -> GraphBatch:
         t = self.tensors

@@ -60,3 +60,71 @@ def test_generate_ctm_and_word_grouping_on_an_oracle_alignment(fx):
     assert sum(len(w.phones) for w in h.word_intervals) == len(iv)
     h.update_utterance_boundaries(1.5, 3.49)
     assert abs(h.word_intervals[0].begin - 1.5) < 1e-9 and h.word_intervals[-1].end <= 3.49
+
+
+def _toy_lexicon(position_dependent):
+    from montreal_forced_aligner_amd import graph as G
+
+    lex = G.LexiconCompiler(position_dependent_phones=position_dependent, phones=["a", "b", "c", "d"], silence_phone="sil",
+                            oov_phone="spn")
+    for w, p in (("ab", "a b"), ("ab", "a"), ("c", "c"), ("bc", "b c"), ("abc", "a b c"), ("d", "d"), ("d", "d d")):
+        lex.add_pronunciation(G.Pronunciation(w, p))
+    lex.build_phone_table()
+    return lex
+
+
+def _ivs(labels):
+    return [C.CtmInterval(0.1 * i, 0.1 * (i + 1), lab, 0) for i, lab in enumerate(labels)]
+
+
+def test_word_grouping_backtracks_when_a_variant_is_a_prefix_of_another():
+    """Non-position-dependent models (english_mfa style): "ab" may be spelt "a b" or "a"; for the word sequence [ab, bc]
+    over phones a b c the greedy longest-first choice (a b) leaves "c" for "bc" and fails — the search must back off to
+    "a" + "b c" (MFA/alignment/multiprocessing.py:1741-1747 composes with the align lexicon, which finds it)."""
+    lex = _toy_lexicon(False)
+    ids = [lex.to_int("ab"), lex.to_int("bc")]
+    h = C.phones_to_pronunciations(lex, ids, _ivs(["sil", "a", "b", "c", "sil"]))
+    got = [(w.label, w.pronunciation) for w in h.word_intervals]
+    assert got == [("<eps>", "sil"), ("ab", "a"), ("bc", "b c"), ("<eps>", "sil")]
+    # unambiguous input still takes the longest variant, silences between words become <eps> entries
+    h = C.phones_to_pronunciations(lex, [lex.to_int("ab"), lex.to_int("c")], _ivs(["a", "b", "sil", "c"]))
+    assert [(w.label, w.pronunciation) for w in h.word_intervals] == [("ab", "a b"), ("<eps>", "sil"), ("c", "c")]
+    # repeated single-phone variants: d ("d" | "d d") twice over d d d has two spellings; one is returned, all phones covered
+    h = C.phones_to_pronunciations(lex, [lex.to_int("d"), lex.to_int("d")], _ivs(["d", "d", "d"]))
+    assert sorted(w.pronunciation for w in h.word_intervals) == ["d", "d d"]
+    import pytest
+    with pytest.raises(C.CtmError):
+        C.phones_to_pronunciations(lex, [lex.to_int("ab")], _ivs(["a", "c"]))
+
+
+def test_word_grouping_uses_word_position_suffixes():
+    """Position-dependent phones: the aligned labels say where words end (_E/_S), so [ab, c] over a_B b_E c_S groups as
+    "a b" + "c" even though "a" alone is also a variant of ab — and a_S b_B c_E forces "a" + "b c"."""
+    lex = _toy_lexicon(True)
+    h = C.phones_to_pronunciations(lex, [lex.to_int("ab"), lex.to_int("c")], _ivs(["a_B", "b_E", "c_S"]))
+    assert [(w.label, w.pronunciation) for w in h.word_intervals] == [("ab", "a b"), ("c", "c")]
+    h = C.phones_to_pronunciations(lex, [lex.to_int("ab"), lex.to_int("bc")], _ivs(["a_S", "sil", "b_B", "c_E"]))
+    assert [(w.label, w.pronunciation) for w in h.word_intervals] == [("ab", "a"), ("<eps>", "sil"), ("bc", "b c")]
+    import pytest
+    with pytest.raises(C.CtmError):   # a_B cannot end a word
+        C.phones_to_pronunciations(lex, [lex.to_int("ab"), lex.to_int("bc")], _ivs(["a_B", "b_B", "c_E"]))
+    # the out-of-vocabulary word is spelt by the position-less oov phone
+    h = C.phones_to_pronunciations(lex, [lex.to_int("zzz"), lex.to_int("c")], _ivs(["spn", "c_S"]))
+    assert [(w.label, w.pronunciation) for w in h.word_intervals] == [("<unk>", "spn"), ("c", "c")]
+
+
+def test_fix_unk_words_restores_transcript_spelling():
+    """MFA/helper.py:772-833 at MFA/alignment/multiprocessing.py:1749-1751: <unk> intervals get the transcript's word,
+    silence intervals stay, known words are untouched."""
+    lex = _toy_lexicon(False)
+    h = C.phones_to_pronunciations(lex, [lex.to_int("ab"), lex.to_int("zork"), lex.to_int("c"), lex.to_int("blip")],
+                                   _ivs(["sil", "a", "b", "spn", "sil", "c", "spn"]))
+    assert [w.label for w in h.word_intervals] == ["<eps>", "ab", "<unk>", "<eps>", "c", "<unk>"]
+    fixed = C.fix_unk_words("ab zork c blip".split(), h.word_intervals, lex)
+    assert [w.label for w in fixed] == ["<eps>", "ab", "zork", "<eps>", "c", "blip"]
+    assert [len(w.phones) for w in fixed] == [1, 2, 1, 1, 1, 1]
+    # a transcript with more words than intervals (a word the decoder dropped) leaves the rest aligned
+    fixed = C.fix_unk_words("ab extra zork c blip".split(), C.phones_to_pronunciations(
+        lex, [lex.to_int("ab"), lex.to_int("zork"), lex.to_int("c"), lex.to_int("blip")],
+        _ivs(["a", "b", "spn", "c", "spn"])).word_intervals, lex)
+    assert [w.label for w in fixed][0] == "ab" and [w.label for w in fixed][-2:] == ["c", "blip"]

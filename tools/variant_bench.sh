@@ -1,13 +1,18 @@
 #!/bin/bash
-# A/B a compile-time variant of libmfa_hip.so on the GPU box:  bash tools/variant_bench.sh "<hipcc flags>" [bench args…]
-# prints stage_ms_per_step of the default build and of the variant, then restores the default build.
-set -eo pipefail
-flags="$1"; shift || true
-run() { python bench.py --no-cpu-baseline --steps 4 "$@" 2>>gpurun_out/variant.err | python -c "
-import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$tag', d['value'], d['stage_ms_per_step'])"; }
-build() { MFA_HIPCC_FLAGS="$1" python -c "
-import sys; sys.path.insert(0, '.')
-from montreal_forced_aligner_amd import _lib; _lib.build_native(force=True)" 2>/dev/null; }
-tag=default; run "$@"
-build "$flags"; tag="variant[$flags]"; run "$@"
-build ""; tag=default-again; run "$@"
+# Short bench runs of several variants on the GPU box; prints stage times per variant.
+# usage: tools/variant_bench.sh OUTDIR "name|bench args" ...
+out=$1; shift
+mkdir -p "$out"
+for v in "$@"; do
+  name=${v%%|*}; args=${v#*|}
+  timeout -k 10 400 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra-loops $args > "$out/$name.json" 2> "$out/$name.err"
+  rc=$?
+  if grep -q "Memory access fault" "$out/$name.err"; then echo "$name: GPU FAULT"; exit 9; fi
+  if [ $rc -ne 0 ]; then echo "$name rc=$rc"; tail -5 "$out/$name.err"; if [ $rc -gt 1 ]; then exit $rc; fi; continue; fi
+  python - "$out/$name.json" "$name" <<'PY'
+import json, sys
+d = json.load(open(sys.argv[1]))
+print(f"{sys.argv[2]:28s} value {d['value']:9.0f}  ms/step {d['ms_per_step']:7.3f}  stages {d['stage_ms_per_step']}  launches(vit) {d['roofline'].get('launches_per_step')}")
+PY
+  grep -h "warmup done\|graph states" "$out/$name.err" | cut -c1-200
+done
