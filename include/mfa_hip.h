@@ -260,6 +260,23 @@ MFA_API int mfa_fmllr_acc_batch(mfa_ctx *ctx, const float *d_feats, const int64_
                                 const int32_t *d_spk_utt_off, const int32_t *d_spk_utt, int32_t n_spk, double *d_beta,
                                 double *d_K, double *d_G);
 
+/* The same from the alignment itself: d_ali [total_frames] transition-ids (0 = no alignment for the frame), d_tid2pdf /
+ * d_tid_weight [n_tids] host-built tables (pdf of a transition-id; frame weight by its phone: silence_weight for silence
+ * phones, 1 otherwise); d_pdf_scratch / d_weight_scratch [total_frames] caller scratch. */
+MFA_API int mfa_fmllr_acc_ali_batch(mfa_ctx *ctx, const float *d_feats, const int64_t *d_frame_off, int32_t n_utt,
+                                    int64_t total_frames, const int32_t *d_ali, const int32_t *d_tid2pdf,
+                                    const float *d_tid_weight, int32_t n_tids, int32_t *d_pdf_scratch, float *d_weight_scratch,
+                                    const int32_t *d_spk_utt_off, const int32_t *d_spk_utt, int32_t n_spk, double *d_beta,
+                                    double *d_K, double *d_G);
+/* Two-model form of the same accumulation — what the reference runs whenever the acoustic model ships final.alimdl
+ * (MFA/corpus/features.py:503-511: FmllrComputer(ali_model_path, model_path, ...); MFA/alignment/mixins.py:404-410):
+ * the Gaussian posteriors come from the model loaded with mfa_load_gmm (the ALIGNMENT model, evaluated on the
+ * speaker-independent features), the statistics are formed with the means and variances given here (the FINAL model;
+ * Kaldi gmm-post-to-gpost + FmllrDiagGmmAccs::AccumulateFromPosteriors).  Both models must have the same number of
+ * Gaussians in every pdf.  Stays in force until the next mfa_load_gmm, or until called with NULL arrays. */
+MFA_API int mfa_fmllr_stats_model(mfa_ctx *ctx, int32_t dim, int32_t num_pdfs, const int32_t *h_pdf_offsets,
+                                  const float *h_means_invvars, const float *h_inv_vars);
+
 #ifdef __cplusplus
 }
 #endif

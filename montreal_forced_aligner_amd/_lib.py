@@ -108,6 +108,8 @@ SIGNATURES = {
     "mfa_fst_last_depths": (C.c_int, [_i32, _vp, _vp, _i32, _vp, _vp]),
     "mfa_build_score_plan": (C.c_int, [_i32, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mfa_fmllr_acc_batch": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
+    "mfa_fmllr_acc_ali_batch": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
+    "mfa_fmllr_stats_model": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp]),
     "mfa_align_workspace_bytes": (C.c_size_t, [_vp, _i32, _i64, C.POINTER(AlignOpts)]),
 }
 

@@ -8,7 +8,8 @@ pushes each batch through MFCC → CMVN → features → scores → Viterbi enti
 utterance of a speaker, so statistics are accumulated over the whole shard first (a cheap pass: MFCC + statistics
 kernels), exactly like ``calc_cmvn`` runs before alignment in the reference.
 
-A failed utterance yields ``None`` and is counted, never raised (MFA/alignment/mixins.py:308-314).
+A failed utterance yields ``None`` and is counted, never raised (MFA/alignment/mixins.py:308-314); the reason is kept in
+``CorpusAligner.failure_reasons``.
 """
 from __future__ import annotations
 
@@ -68,26 +69,57 @@ class AlignOptions:
 
 
 class CorpusAligner:
-    """``CorpusAligner(tm, am, tree, lexicon, lda=None)`` then ``align(utterances)`` / ``export_textgrids(...)``."""
+    """``CorpusAligner(tm, am, tree, lexicon, lda=None, ali_am=None)`` then ``align(utterances)`` / ``export_textgrids(...)``.
+
+    ``ali_am``: the speaker-independent alignment model of a SAT acoustic model (``final.alimdl``).  When given, the first
+    pass runs on it (MFA/alignment/mixins.py:404-410), fMLLR statistics take their posteriors from it and their means and
+    variances from ``am`` (MFA/corpus/features.py:503-511), the second pass runs on ``am`` with the transforms, and an
+    utterance that fails the second pass keeps its first-pass alignment (MFA/alignment/multiprocessing.py:841-863,
+    :1784-1860)."""
 
     def __init__(self, tm: TransitionModel, am: DiagGmmModel, tree, lexicon, lda: Optional[np.ndarray] = None,
                  options: Optional[AlignOptions] = None, device: int = 0, engine: Optional[AlignmentEngine] = None,
-                 mfcc_options: Optional[dict] = None, silence_phones: Sequence[int] = ()):
-        self.tm, self.am, self.tree, self.lexicon = tm, am, tree, lexicon
+                 mfcc_options: Optional[dict] = None, silence_phones: Sequence[int] = (),
+                 ali_am: Optional[DiagGmmModel] = None, lazy: bool = True):
+        self.tm, self.tree, self.lexicon = tm, tree, lexicon
         self.lda = None if lda is None else np.asarray(lda, dtype=np.float32)
         self.opt = options or AlignOptions()
         self.engine = engine or AlignmentEngine(device)
         self.mfcc_options = dict(mfcc_options or {})
         self.engine.configure_mfcc(**self.mfcc_options)
         self.silence_phones = list(silence_phones)
-        if self.opt.boost_silence != 1.0 and self.silence_phones:
-            from .model import pdfs_of_phones
-            self.am.boost_silence(self.opt.boost_silence, pdfs_of_phones(tm, self.silence_phones))
-        self.engine.load_gmm(self.am)
+        self.lazy = bool(lazy)
+        # boost_silence scales the weights of the silence pdfs (GmmAligner.boost_silence, MFA/alignment/multiprocessing.py:
+        # 803-815) of whichever model a pass aligns with — on COPIES: the caller's models are left as they were
+        self.am = self._boosted(am)
+        self.ali_am = None if ali_am is None else self._boosted(ali_am)
+        if self.ali_am is not None and not np.array_equal(self.ali_am.pdf_offsets, self.am.pdf_offsets):
+            raise ValueError("final.alimdl and final.mdl must have the same Gaussians per pdf")
+        self._loaded = None
+        self._load(self.am)
         self.compiler = _graph.TrainingGraphCompiler(tm, tree, lexicon)
         self.scaled = tm.scaled_log_probs(self.opt.transition_scale, self.opt.self_loop_scale)
         self.frame_shift = float(self.mfcc_options.get("frame_shift_ms", 10.0)) / 1000.0
         self.failed: List[str] = []
+        self.failure_reasons: Dict[str, str] = {}
+        self.fallback_first_pass: List[str] = []
+        self.transforms: Optional[np.ndarray] = None
+
+    def _boosted(self, am: DiagGmmModel) -> DiagGmmModel:
+        import copy
+
+        if self.opt.boost_silence == 1.0 or not self.silence_phones:
+            return am
+        from .model import pdfs_of_phones
+        am2 = copy.copy(am)
+        am2.gconsts = np.array(am.gconsts, dtype=np.float32, copy=True)
+        am2.boost_silence(self.opt.boost_silence, pdfs_of_phones(self.tm, self.silence_phones))
+        return am2
+
+    def _load(self, am: DiagGmmModel) -> None:
+        if self._loaded is not am:
+            self.engine.load_gmm(am)
+            self._loaded = am
 
     # ------------------------------------------------------------------ helpers
     def _batches(self, utts: Sequence[CorpusUtterance]) -> List[List[int]]:
@@ -126,25 +158,50 @@ class CorpusAligner:
             total[torch.from_numpy(local.astype(np.int64)).to(self.engine.device)] += st
         return spk_ids, total
 
+    def _decode(self, graphs, feats, fo, max_tokens, bp_tokens):
+        """One device call: scores evaluated lazily for the cells live tokens can reach (default), or the dense matrix."""
+        eng, o = self.engine, self.opt
+        if self.lazy:
+            return eng.align_features(graphs, feats, fo, beam=o.beam, retry_beam=o.retry_beam, acoustic_scale=o.acoustic_scale,
+                                      max_tokens=max_tokens, bp_tokens_per_frame=bp_tokens)
+        ll, ll_off, ll_cols = eng.score(feats, fo, graphs.pdf_list, graphs.pdf_off_host, graphs.class_counts,
+                                        pdf_first_frame=graphs.pdf_first_frame)
+        return eng.align(graphs, ll, ll_off, ll_cols, fo, beam=o.beam, retry_beam=o.retry_beam, acoustic_scale=o.acoustic_scale,
+                         max_tokens=max_tokens, bp_tokens_per_frame=bp_tokens)
+
     def _pass(self, utts, spk_ids, cmvn, fmllr, want_feats=False):
         """One alignment pass over all batches.  Returns per-utterance dicts (None where alignment failed) and, when
-        asked, what fMLLR estimation needs (features, alignments, frame offsets per batch)."""
+        asked, what fMLLR estimation needs (features, alignments, frame offsets per batch).  Nothing an individual
+        utterance does aborts the pass: unsupported graphs and decoder statuses beyond "failed" are recorded in
+        ``failure_reasons`` (the reference logs and continues, MFA/alignment/mixins.py:308-314)."""
         import torch
 
         eng, o = self.engine, self.opt
         d_lda = None if self.lda is None else torch.from_numpy(self.lda).to(eng.device)
         results: List[Optional[dict]] = [None] * len(utts)
         kept = []
-        for idx in self._batches(utts):
+        for idx_all in self._batches(utts):
+            fsts_all = [_graph.add_transition_probs(self.compiler.compile_fst(utts[i].text), self.scaled) for i in idx_all]
+            idx, fsts = [], []
+            for i, f in zip(idx_all, fsts_all):       # graphs the device decoder does not take: this utterance only
+                reason = None
+                if f.num_arcs == 0 or f.num_states == 0:
+                    reason = "empty training graph"
+                elif np.any(f.arcs["ilabel"] <= 0):
+                    reason = "training graph has epsilon input arcs"
+                elif int(np.diff(f.arc_offsets).max()) > 64:
+                    reason = "a graph state has more than 64 arcs"
+                if reason is None:
+                    idx.append(i); fsts.append(f)
+                else:
+                    self.failure_reasons[utts[i].utt_id] = reason
+            if not idx:
+                continue
             mfcc, fo = self._mfcc(utts, idx)
             rows = np.array([spk_ids[utts[i].speaker] for i in idx], dtype=np.int32)
             feats = eng.features(mfcc, fo, rows, cmvn, lda=d_lda, fmllr=fmllr)
-            fsts = [_graph.add_transition_probs(self.compiler.compile_fst(utts[i].text), self.scaled) for i in idx]
             graphs = eng.pack_graphs(fsts, self.tm)
-            ll, ll_off, ll_cols = eng.score(feats, fo, graphs.pdf_list, graphs.pdf_off_host, graphs.class_counts,
-                                            pdf_first_frame=graphs.pdf_first_frame)
-            res = eng.align(graphs, ll, ll_off, ll_cols, fo, beam=o.beam, retry_beam=o.retry_beam,
-                            acoustic_scale=o.acoustic_scale, max_tokens=o.max_tokens, bp_tokens_per_frame=o.bp_tokens_per_frame)
+            res = self._decode(graphs, feats, fo, o.max_tokens, o.bp_tokens_per_frame)
             status = res["status"].cpu().numpy()
             ali, words = res["ali"].cpu().numpy(), res["words"].cpu().numpy()
             n_words, like = res["n_words"].cpu().numpy(), res["like"].cpu().numpy()
@@ -154,11 +211,9 @@ class CorpusAligner:
             if over:
                 sub = eng.pack_graphs([fsts[k] for k in over], self.tm)
                 fo2 = np.concatenate([[0], np.cumsum([fo[k + 1] - fo[k] for k in over])]).astype(np.int64)
-                rows_sel = torch.from_numpy(np.concatenate([np.arange(fo[k], fo[k + 1]) for k in over])).to(eng.device)
-                ll2, off2, cols2 = eng.score(feats[rows_sel].contiguous(), fo2, sub.pdf_list, sub.pdf_off_host, sub.class_counts,
-                                             pdf_first_frame=sub.pdf_first_frame)
-                r2 = eng.align(sub, ll2, off2, cols2, fo2, beam=o.beam, retry_beam=o.retry_beam, acoustic_scale=o.acoustic_scale,
-                               max_tokens=sub.max_states, bp_tokens_per_frame=sub.max_states)
+                sel = np.concatenate([np.arange(fo[k], fo[k + 1]) for k in over])
+                f2 = eng.gather_rows(feats, sel)
+                r2 = self._decode(sub, f2, fo2, sub.max_states, sub.max_states)
                 st2, ali2, w2 = r2["status"].cpu().numpy(), r2["ali"].cpu().numpy(), r2["words"].cpu().numpy()
                 nw2, like2 = r2["n_words"].cpu().numpy(), r2["like"].cpu().numpy()
                 ali, words = ali.copy(), words.copy()
@@ -175,40 +230,73 @@ class CorpusAligner:
                 a, b = int(fo[k]), int(fo[k + 1])
                 if status[k] in (0, 1):
                     results[i] = dict(ali=ali[a:b].copy(), words=words[a: a + int(n_words[k])].copy(), like=float(like[k]), frames=b - a)
-                elif status[k] > 2:
-                    raise RuntimeError(f"device decoder reported status {int(status[k])} for {utts[i].utt_id} (include/mfa_hip.h)")
+                elif status[k] == 2:
+                    self.failure_reasons.setdefault(utts[i].utt_id, "no alignment within the retry beam")
+                else:
+                    self.failure_reasons[utts[i].utt_id] = f"device decoder status {int(status[k])} (include/mfa_hip.h)"
             if want_feats:
+                if over:   # frames of utterances that still failed must not vote in the fMLLR statistics
+                    pass
+                bad = [k for k in range(len(idx)) if status[k] not in (0, 1)]
+                if bad:
+                    ali_dev = res["ali"].clone()
+                    for k in bad:
+                        ali_dev[int(fo[k]): int(fo[k + 1])] = 0
+                    res["ali"] = ali_dev
                 kept.append((idx, feats, res["ali"], fo, rows))
         return results, kept
 
     # ------------------------------------------------------------------ public
-    def align(self, utterances: Sequence[CorpusUtterance], speaker_adapted: bool = False, make_ctm: bool = True) -> List[Optional[UtteranceResult]]:
-        """First pass with speaker-independent features; with ``speaker_adapted`` (a SAT model, ``uses_speaker_adaptation``
-        in MFA) per-speaker fMLLR is estimated from it and a second pass is run with the transforms."""
+    def align(self, utterances: Sequence[CorpusUtterance], speaker_adapted: bool = False, make_ctm: bool = True,
+              previous_transforms: Optional[np.ndarray] = None) -> List[Optional[UtteranceResult]]:
+        """The reference's flow (MFA/alignment/base.py:510-539): first pass on speaker-independent features — with the
+        alignment model when the acoustic model ships one —; with ``speaker_adapted`` (a SAT model, ``uses_speaker_adaptation``
+        in MFA) per-speaker fMLLR is estimated from it and a second pass is run with the transforms on ``am``.
+        ``previous_transforms`` [n_spk, D, D+1] (speaker rows in first-appearance order): transforms the features already
+        carry in the first pass; the new estimate is composed onto them (CalcFmllrFunction's previous_transform_archive)."""
         import torch
 
         utts = list(utterances)
-        self.failed = []
+        self.failed, self.failure_reasons, self.fallback_first_pass = [], {}, []
         spk_ids, cmvn = self.speaker_cmvn(utts)
-        results, kept = self._pass(utts, spk_ids, cmvn, None, want_feats=speaker_adapted)
-        self.transforms: Optional[np.ndarray] = None
+        first_model = self.ali_am if self.ali_am is not None else self.am
+        self._load(first_model)
+        prev = None if previous_transforms is None else torch.from_numpy(np.asarray(previous_transforms, dtype=np.float32)).to(self.engine.device)
+        results, kept = self._pass(utts, spk_ids, cmvn, prev, want_feats=speaker_adapted)
+        self.transforms = None if previous_transforms is None else np.asarray(previous_transforms, dtype=np.float32)
         if speaker_adapted:
             if self.lda is None:
                 raise NotImplementedError("speaker adaptation needs the LDA feature path")
             D = self.lda.shape[0]
             beta = np.zeros(len(spk_ids)); K = np.zeros((len(spk_ids), D, D + 1)); G = np.zeros((len(spk_ids), D, D + 1, D + 1))
+            two_model = self.am if self.ali_am is not None else None
             for idx, feats, ali, fo, rows in kept:
-                ids, b, k, g = fmllr_statistics(self.engine, feats, fo, ali, self.tm, rows, self.silence_phones, self.opt.silence_weight)
+                ids, b, k, g = fmllr_statistics(self.engine, feats, fo, ali, self.tm, rows, self.silence_phones,
+                                                self.opt.silence_weight, stats_model=two_model)
                 beta[ids] += b; K[ids] += k; G[ids] += g
             W = np.tile(np.eye(D, D + 1, dtype=np.float32), (len(spk_ids), 1, 1))
             for s in range(len(spk_ids)):
                 W[s], _impr = _fmllr.compute_fmllr(beta[s], K[s], G[s], min_count=self.opt.fmllr_min_count)
+                if previous_transforms is not None:
+                    W[s] = _fmllr.compose_transforms(W[s], previous_transforms[s])
             self.transforms = W
+            self._load(self.am)
+            first = results
+            self.failure_reasons = {}
             results, _ = self._pass(utts, spk_ids, cmvn, torch.from_numpy(W).to(self.engine.device))
+            if self.ali_am is not None:
+                # an utterance the second pass lost keeps its first-pass (alignment-model) result:
+                # ali_first_pass / words_first_pass / likelihoods_first_pass, MFA/alignment/multiprocessing.py:1784-1860
+                for i, (r2, r1) in enumerate(zip(results, first)):
+                    if r2 is None and r1 is not None:
+                        results[i] = r1
+                        self.fallback_first_pass.append(utts[i].utt_id)
+                        self.failure_reasons.pop(utts[i].utt_id, None)
         out: List[Optional[UtteranceResult]] = []
         for u, r in zip(utts, results):
             if r is None:
                 self.failed.append(u.utt_id)
+                self.failure_reasons.setdefault(u.utt_id, "no alignment")
                 out.append(None)
                 continue
             ur = UtteranceResult(u.utt_id, u.speaker, r["ali"], r["words"], r["like"], r["frames"])
@@ -217,6 +305,8 @@ class CorpusAligner:
                 ur.ctm = _ctm.phones_to_pronunciations(self.lexicon, r["words"], ivs, text=u.text)
                 ur.ctm.likelihood = ur.per_frame_likelihood
                 ur.ctm.update_utterance_boundaries(u.begin, u.begin + len(u.pcm) / float(self.mfcc_options.get("sample_frequency", 16000.0)))
+                if u.text is not None:   # <unk> intervals get their transcript spelling (MFA/alignment/multiprocessing.py:1749-1751)
+                    ur.ctm.word_intervals = _ctm.fix_unk_words(u.text.split(), ur.ctm.word_intervals, self.lexicon)
             out.append(ur)
         return out
 

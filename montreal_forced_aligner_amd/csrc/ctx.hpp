@@ -64,7 +64,8 @@ struct mfa_ctx {
   int32_t *d_row0 = nullptr;   // [num_pdfs] first packed row
   int32_t *d_nblk = nullptr;   // [num_pdfs] number of 32-row blocks (slot 32) else 1
   int32_t *d_slot = nullptr;   // [num_pdfs] slot class rows (1,4,8,16,32)
-  std::vector<int32_t> h_slot, h_nblk;
+  std::vector<int32_t> h_slot, h_nblk, h_row0, h_ngauss;
+  float *d_w_stats = nullptr;  // packed rows of the fMLLR statistics model (two-model form; mfa_fmllr_stats_model) or NULL
   bool has_slot_class[5] = {false, false, false, false, false};   // model has pdfs of slot 32 / 16 / 8 / 4 / 1 rows
   bool has_single32 = false;       // some pdf is one 32-row block (17–32 Gaussians): gmm_split_single_kernel has work
   bool has_multi_block = false;    // some pdf has more than 32 Gaussians (several blocks, merged by gmm_bf16_kernel<…, true>)

@@ -9,6 +9,8 @@
 // dimension for a/b (ascending Gaussian order — the oracle's order).  Kernel 2 (block per speaker × group of 8 output
 // rows d): streams the speaker's frames through LDS in chunks of 64 and keeps 7 (e,f) pairs × 8 rows of G in registers
 // (float64 FMA); deterministic, no atomics.  Bound: f64 vector FMA (≈72 k DFMA per frame).
+#include <vector>
+
 #include "ctx.hpp"
 
 namespace {
@@ -19,6 +21,7 @@ constexpr int kChunk = 64;
 struct FmllrFrameParams {
   int D, kpad;
   const float *w; const float *gc; const int32_t *row0; const int32_t *nrows;  // packed model (gmm.hip layout)
+  const float *ws;   // packed rows of the model the statistics are formed with (two-model form) — same layout; == w otherwise
   const float *feats; const int32_t *ali_pdf; const float *weight; int64_t total_frames;
   float *a; float *b; float *cnt;
 };
@@ -73,8 +76,8 @@ __global__ __launch_bounds__(256) void fmllr_frame_kernel(FmllrFrameParams p) {
     float a = 0.0f, b = 0.0f;
     for (int g = 0; g < n; g++) {
       const float pg = ((volatile float *)post)[g];
-      a = fmaf(p.w[mfa_packed_offset(r0 + g, lane, p.kpad)], pg, a);
-      b = fmaf(-2.0f * p.w[mfa_packed_offset(r0 + g, p.D + lane, p.kpad)], pg, b);  // stored −½·inv_var
+      a = fmaf(p.ws[mfa_packed_offset(r0 + g, lane, p.kpad)], pg, a);
+      b = fmaf(-2.0f * p.ws[mfa_packed_offset(r0 + g, p.D + lane, p.kpad)], pg, b);  // stored −½·inv_var
     }
     a_out[lane] = a; b_out[lane] = b;
   }
@@ -189,11 +192,62 @@ MFA_API int mfa_fmllr_acc_batch(mfa_ctx *c, const float *d_feats, const int64_t 
     MFA_HIP_CHECK(c, hipMalloc((void **)&c->d_nrows, nrows.size() * 4));
     MFA_HIP_CHECK(c, hipMemcpy(c->d_nrows, nrows.data(), nrows.size() * 4, hipMemcpyHostToDevice));
   }
-  FmllrFrameParams fp{D, c->kpad, c->d_w, c->d_gc, c->d_row0, c->d_nrows, d_feats, d_ali_pdf, d_weight, total_frames, a, b, cnt};
+  FmllrFrameParams fp{D, c->kpad, c->d_w, c->d_gc, c->d_row0, c->d_nrows, c->d_w_stats ? c->d_w_stats : c->d_w,
+                      d_feats, d_ali_pdf, d_weight, total_frames, a, b, cnt};
   hipLaunchKernelGGL(fmllr_frame_kernel, dim3((unsigned)((total_frames + 3) / 4)), dim3(256), 0, c->stream, fp);
   FmllrSpkParams sp{D, d_feats, a, b, cnt, d_frame_off, d_spk_utt_off, d_spk_utt, d_beta, d_K, d_G};
   hipLaunchKernelGGL(fmllr_spk_kernel, dim3(n_spk, (D + 7) / 8), dim3(256), 0, c->stream, sp);
   MFA_HIP_CHECK(c, hipGetLastError());
+  return 0;
+}
+
+// alignment (transition-ids) → per-frame pdf and weight through the host-built tables (0 / unknown ids: weight 0)
+__global__ void fmllr_tid_lookup_kernel(const int32_t *ali, int64_t n, const int32_t *tid2pdf, const float *tid_weight,
+                                        int32_t n_tids, int32_t *pdf, float *weight) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const int tid = ali[t];
+  const bool ok = tid > 0 && tid < n_tids;
+  pdf[t] = ok ? tid2pdf[tid] : -1;
+  weight[t] = ok ? tid_weight[tid] : 0.0f;
+}
+
+MFA_API int mfa_fmllr_acc_ali_batch(mfa_ctx *c, const float *d_feats, const int64_t *d_frame_off, int32_t n_utt,
+                                    int64_t total_frames, const int32_t *d_ali, const int32_t *d_tid2pdf,
+                                    const float *d_tid_weight, int32_t n_tids, int32_t *d_pdf_scratch, float *d_weight_scratch,
+                                    const int32_t *d_spk_utt_off, const int32_t *d_spk_utt, int32_t n_spk, double *d_beta,
+                                    double *d_K, double *d_G) {
+  MFA_HIP_CHECK(c, hipSetDevice(c->device));
+  if (n_utt <= 0 || n_spk <= 0 || total_frames <= 0) return 0;
+  hipLaunchKernelGGL(fmllr_tid_lookup_kernel, dim3((unsigned)((total_frames + 255) / 256)), dim3(256), 0, c->stream, d_ali,
+                     total_frames, d_tid2pdf, d_tid_weight, n_tids, d_pdf_scratch, d_weight_scratch);
+  MFA_HIP_CHECK(c, hipGetLastError());
+  return mfa_fmllr_acc_batch(c, d_feats, d_frame_off, n_utt, total_frames, d_pdf_scratch, d_weight_scratch, d_spk_utt_off,
+                             d_spk_utt, n_spk, d_beta, d_K, d_G);
+}
+
+MFA_API int mfa_fmllr_stats_model(mfa_ctx *c, int32_t dim, int32_t num_pdfs, const int32_t *h_pdf_offsets,
+                                  const float *h_means_invvars, const float *h_inv_vars) {
+  MFA_HIP_CHECK(c, hipSetDevice(c->device));
+  if (c->d_w_stats) { MFA_HIP_CHECK(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->d_w_stats); c->d_w_stats = nullptr; }
+  if (!h_means_invvars) return 0;   // back to the single-model form
+  if (!c->gmm_ready) return c->fail("mfa_load_gmm has not been called");
+  if (dim != c->dim || num_pdfs != c->num_pdfs) return c->fail("fMLLR statistics model: %d pdfs of dim %d, loaded model has %d of dim %d", num_pdfs, dim, c->num_pdfs, c->dim);
+  for (int p = 0; p < num_pdfs; p++)
+    if (h_pdf_offsets[p + 1] - h_pdf_offsets[p] != c->h_ngauss[p])
+      return c->fail("fMLLR statistics model: pdf %d has %d Gaussians, the loaded (alignment) model %d — the two models must share their Gaussian layout", p, h_pdf_offsets[p + 1] - h_pdf_offsets[p], c->h_ngauss[p]);
+  const int blocks = (c->num_rows + 1 + 31) / 32;
+  std::vector<float> w((size_t)blocks * 32 * c->kpad, 0.0f);
+  for (int p = 0; p < num_pdfs; p++) {
+    const int g0 = h_pdf_offsets[p], g = h_pdf_offsets[p + 1] - g0;
+    for (int i = 0; i < g; i++) {
+      const float *mi = h_means_invvars + (size_t)(g0 + i) * dim, *iv = h_inv_vars + (size_t)(g0 + i) * dim;
+      for (int k = 0; k < 2 * dim; k++)
+        w[mfa_packed_offset(c->h_row0[p] + i, k, c->kpad)] = k < dim ? mi[k] : -0.5f * iv[k - dim];
+    }
+  }
+  MFA_HIP_CHECK(c, hipMalloc((void **)&c->d_w_stats, w.size() * 4));
+  MFA_HIP_CHECK(c, hipMemcpy(c->d_w_stats, w.data(), w.size() * 4, hipMemcpyHostToDevice));
   return 0;
 }
 

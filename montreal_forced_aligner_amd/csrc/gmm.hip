@@ -1738,6 +1738,11 @@ MFA_API int mfa_load_gmm(mfa_ctx *c, int32_t dim, int32_t num_pdfs, const int32_
   c->dim = dim; c->kpad = kpad; c->num_pdfs = num_pdfs; c->num_rows = rows;
   c->h_slot = slot;
   c->h_nblk = nblk;
+  c->h_row0.assign(row0.begin(), row0.begin() + num_pdfs);
+  c->h_ngauss.resize(num_pdfs);
+  for (int p = 0; p < num_pdfs; p++) c->h_ngauss[p] = h_pdf_offsets[p + 1] - h_pdf_offsets[p];
+  if (c->d_w_stats) { (void)hipFree(c->d_w_stats); c->d_w_stats = nullptr; }   // belonged to the previous model's layout
+  if (c->d_nrows) { (void)hipFree(c->d_nrows); c->d_nrows = nullptr; }
   c->all_single_block = true;   // (name kept: "all pdfs are 32-row pdfs", single- or multi-block)
   c->has_multi_block = false;
   for (int q = 0; q < 5; q++) c->has_slot_class[q] = false;

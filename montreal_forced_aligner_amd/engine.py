@@ -338,6 +338,19 @@ class AlignmentEngine:
                                                  _ptr(n_words), _ptr(like), _ptr(flike), _ptr(status)), "mfa_align_batch")
         return dict(ali=ali, words=words, n_words=n_words, like=like, status=status, frame_like=flike)
 
+    def gather_rows(self, feats: torch.Tensor, rows: np.ndarray) -> torch.Tensor:
+        """Rows ``rows`` of a device matrix as a new contiguous device matrix (device-to-device copies of the contiguous
+        runs; no arithmetic)."""
+        rows = np.asarray(rows, dtype=np.int64)
+        out = torch.empty((rows.shape[0], feats.shape[1]), dtype=feats.dtype, device=feats.device)
+        if rows.shape[0] == 0:
+            return out
+        cuts = np.nonzero(np.diff(rows) != 1)[0] + 1
+        starts = np.concatenate([[0], cuts]); ends = np.concatenate([cuts, [rows.shape[0]]])
+        for a, b in zip(starts, ends):
+            out[a:b].copy_(feats[int(rows[a]): int(rows[a]) + int(b - a)])
+        return out
+
     def align_features(self, graphs: PackedGraphs, feats: torch.Tensor, frame_off: np.ndarray, beam: float = 10.0,
                        retry_beam: float = 40.0, acoustic_scale: float = 0.1, max_tokens: int = 1024,
                        bp_tokens_per_frame: int = 512, want_frame_likes: bool = False, window: int = 64,
@@ -582,20 +595,34 @@ class Pipeline:
 
 
 def fmllr_statistics(engine: "AlignmentEngine", feats: torch.Tensor, frame_off: np.ndarray, ali: torch.Tensor,
-                     tm: TransitionModel, utt2spk: np.ndarray, silence_phones: Sequence[int], silence_weight: float = 0.0):
+                     tm: TransitionModel, utt2spk: np.ndarray, silence_phones: Sequence[int], silence_weight: float = 0.0,
+                     stats_model: Optional[DiagGmmModel] = None):
     """Per-speaker fMLLR statistics from first-pass alignments (mfa_fmllr_acc_batch).
 
     ``ali``: int32 [ΣT] transition-ids (0 where an utterance failed: those frames get weight 0).  Returns
-    (speaker ids, beta [S], K [S,D,D+1], G [S,D,D+1,D+1]) as float64 numpy arrays."""
+    (speaker ids, beta [S], K [S,D,D+1], G [S,D,D+1,D+1]) as float64 numpy arrays.
+
+    ``stats_model``: the two-model form the reference runs for models that ship ``final.alimdl``
+    (FmllrComputer(ali_model_path, model_path, …), MFA/corpus/features.py:503-511): posteriors from the model loaded in the
+    engine (the alignment model), statistics with ``stats_model``'s means and variances (``final.mdl``)."""
     dev = engine.device
+    if stats_model is not None:
+        po = np.ascontiguousarray(stats_model.pdf_offsets, dtype=np.int32)
+        mi = np.ascontiguousarray(stats_model.means_invvars, dtype=np.float32)
+        iv = np.ascontiguousarray(stats_model.inv_vars, dtype=np.float32)
+        check(engine.ctx, engine.lib.mfa_fmllr_stats_model(engine.ctx, stats_model.dim, stats_model.num_pdfs, po.ctypes.data,
+                                                           mi.ctypes.data, iv.ctypes.data), "mfa_fmllr_stats_model")
+    else:
+        check(engine.ctx, engine.lib.mfa_fmllr_stats_model(engine.ctx, 0, 0, None, None, None), "mfa_fmllr_stats_model")
     id2pdf = torch.from_numpy(np.maximum(tm.id2pdf, 0).astype(np.int32)).to(dev)
     sil = np.zeros(tm.id2phone.shape[0], dtype=np.float32)
     sil[np.isin(tm.id2phone, np.asarray(list(silence_phones), dtype=np.int64))] = 1.0
-    w_of_tid = torch.from_numpy(np.where(sil > 0, np.float32(silence_weight), np.float32(1.0)).astype(np.float32)).to(dev)
-    w_of_tid[0] = 0.0
-    ali64 = ali.to(torch.int64)
-    pdf = id2pdf[ali64].contiguous()
-    weight = w_of_tid[ali64].contiguous()
+    w_host = np.where(sil > 0, np.float32(silence_weight), np.float32(1.0)).astype(np.float32)
+    w_host[0] = 0.0
+    w_of_tid = torch.from_numpy(w_host).to(dev)
+    ali = ali.to(torch.int32).contiguous() if ali.dtype != torch.int32 else ali.contiguous()
+    pdf = torch.empty(ali.shape[0], dtype=torch.int32, device=dev)       # scratch: the lookup runs inside the library
+    weight = torch.empty(ali.shape[0], dtype=torch.float32, device=dev)
     spk_ids, inv = np.unique(np.asarray(utt2spk), return_inverse=True)
     n_spk = len(spk_ids)
     order = np.argsort(inv, kind="stable").astype(np.int32)
@@ -605,7 +632,8 @@ def fmllr_statistics(engine: "AlignmentEngine", feats: torch.Tensor, frame_off: 
     K = torch.zeros((n_spk, D, D + 1), dtype=torch.float64, device=dev)
     G = torch.zeros((n_spk, D, D + 1, D + 1), dtype=torch.float64, device=dev)
     d_fo, d_so, d_su = engine._dev(frame_off), engine._dev(spk_off), engine._dev(order)
-    check(engine.ctx, engine.lib.mfa_fmllr_acc_batch(engine.ctx, _ptr(feats), _ptr(d_fo), len(frame_off) - 1, int(frame_off[-1]),
-                                                      _ptr(pdf), _ptr(weight), _ptr(d_so), _ptr(d_su), n_spk, _ptr(beta),
-                                                      _ptr(K), _ptr(G)), "mfa_fmllr_acc_batch")
+    check(engine.ctx, engine.lib.mfa_fmllr_acc_ali_batch(engine.ctx, _ptr(feats), _ptr(d_fo), len(frame_off) - 1,
+                                                          int(frame_off[-1]), _ptr(ali), _ptr(id2pdf), _ptr(w_of_tid),
+                                                          int(id2pdf.shape[0]), _ptr(pdf), _ptr(weight), _ptr(d_so), _ptr(d_su),
+                                                          n_spk, _ptr(beta), _ptr(K), _ptr(G)), "mfa_fmllr_acc_ali_batch")
     return spk_ids, beta.cpu().numpy(), K.cpu().numpy(), G.cpu().numpy()

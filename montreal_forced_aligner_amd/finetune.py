@@ -129,7 +129,7 @@ def fine_tune_boundaries(aligner, compiler: _graph.TrainingGraphCompiler, pcm: S
         rows.append(np.arange(frame_off[k] + a, frame_off[k] + b, dtype=np.int64))
         new_off.append(new_off[-1] + (b - a))
     new_off = np.asarray(new_off, dtype=np.int64)
-    sub = feats[torch.from_numpy(np.concatenate(rows)).to(eng.device)].contiguous() if new_off[-1] else feats[:0]
+    sub = eng.gather_rows(feats, np.concatenate(rows)) if new_off[-1] else feats[:0]   # device-to-device copies of the windows
     # ---- two-phone graphs (cached per group pair)
     cache: Dict[Tuple[Tuple[int, ...], Tuple[int, ...]], object] = {}
     fsts = []
@@ -146,7 +146,7 @@ def fine_tune_boundaries(aligner, compiler: _graph.TrainingGraphCompiler, pcm: S
         graphs = eng.pack_graphs([fsts[k] for k in sel], tm)
         fo = np.concatenate([[0], np.cumsum([new_off[k + 1] - new_off[k] for k in sel])]).astype(np.int64)
         idx = np.concatenate([np.arange(new_off[k], new_off[k + 1]) for k in sel])
-        x = sub[torch.from_numpy(idx).to(eng.device)].contiguous()
+        x = eng.gather_rows(sub, idx)
         ll, ll_off, ll_cols = eng.score(x, fo, graphs.pdf_list, graphs.pdf_off_host, graphs.class_counts,
                                         pdf_first_frame=graphs.pdf_first_frame)
         res = eng.align(graphs, ll, ll_off, ll_cols, fo, beam=aligner.beam, retry_beam=aligner.retry_beam,
@@ -213,12 +213,12 @@ def phone_confidence(engine, feats, frame_off: np.ndarray, phone_pdf_counts: Dic
     W = np.zeros((num_pdfs, len(names)), dtype=np.float64)
     for p, (pdfs, w) in table.items():
         np.add.at(W[:, index[p]], col_of[pdfs], w)
-    d_w = torch.from_numpy(W).to(engine.device)
+    ll_host = ll.cpu().numpy()     # the phone scores are host arithmetic, as in the reference (numpy, :1415-1440)
     out = []
     for u in range(n_utt):
         T = int(frame_off[u + 1] - frame_off[u])
-        likes = ll[ll_off[u]: ll_off[u + 1]].view(T, num_pdfs).to(torch.float64)
-        phone_likes = (likes @ d_w).cpu().numpy()
+        likes = ll_host[ll_off[u]: ll_off[u + 1]].reshape(T, num_pdfs).astype(np.float64)
+        phone_likes = likes @ W
         top = phone_likes.argmax(axis=1)
         begin0 = 0.0 if utt_begins is None else utt_begins[u]
         res = []

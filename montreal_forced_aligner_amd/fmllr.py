@@ -55,3 +55,15 @@ def compute_fmllr(beta: float, K: np.ndarray, G: np.ndarray, num_iters: int = 40
     if impr < 0.0 and not abs(new - old) <= 0.001 * (abs(new) + abs(old)):
         return W0.astype(np.float32), 0.0
     return W.astype(np.float32), float(impr)
+
+
+def compose_transforms(new: np.ndarray, previous: np.ndarray) -> np.ndarray:
+    """Affine composition ``new ∘ previous`` of two fMLLR matrices [D, D+1] (Kaldi ComposeTransforms with b_is_affine):
+    features that already carry ``previous`` were used to estimate ``new``; the product applies to the untransformed ones
+    (the ``previous_transform_archive`` branch of CalcFmllrFunction, MFA/corpus/features.py:482-512)."""
+    new = np.asarray(new, dtype=np.float64)
+    prev = np.asarray(previous, dtype=np.float64)
+    D = new.shape[0]
+    A = new[:, :D] @ prev[:, :D]
+    b = new[:, :D] @ prev[:, D] + new[:, D]
+    return np.concatenate([A, b[:, None]], axis=1).astype(np.float32)

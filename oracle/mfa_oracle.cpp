@@ -760,9 +760,27 @@ ORC_API int32_t orc_version() { return 1; }
 // Statistics: beta (count), K [D][D+1], G [D][(D+1)x(D+1)] (full symmetric storage here), all double.
 // ---------------------------------------------------------------------------
 // One utterance: frame t is aligned to pdf ali_pdf[t] with weight w[t] (0 for silence frames when silence_weight = 0).
+// Two-model form (the one the reference runs for every model that ships final.alimdl — MFA/corpus/features.py:503-511:
+// FmllrComputer(ali_model_path, model_path, ...)): Gaussian posteriors come from the ALIGNMENT model (gconsts,
+// means_invvars, inv_vars) evaluated on the speaker-independent features, the statistics a, b are formed with the FINAL
+// model's means and variances (stat_means_invvars, stat_inv_vars) — Kaldi gmm-post-to-gpost with the alignment model
+// followed by FmllrDiagGmmAccs::AccumulateFromPosteriors on the final one; the two models share their Gaussian layout.
+// stat_* == NULL is the single-model form.
+ORC_API void orc_fmllr_acc2(const float *feats, int32_t T, int32_t D, const int32_t *ali_pdf, const float *weight,
+                            const float *gconsts, const float *means_invvars, const float *inv_vars,
+                            const float *stat_means_invvars, const float *stat_inv_vars,
+                            const int32_t *pdf_offsets, double *beta, double *K /*[D][D+1]*/, double *G /*[D][D+1][D+1]*/);
 ORC_API void orc_fmllr_acc(const float *feats, int32_t T, int32_t D, const int32_t *ali_pdf, const float *weight,
                            const float *gconsts, const float *means_invvars, const float *inv_vars,
                            const int32_t *pdf_offsets, double *beta, double *K /*[D][D+1]*/, double *G /*[D][D+1][D+1]*/) {
+  orc_fmllr_acc2(feats, T, D, ali_pdf, weight, gconsts, means_invvars, inv_vars, nullptr, nullptr, pdf_offsets, beta, K, G);
+}
+ORC_API void orc_fmllr_acc2(const float *feats, int32_t T, int32_t D, const int32_t *ali_pdf, const float *weight,
+                            const float *gconsts, const float *means_invvars, const float *inv_vars,
+                            const float *stat_means_invvars, const float *stat_inv_vars,
+                            const int32_t *pdf_offsets, double *beta, double *K /*[D][D+1]*/, double *G /*[D][D+1][D+1]*/) {
+  const float *smi = stat_means_invvars ? stat_means_invvars : means_invvars;
+  const float *siv = stat_inv_vars ? stat_inv_vars : inv_vars;
   const int D1 = D + 1;
   std::vector<float> x2(D), ll, a(D), b(D);
   std::vector<double> xplus(D1);
@@ -785,7 +803,7 @@ ORC_API void orc_fmllr_acc(const float *feats, int32_t T, int32_t D, const int32
     for (int g = 0; g < n; g++) {
       float post = ll[g] * inv * weight[t];
       count += post;
-      const float *mi = means_invvars + (size_t)(g0 + g) * D, *iv = inv_vars + (size_t)(g0 + g) * D;
+      const float *mi = smi + (size_t)(g0 + g) * D, *iv = siv + (size_t)(g0 + g) * D;
       for (int d = 0; d < D; d++) { a[d] = fmaf(mi[d], post, a[d]); b[d] = fmaf(iv[d], post, b[d]); }
     }
     if (count == 0.0f) continue;

@@ -223,17 +223,23 @@ def split_to_phones(ali, id2state, is_self_loop, is_final, tuples):
     return out[:n].copy(), bool(ok.value)
 
 
-def fmllr_acc(feats, ali_pdf, weight, gconsts, means_invvars, inv_vars, pdf_offsets, stats=None):
-    """Accumulate fMLLR statistics of one utterance; stats = (beta[1], K[D,D+1], G[D,D+1,D+1]) float64, created if None."""
+def fmllr_acc(feats, ali_pdf, weight, gconsts, means_invvars, inv_vars, pdf_offsets, stats=None, stat_means_invvars=None,
+              stat_inv_vars=None):
+    """Accumulate fMLLR statistics of one utterance; stats = (beta[1], K[D,D+1], G[D,D+1,D+1]) float64, created if None.
+    With ``stat_means_invvars`` / ``stat_inv_vars`` the posteriors come from (gconsts, means_invvars, inv_vars) — the
+    alignment model — and the statistics from the stat_* arrays — the final model (MFA/corpus/features.py:503-511)."""
     feats = np.ascontiguousarray(feats, np.float32)
     T, D = feats.shape
     if stats is None:
         stats = (np.zeros(1), np.zeros((D, D + 1)), np.zeros((D, D + 1, D + 1)))
     beta, K, G = stats
-    lib().orc_fmllr_acc(_p(feats), C.c_int32(T), C.c_int32(D), _p(np.ascontiguousarray(ali_pdf, np.int32)),
-                        _p(np.ascontiguousarray(weight, np.float32)), _p(np.ascontiguousarray(gconsts, np.float32)),
-                        _p(np.ascontiguousarray(means_invvars, np.float32)), _p(np.ascontiguousarray(inv_vars, np.float32)),
-                        _p(np.ascontiguousarray(pdf_offsets, np.int32)), _p(beta), _p(K), _p(G))
+    smi = None if stat_means_invvars is None else np.ascontiguousarray(stat_means_invvars, np.float32)
+    siv = None if stat_inv_vars is None else np.ascontiguousarray(stat_inv_vars, np.float32)
+    lib().orc_fmllr_acc2(_p(feats), C.c_int32(T), C.c_int32(D), _p(np.ascontiguousarray(ali_pdf, np.int32)),
+                         _p(np.ascontiguousarray(weight, np.float32)), _p(np.ascontiguousarray(gconsts, np.float32)),
+                         _p(np.ascontiguousarray(means_invvars, np.float32)), _p(np.ascontiguousarray(inv_vars, np.float32)),
+                         None if smi is None else _p(smi), None if siv is None else _p(siv),
+                         _p(np.ascontiguousarray(pdf_offsets, np.int32)), _p(beta), _p(K), _p(G))
     return stats
 
 

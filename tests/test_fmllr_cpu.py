@@ -68,3 +68,49 @@ def test_solver_host_vs_oracle_and_recovers_known_transform():
     W_i, impr_i = F.compute_fmllr(100.0, K, G)
     assert impr_i == 0.0 and np.array_equal(W_i[:, :D], np.eye(D, dtype=np.float32))
     assert O.fmllr_solve(100.0, K, G)[1] == 0.0
+
+
+def test_two_model_accumulation_and_transform_composition():
+    """Two-model form (posteriors from the alignment model, statistics from the final model — MFA/corpus/features.py:503-511)
+    against a float64 numpy restatement, and compose_transforms (previous_transform_archive, :482-512) as plain algebra."""
+    from montreal_forced_aligner_amd import fmllr as F
+
+    rng = np.random.default_rng(12)
+    D, T = 5, 60
+    sizes = [3, 1, 4]
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+
+    def model(seed):
+        r = np.random.default_rng(seed)
+        n = int(offs[-1])
+        mean = r.normal(0, 2, size=(n, D)); var = r.uniform(0.5, 2, size=(n, D))
+        w = np.concatenate([r.dirichlet(np.ones(s)) for s in sizes])
+        gc = np.log(w) - 0.5 * (D * np.log(2 * np.pi) + np.log(var).sum(1) + (mean * mean / var).sum(1))
+        return gc.astype(np.float32), (mean / var).astype(np.float32), (1 / var).astype(np.float32)
+
+    gc_a, mi_a, iv_a = model(1)
+    gc_f, mi_f, iv_f = model(2)
+    x = rng.normal(0, 2, size=(T, D)).astype(np.float32)
+    pdf = rng.integers(0, len(sizes), size=T).astype(np.int32)
+    w = (rng.random(T) > 0.2).astype(np.float32)
+    beta, K, G = O.fmllr_acc(x, pdf, w, gc_a, mi_a, iv_a, offs, stat_means_invvars=mi_f, stat_inv_vars=iv_f)
+    rb, rK, rG = 0.0, np.zeros((D, D + 1)), np.zeros((D, D + 1, D + 1))
+    for t in range(T):
+        if w[t] == 0:
+            continue
+        a, b = offs[pdf[t]], offs[pdf[t] + 1]
+        xd = x[t].astype(np.float64)
+        ll = gc_a[a:b] + mi_a[a:b].astype(np.float64) @ xd - 0.5 * iv_a[a:b].astype(np.float64) @ (xd * xd)
+        post = np.exp(ll - ll.max()); post /= post.sum()
+        xi = np.append(xd, 1.0)
+        rb += 1.0
+        rK += np.outer(post @ mi_f[a:b], xi)
+        bb = post @ iv_f[a:b]
+        rG += bb[:, None, None] * np.outer(xi, xi)[None]
+    assert abs(beta[0] - rb) < 1e-4 and np.allclose(K, rK, rtol=1e-4, atol=1e-3) and np.allclose(G, rG, rtol=1e-4, atol=1e-3)
+    W1 = np.concatenate([np.eye(D) + 0.1 * rng.normal(size=(D, D)), rng.normal(size=(D, 1))], axis=1).astype(np.float32)
+    W2 = np.concatenate([np.eye(D) + 0.1 * rng.normal(size=(D, D)), rng.normal(size=(D, 1))], axis=1).astype(np.float32)
+    Wc = F.compose_transforms(W2, W1)
+    v = rng.normal(size=D)
+    once = W1[:, :D] @ v + W1[:, D]
+    assert np.allclose(Wc[:, :D] @ v + Wc[:, D], W2[:, :D] @ once + W2[:, D], atol=1e-5)
