@@ -66,6 +66,10 @@ class AlignOptions:
     batch_frames: int = 2_000_000   # frames per device batch (≈ 2 000 ten-second utterances)
     fmllr_min_count: float = 500.0
     silence_weight: float = 0.0
+    # `mfa align` (the corpus path) stores raw MFCCs and the CMVN-applied features as 8-bit Kaldi CompressedMatrix tables
+    # (MFA/corpus/features.py:235, :356-365) and therefore aligns features quantised twice; `align_one` / the online path
+    # keep float32 (the default here).  True reproduces the corpus path's two quantisations (host-side codec).
+    corpus_compression: bool = False
 
 
 class CorpusAligner:
@@ -142,7 +146,36 @@ class CorpusAligner:
 
         so = np.concatenate([[0], np.cumsum([len(utts[i].pcm) for i in idx])]).astype(np.int64)
         pcm = torch.from_numpy(np.concatenate([np.ascontiguousarray(utts[i].pcm, dtype=np.int16) for i in idx])).to(self.engine.device)
-        return self.engine.mfcc(pcm, so)
+        mfcc, fo = self.engine.mfcc(pcm, so)
+        if self.opt.corpus_compression:      # feats.*.ark of MfccFunction: compute_mfccs_for_export(seg, compress=True)
+            from . import kaldi_io as _kio
+            host = mfcc.cpu().numpy()
+            for k in range(len(idx)):
+                a, b = int(fo[k]), int(fo[k + 1])
+                if b > a:
+                    host[a:b] = _kio.compress_round_trip(host[a:b])
+            mfcc = torch.from_numpy(host).to(self.engine.device)
+        return mfcc, fo
+
+    def _final_features(self, mfcc, fo, rows, cmvn, d_lda, fmllr):
+        """CMVN → Δ+ΔΔ | splice+LDA(+fMLLR).  With ``corpus_compression`` the CMVN-applied MFCCs take the second trip
+        through the 8-bit codec first (FinalFeatureFunction, MFA/corpus/features.py:323-365), on the host."""
+        import torch
+
+        eng = self.engine
+        if not self.opt.corpus_compression:
+            return eng.features(mfcc, fo, rows, cmvn, lda=d_lda, fmllr=fmllr)
+        from . import kaldi_io as _kio
+        host = mfcc.cpu().numpy()
+        stats = cmvn.cpu().numpy()
+        dim = host.shape[1]
+        for k in range(len(fo) - 1):
+            a, b = int(fo[k]), int(fo[k + 1])
+            if b > a:
+                st = stats[rows[k]]
+                mean = (st[0, :dim] / st[0, dim]).astype(np.float32)       # ApplyCmvn, no variance normalisation
+                host[a:b] = _kio.compress_round_trip(host[a:b] - mean)
+        return eng.features(torch.from_numpy(host).to(eng.device), fo, rows, None, lda=d_lda, fmllr=fmllr)
 
     def speaker_cmvn(self, utts: Sequence[CorpusUtterance]) -> Tuple[Dict[str, int], "object"]:
         """calc_cmvn: float64 [n_spk, 2, dim+1] on the device, and the speaker → row map."""
@@ -199,7 +232,7 @@ class CorpusAligner:
                 continue
             mfcc, fo = self._mfcc(utts, idx)
             rows = np.array([spk_ids[utts[i].speaker] for i in idx], dtype=np.int32)
-            feats = eng.features(mfcc, fo, rows, cmvn, lda=d_lda, fmllr=fmllr)
+            feats = self._final_features(mfcc, fo, rows, cmvn, d_lda, fmllr)
             graphs = eng.pack_graphs(fsts, self.tm)
             res = self._decode(graphs, feats, fo, o.max_tokens, o.bp_tokens_per_frame)
             status = res["status"].cpu().numpy()

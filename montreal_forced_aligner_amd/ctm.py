@@ -150,7 +150,7 @@ def phones_to_pronunciations(lexicon, word_ids: Sequence[int], intervals: Sequen
     variants, optional-silence intervals in between — is solved as a search over (word index, interval index) with
     backtracking, so a variant that is a prefix of another cannot steal the following word's phones.  With
     position-dependent phones the aligned labels carry ``_B/_I/_E/_S`` and a variant must match them exactly (the word-end
-    evidence decides between "a b" + "c" and "a" + "b c"); silence phones never carry a position.  Optional-silence
+    evidence decides between "a b" + "c" and "a" + "b c").  Optional-silence
     intervals between words become ``silence_word`` entries, as MFA stores them."""
     sil = lexicon.silence_phone
     pos_dep = bool(lexicon.position_dependent_phones)
@@ -170,13 +170,9 @@ def phones_to_pronunciations(lexicon, word_ids: Sequence[int], intervals: Sequen
         return out
 
     def expected(ph: List[str]) -> List[str]:
-        if not pos_dep:
-            return ph
-        plain = [q for q in ph]
-        if any(q == sil or q == getattr(lexicon, "oov_phone", None) for q in plain):   # silence-type phones carry no position
-            return [q if (q == sil or q == getattr(lexicon, "oov_phone", None)) else lab
-                    for q, lab in zip(plain, _position_labels(plain))]
-        return _position_labels(plain)
+        # every phone of a WORD carries its position, the oov word's spn included (spn_S — LexiconCompiler.phone_ids and
+        # tests/data/dictionaries/expected/lexicon.text.fst); only the optional silence between words is a bare phone
+        return _position_labels(ph) if pos_dep else ph
 
     var_cache = [[(ph, expected(ph)) for ph in variants(w)] for w in words]
     dead = set()          # (word index, interval index) states known to have no completion

@@ -231,6 +231,44 @@ class LexiconCompiler:
             out.append(k)
         return out
 
+    # -- the lexicon as one transducer (text form) ---------------------------------------------------
+    def lexicon_fst_text(self) -> str:
+        """L.fst in OpenFst text form, the structure kalpy's LexiconCompiler / Kaldi's make_lexicon_fst_silprob build and
+        the reference keeps an expected copy of (tests/data/dictionaries/expected/lexicon.text.fst): state 0 start, state 1
+        the loop state (final), state 2 the silence state;  0→1 on <eps> (−ln(1−p_init)) or on the silence phone
+        (−ln p_init);  2→1 on the silence phone;  every pronunciation leaves the loop state with its word as output on its
+        first phone and returns to the loop state (−ln(1−p_sil)) or to the silence state (−ln p_sil) on its last.
+        ``phone_graph`` is this transducer composed with a linear transcript (the ε arc folded into its successors);
+        writing it out lets the construction be checked against the reference's own expected file."""
+        def w(cost: float) -> str:
+            return "" if cost == 0.0 else "\t" + repr(float(cost))
+
+        sil = self.silence_phone
+        lines = [f"0\t1\t<eps>\t<eps>{w(_cost(1.0 - self.initial_silence_probability))}",
+                 f"0\t1\t{sil}\t<eps>{w(_cost(self.initial_silence_probability))}",
+                 f"2\t1\t{sil}\t<eps>"]
+        nxt = 3
+        for word, prons in self._by_word.items():
+            no_probs = all(p.probability is None for p in prons)
+            for p in prons:
+                syms = [self.phone_table.find(k) for k in self.phone_ids(p)]
+                pc = 0.0 if no_probs else _cost(p.probability if p.probability is not None else 1.0)
+                p_after = p.silence_after_probability if p.silence_after_probability is not None else self.silence_probability
+                cur = 1
+                for k, ph in enumerate(syms):
+                    ol = word if k == 0 else "<eps>"
+                    c = pc if k == 0 else 0.0
+                    if k < len(syms) - 1:
+                        lines.append(f"{cur}\t{nxt}\t{ph}\t{ol}{w(c)}")
+                        cur = nxt
+                        nxt += 1
+                    else:
+                        lines.append(f"{cur}\t1\t{ph}\t{ol}{w(c + _cost(1.0 - p_after))}")
+                        if p_after > 0:
+                            lines.append(f"{cur}\t2\t{ph}\t{ol}{w(c + _cost(p_after))}")
+        lines.append("1\t0")
+        return "\n".join(lines) + "\n"
+
     # -- phone-level graph for one transcript -------------------------------------------------------
     def phone_graph(self, words: Sequence[str]) -> "PhoneGraph":
         """Linear transcript composed with the lexicon (Kaldi make_lexicon_fst[_silprob] structure):

@@ -7,6 +7,7 @@ Host-side plumbing only: nothing here touches the GPU.
 """
 from __future__ import annotations
 
+import io
 import struct
 import zipfile
 from dataclasses import dataclass, field
@@ -191,6 +192,17 @@ def write_compressed_matrix(f: BinaryIO, m: np.ndarray) -> None:
         data[c] = np.where(col < f25, lo, np.where(col < f75, mid, hi)).astype(np.uint8)
     f.write(hdr.astype("<u2").tobytes())
     f.write(data.tobytes())
+
+
+def compress_round_trip(m: np.ndarray) -> np.ndarray:
+    """What a feature matrix looks like after it has been written to and read back from a Kaldi CompressedMatrix table
+    (8-bit, per-column headers) — the corpus path of the reference stores raw MFCCs and the CMVN-applied features this way
+    (MFA/corpus/features.py:235, :356-365), so `mfa align` aligns features quantised twice."""
+    buf = io.BytesIO()
+    write_compressed_matrix(buf, m)
+    r = BinaryReader(buf.getvalue())
+    fmt = r.token()
+    return _read_compressed(r, fmt)
 
 
 def write_vector(f: BinaryIO, v: np.ndarray) -> None:

@@ -108,8 +108,8 @@ def test_word_grouping_uses_word_position_suffixes():
     import pytest
     with pytest.raises(C.CtmError):   # a_B cannot end a word
         C.phones_to_pronunciations(lex, [lex.to_int("ab"), lex.to_int("bc")], _ivs(["a_B", "b_B", "c_E"]))
-    # the out-of-vocabulary word is spelt by the position-less oov phone
-    h = C.phones_to_pronunciations(lex, [lex.to_int("zzz"), lex.to_int("c")], _ivs(["spn", "c_S"]))
+    # the out-of-vocabulary word is a one-phone word: spn_S (tests/data/dictionaries/expected/lexicon.text.fst)
+    h = C.phones_to_pronunciations(lex, [lex.to_int("zzz"), lex.to_int("c")], _ivs(["spn_S", "c_S"]))
     assert [(w.label, w.pronunciation) for w in h.word_intervals] == [("<unk>", "spn"), ("c", "c")]
 
 

@@ -59,3 +59,34 @@ def test_oracle_reproduces_golden_scores_graph_and_alignment(fx, gold):
     # the product's host code splits the same alignment into the same phones
     from montreal_forced_aligner_amd import ctm as C
     assert [(a, n, p) for a, n, p in C.split_to_phones(gold["ali"], tm)] == [tuple(r) for r in gold["phone_intervals"].tolist()]
+
+
+def test_oracle_against_reference_output_when_captured(fx):
+    """tools/capture_kalpy_golden.py (run by hand where kalpy is installed) writes tests/golden/kalpy_vectors.npz: the same
+    inputs through the reference's own dependency.  Absent here (kalpy cannot be installed: parity unpinned) → skipped;
+    present → the oracle must reproduce the reference's numbers (north_star bars: alignment identical, log-likelihood
+    within 1e-3 per frame; features / scores to float32 FFT and summation-order noise)."""
+    import os
+
+    path = os.environ.get("MFA_KALPY_GOLDEN", str(helpers.REF.parent / "kalpy_vectors.npz"))
+    if not os.path.exists(path):
+        pytest.skip("no reference capture (tools/capture_kalpy_golden.py has not been run where kalpy exists)")
+    ref = np.load(path)
+    wave = fx.pcm[: int(ref["pcm_samples"])].astype(np.float32)
+    for snip in (0, 1):
+        assert np.abs(O.mfcc(wave, O.default_mfcc_opts(snip_edges=snip)) - ref[f"mfcc_snip{snip}"]).max() < 2e-3
+    mf = ref["mfcc_snip0"]
+    stats = O.cmvn_stats([mf])
+    assert np.allclose(stats, ref["cmvn_stats"], rtol=1e-9, atol=1e-6)
+    x = O.deltas(O.cmvn_apply(stats, mf))
+    assert np.abs(x - ref["delta_feats"]).max() < 1e-4
+    assert np.abs(O.affine(O.splice(O.cmvn_apply(stats, mf)), fx.g2p_lda) - ref["lda_feats"]).max() < 1e-3
+    tm, am = fx.mono_tm, fx.mono_am
+    ll = O.gmm_loglikes(ref["delta_feats"][:50], am.gconsts, am.means_invvars, am.inv_vars, am.pdf_offsets, np.arange(am.num_pdfs))
+    assert np.abs(ll - ref["loglikes_first50_allpdfs"]).max() < 1e-3
+    fst = fx.mono_graph(str(ref["text"]))
+    pl = np.unique(tm.id2pdf[fst.arcs["ilabel"]])
+    lls = O.gmm_loglikes(ref["delta_feats"], am.gconsts, am.means_invvars, am.inv_vars, am.pdf_offsets, pl)
+    res = helpers.oracle_align(tm, fst, lls, pl, beam=100.0, retry_beam=400.0)
+    assert np.array_equal(res["ali"], ref["ali"]) and np.array_equal(res["words"], ref["words"])
+    assert abs(res["like"] - float(ref["like"])) / len(ref["ali"]) < 1e-3

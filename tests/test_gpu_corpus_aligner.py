@@ -53,3 +53,42 @@ def test_corpus_aligner_on_reference_fixture(engine, fx, tmp_path):
     res2 = al.align([utts[2], bad])
     assert res2[0] is not None and res2[1] is None and al.failed == ["spkB-x"]
 
+
+
+def test_corpus_path_double_compression_flag(engine, fx):
+    """`mfa align` aligns features that went through Kaldi's 8-bit CompressedMatrix twice (raw MFCC, then CMVN-applied:
+    MFA/corpus/features.py:235, :356-365); AlignOptions(corpus_compression=True) reproduces both quantisations.  Checked
+    against the oracle fed the same round-tripped features: identical alignment; and against the float path: the
+    quantisation is visible but small."""
+    from montreal_forced_aligner_amd import kaldi_io as K
+    from montreal_forced_aligner_amd.aligner import AlignOptions, CorpusAligner, CorpusUtterance
+
+    sr = 16000
+    cuts = [("spkA", 0.0, 4.2, "this is the acoustic corpus i'm talking pretty fast here"),
+            ("spkA", 4.0, 6.5, "there's nothing going else going on")]
+    utts = [CorpusUtterance(f"{s}-{k}", s, fx.pcm[int(a * sr): int(b * sr)], t) for k, (s, a, b, t) in enumerate(cuts)]
+    al = CorpusAligner(fx.mono_tm, fx.mono_am, fx.mono_tree, fx.mono_lex, engine=engine,
+                       options=AlignOptions(beam=100.0, retry_beam=400.0, corpus_compression=True))
+    res = al.align(utts, make_ctm=False)
+    plain = CorpusAligner(fx.mono_tm, fx.mono_am, fx.mono_tree, fx.mono_lex, engine=engine,
+                          options=AlignOptions(beam=100.0, retry_beam=400.0)).align(utts, make_ctm=False)
+    assert all(r is not None for r in res) and all(r is not None for r in plain)
+    am, tm = fx.mono_am, fx.mono_tm
+    # the device MFCCs (what the aligner compressed), CMVN statistics from the round-tripped matrices, second round trip
+    so = np.concatenate([[0], np.cumsum([len(u.pcm) for u in utts])]).astype(np.int64)
+    import torch
+    mfcc, fo = engine.mfcc(torch.from_numpy(np.concatenate([u.pcm for u in utts])).to(engine.device), so)
+    mf = [K.compress_round_trip(mfcc.cpu().numpy()[fo[k]: fo[k + 1]]) for k in range(2)]
+    stats = O.cmvn_stats(mf)
+    moved = 0
+    for u, r, p, m in zip(utts, res, plain, mf):
+        x = O.deltas(K.compress_round_trip(O.cmvn_apply(stats, m)))
+        fst = fx.mono_graph(u.text)
+        pl = np.unique(tm.id2pdf[fst.arcs["ilabel"]])
+        ref = helpers.oracle_align(tm, fst, O.gmm_loglikes(x, am.gconsts, am.means_invvars, am.inv_vars, am.pdf_offsets, pl), pl,
+                                   beam=100.0, retry_beam=400.0)
+        assert np.array_equal(r.alignment, ref["ali"])
+        assert abs(r.per_frame_likelihood - ref["like"] / len(ref["ali"])) < 1e-3
+        assert abs(r.per_frame_likelihood - p.per_frame_likelihood) < 0.5     # same utterance, slightly different features
+        moved += int((r.alignment != p.alignment).sum())
+    assert moved < 0.2 * sum(len(r.alignment) for r in res)

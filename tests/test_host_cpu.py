@@ -160,3 +160,48 @@ def test_compressed_matrix_round_trip_and_scp(tmp_path):
     cache = {}
     assert K.read_scp_object(cache, entries[1][1], entries[1][2], "matrix").shape == (3, 4)
     assert [k for k, _ in K.read_ark(ark.read_bytes(), "matrix")] == ["spk1-utt1", "spk1-utt2"]
+
+
+def _parse_text_fst(text):
+    arcs, finals = [], {}
+    for line in text.strip().split("\n"):
+        f = line.split()
+        if len(f) <= 2:
+            finals[int(f[0])] = float(f[1]) if len(f) == 2 else 0.0
+        else:
+            arcs.append((int(f[0]), int(f[1]), f[2], f[3], float(f[4]) if len(f) > 4 else 0.0))
+    n = 1 + max([a[0] for a in arcs] + [a[1] for a in arcs] + list(finals))
+    return n, arcs, finals
+
+
+def test_lexicon_fst_equals_the_references_expected_file():
+    """The only vector the reference holds for the graph builder: tests/data/dictionaries/expected/
+    {lexicon.text.fst, phones.txt, words.txt} for a two-word position-dependent dictionary (copied as data under
+    tests/golden/ref_fixtures/expected_*).  LexiconCompiler's phone table must equal phones.txt line for line and its
+    L.fst must equal lexicon.text.fst up to a renumbering of states, weights to 1e-12."""
+    import itertools
+
+    from montreal_forced_aligner_amd import graph as G
+    from tests import helpers
+
+    lex = G.LexiconCompiler(position_dependent_phones=True, silence_word="!SIL", oov_word="<unk>", silence_phone="sil",
+                            oov_phone="spn", silence_probability=0.5, initial_silence_probability=0.5, ignore_case=False)
+    for w, p in (("!SIL", "sil"), ("<unk>", "spn"), ("worda", "phonea phoneb"), ("wordb", "phonea phonec")):
+        lex.add_pronunciation(G.Pronunciation(w, p))
+    lex.build_phone_table()
+    want_phones = [ln.split() for ln in (helpers.REF / "expected_phones.txt").read_text().strip().split("\n")]
+    assert [[s, str(k)] for k, s in lex.phone_table] == want_phones
+    want_words = [ln.split()[0] for ln in (helpers.REF / "expected_words.txt").read_text().strip().split("\n")]
+    got_words = [s for _k, s in lex.word_table]
+    assert want_words[0] == "<eps>" and want_words[1:5] == got_words[:4]      # same order after the reference's <eps> entry
+    na, arcs_a, fin_a = _parse_text_fst(lex.lexicon_fst_text())
+    nb, arcs_b, fin_b = _parse_text_fst((helpers.REF / "expected_lexicon.text.fst").read_text())
+    assert na == nb and len(arcs_a) == len(arcs_b)
+
+    def canon(arcs, finals, perm):
+        return (sorted((perm[s], perm[d], il, ol, round(w, 12)) for s, d, il, ol, w in arcs),
+                sorted((perm[s], round(w, 12)) for s, w in finals.items()))
+
+    target = canon(arcs_b, fin_b, list(range(nb)))
+    assert any(canon(arcs_a, fin_a, (0,) + perm) == target for perm in itertools.permutations(range(1, na))), \
+        "no renumbering of states maps the generated L.fst onto the reference's expected one"
