@@ -48,7 +48,7 @@ def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=4096, help="utterances per step per GPU")
     ap.add_argument("--pool", type=int, default=0,
                     help="distinct synthetic utterances generated per rank (0 = one per batch slot: all distinct)")
@@ -70,6 +70,10 @@ def parse_args(argv=None):
                     help="1: windowed scoring of the cells live decoder tokens can ask for (mfa_align_features_batch); "
                          "0: score the whole (reachability-bounded) matrix, then decode")
     ap.add_argument("--window", type=int, default=64, help="frames per scoring/decoding window of the lazy path")
+    ap.add_argument("--inflight", type=int, default=3,
+                    help="batches in flight per GPU: steps alternate between this many pipelines (own HIP stream, engine "
+                         "context and buffers each), so that the short latency-bound tails of a step — retry-beam and "
+                         "table-growth passes over a handful of utterances — run under the next step's kernels")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo to rehearse "
                                                            "several ranks on one GPU)")
     ap.add_argument("--verbose", action="store_true")
@@ -259,9 +263,25 @@ def main():
     log(rank, f"batch of {B} graphs packed in {time.time() - t0:.1f}s")
     ids_k, inv_k = np.unique(utt_spk, return_inverse=True)
     fm_k = None if mono else torch.from_numpy(fm_np[ids_k % n_spk_total]).to(dev)
-    pipe = Pipeline(eng, pcm_all, sample_off, inv_k.astype(np.int32), graphs, lda=d_lda, fmllr=fm_k,
-                    beam=args.beam, retry_beam=args.retry_beam, max_tokens=args.max_tokens, bp_tokens_per_frame=args.bp_tokens,
-                    reachability=bool(args.reachability), lazy=bool(args.lazy), window=args.window)
+    # one Pipeline per batch in flight: own stream, own engine context (decoder workspace), own feature / score / output
+    # buffers; the PCM, the graphs and the model arrays are read-only and shared
+    n_inflight = max(1, args.inflight)
+    engines, pipes, streams = [], [], []
+    for k in range(n_inflight):
+        st = torch.cuda.current_stream(dev) if k == 0 else torch.cuda.Stream(dev)
+        with torch.cuda.stream(st):
+            e_k = eng
+            if k > 0:
+                e_k = AlignmentEngine(local_rank)
+                e_k.configure_mfcc()
+                e_k.load_gmm(model.am)
+            pipes.append(Pipeline(e_k, pcm_all, sample_off, inv_k.astype(np.int32), graphs, lda=d_lda, fmllr=fm_k,
+                                  beam=args.beam, retry_beam=args.retry_beam, max_tokens=args.max_tokens,
+                                  bp_tokens_per_frame=args.bp_tokens, reachability=bool(args.reachability),
+                                  lazy=bool(args.lazy), window=args.window))
+        engines.append(e_k)
+        streams.append(st)
+    pipe = pipes[0]
     torch.cuda.synchronize()
     log(rank, f"setup {time.time() - t_setup:.1f}s; HBM in use {torch.cuda.memory_allocated(dev) / 2**30:.1f} GiB "
               f"(+ Viterbi workspace); audio per step {pipe.audio_seconds:.0f}s")
@@ -286,13 +306,18 @@ def main():
         np.save(os.environ["MFA_VIT_STAMPS"], stamps.cpu().numpy().reshape(pipe.n_utt, 12))
 
     # pinned host buffers the alignments land in (the boundary's host side): ali, words, n_words, like, status
-    host_out = pipe.host_output_buffers(pinned)
+    host_outs = [p_.host_output_buffers(pinned) for p_ in pipes]
+    host_out = host_outs[0]
+    turn = {"i": 0}
 
     def step_resident():
-        pipe.step()
-        pipe.outputs_to_host(host_out)
+        k = turn["i"] % n_inflight
+        turn["i"] += 1
+        with torch.cuda.stream(streams[k]):
+            pipes[k].step()
+            pipes[k].outputs_to_host(host_outs[k])
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, n_inflight)):   # (every pipeline runs at least once before the clock starts)
         step_resident()
     torch.cuda.synchronize()
     status = host_out["status"].numpy().copy()
@@ -318,59 +343,71 @@ def main():
             dt_ = float(t.item())
         return dt_
 
-    eng.kernel_timing(True)
-    eng.reset_kernel_times()
+    for e_ in engines:
+        e_.kernel_timing(True)
+        e_.reset_kernel_times()
     dt = timed_loop(step_resident, args.steps)
-    ktimes = eng.kernel_times()
-    eng.kernel_timing(False)
+    ktimes = {}
+    for e_ in engines:     # HIP-event times on each pipeline's own stream (kernels of two streams may overlap in wall time)
+        for k_, v_ in e_.kernel_times().items():
+            acc_ = ktimes.setdefault(k_, dict(ms=0.0, launches=0))
+            acc_["ms"] += v_["ms"]
+            acc_["launches"] += v_["launches"]
+        e_.kernel_timing(False)
     total_utts = B * args.steps * world
     value = total_utts / dt
 
     extra = {}
     if not args.no_extra_loops:
-        # ---- host-fed loop: PCM from pinned host memory, two device buffers, H2D of step i+1 under the kernels of step i
+        # ---- host-fed loop: PCM from pinned host memory; every pipeline in flight has its own device PCM buffer and copy
+        # stream, so the H2D of one step travels under the kernels of the other pipeline's step (and, with one pipeline,
+        # two buffers alternate: the copy of step i+1 under the kernels of step i)
         n_hf = max(3, min(args.steps, 10))
-        bufs = [pcm_all, torch.empty_like(pcm_all)]
-        copy_stream = torch.cuda.Stream(dev)
-        main_stream = torch.cuda.current_stream(dev)
-        ev_copied = [torch.cuda.Event() for _ in range(2)]
-        ev_free = [torch.cuda.Event() for _ in range(2)]
-        state = {"i": 0}
+        n_buf = 2 if n_inflight == 1 else 1
+        bufs = [[torch.empty_like(pcm_all) for _ in range(n_buf)] for _ in pipes]
+        copy_streams = [torch.cuda.Stream(dev) for _ in pipes]
+        ev_copied = [[torch.cuda.Event() for _ in range(n_buf)] for _ in pipes]
+        ev_free = [[torch.cuda.Event() for _ in range(n_buf)] for _ in pipes]
+        for k in range(n_inflight):
+            for b_ in range(n_buf):
+                ev_free[k][b_].record(streams[k])
+        hf = {"i": 0, "queued": [0] * n_inflight}
 
-        def enqueue_copy(i):
-            b = i % 2
-            with torch.cuda.stream(copy_stream):
-                copy_stream.wait_event(ev_free[b])          # the step that last read this buffer has finished
-                bufs[b].copy_(pcm_host, non_blocking=True)
-                ev_copied[b].record(copy_stream)
-
-        for b in range(2):
-            ev_free[b].record(main_stream)
+        def enqueue_copy(k, j):
+            b_ = j % n_buf
+            with torch.cuda.stream(copy_streams[k]):
+                copy_streams[k].wait_event(ev_free[k][b_])      # the step that last read this buffer has finished
+                bufs[k][b_].copy_(pcm_host, non_blocking=True)
+                ev_copied[k][b_].record(copy_streams[k])
 
         def step_host_fed():
-            i = state["i"]
-            if i == 0:
-                enqueue_copy(0)
-            enqueue_copy(i + 1)                              # next step's PCM travels while this step computes
-            b = i % 2
-            main_stream.wait_event(ev_copied[b])
-            pipe.pcm = bufs[b]
-            pipe.step()
-            ev_free[b].record(main_stream)
-            pipe.outputs_to_host(host_out)
-            state["i"] = i + 1
+            i = hf["i"]
+            k, j = i % n_inflight, i // n_inflight
+            hf["i"] = i + 1
+            while hf["queued"][k] <= j + (n_buf - 1):            # this step's copy, and the next one's when double-buffered
+                enqueue_copy(k, hf["queued"][k])
+                hf["queued"][k] += 1
+            b_ = j % n_buf
+            with torch.cuda.stream(streams[k]):
+                streams[k].wait_event(ev_copied[k][b_])
+                pipes[k].pcm = bufs[k][b_]
+                pipes[k].step()
+                ev_free[k][b_].record(streams[k])
+                pipes[k].outputs_to_host(host_outs[k])
 
-        step_host_fed()                                      # warm-up (first copy not overlapped)
+        for _ in range(n_inflight):
+            step_host_fed()                                  # warm-up (first copies not overlapped)
         torch.cuda.synchronize()
         dt_hf = timed_loop(step_host_fed, n_hf)
         torch.cuda.synchronize()
-        pipe.pcm = pcm_all
+        for p_ in pipes:
+            p_.pcm = pcm_all
         extra["value_host_fed"] = round(B * n_hf * world / dt_hf, 2)
         extra["host_fed"] = {"steps": n_hf, "ms_per_step": round(dt_hf / n_hf * 1e3, 3), "pinned": pinned,
                              "pcm_bytes_per_step": int(pcm_all.numel() * 2),
                              "h2d_GBps_needed": round(pcm_all.numel() * 2 / (dt_hf / n_hf) / 1e9, 2),
-                             "what": "PCM in pinned host memory -> double-buffered H2D on a copy stream under the previous "
-                                     "step's kernels -> device path -> ali/words/n_words/like/status in pinned host memory"}
+                             "what": "PCM in pinned host memory -> H2D on a copy stream under other steps' kernels -> device "
+                                     "path -> ali/words/n_words/like/status in pinned host memory"}
         del bufs
         # ---- strict-precision scoring, same resident-input loop (driver-verifiable): bf16x3 and bit-exact f32
         n_px = max(2, min(args.steps, 5))
@@ -380,7 +417,8 @@ def main():
             old = {k: os.environ.get(k) for k in env}
             os.environ.update(env)
             try:
-                step_resident()
+                for _ in range(n_inflight):
+                    step_resident()
                 torch.cuda.synchronize()
                 st2 = host_out["status"].numpy()
                 ok2 = int(((st2 == 0) | (st2 == 1)).sum())
@@ -394,7 +432,8 @@ def main():
                         os.environ.pop(k, None)
                     else:
                         os.environ[k] = v
-        step_resident()
+        for _ in range(n_inflight):
+            step_resident()
         torch.cuda.synchronize()
 
     # ---- roofline of the dominant kernel of the step (largest share of the per-stage HIP-event times)
@@ -433,6 +472,7 @@ def main():
             "batch_per_gpu": B, "utterances_total": total_utts, "distinct_utterances_per_gpu": n_pool,
             "frames_per_utt": int(pipe.max_frames), "parallelism": f"utterance-sharded x{world}, no collective",
             "inputs": "PCM + graphs resident in HBM; alignments copied to pinned host memory inside every step",
+            "batches_in_flight": n_inflight,
             "scores": pipe.scores_string(),
         },
         "real_time_factor": dt / (pipe.audio_seconds * args.steps * world),
@@ -470,7 +510,8 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
-    eng.close()
+    for e_ in engines:
+        e_.close()
 
 
 if __name__ == "__main__":

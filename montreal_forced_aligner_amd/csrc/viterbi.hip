@@ -19,6 +19,7 @@
 // per-utterance HBM workspace (288 GB lets every in-flight utterance keep its own).  No MFMA: this is min-plus DP.
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 
 #include <algorithm>
@@ -33,6 +34,7 @@ typedef unsigned int u32;
 
 constexpr u32 kEmpty = 0xFFFFFFFFu;
 constexpr u32 kClaim = 0xFFFFFFFEu;
+constexpr u32 kOver = 0xFFFFFFFDu;   // hash bucket of a state that found no free slot (the frame is about to report overflow)
 constexpr u64 kKeyInf = 0xFFFFFFFFFFFFFFFFull;
 constexpr int kMinActive = 20;
 constexpr float kBeamDelta = 0.5f;
@@ -50,6 +52,7 @@ struct VitParams {
   const float *ll; const int64_t *ll_off; const int32_t *ll_cols; const int64_t *frame_off;
   float beam, scale;
   int nmax, cmax, bpf;        // live-token capacity, candidate capacity, back-pointer tokens per frame
+  int hbits;                  // log2 of the state→slot hash table size (>= 4 x nmax entries)
   const int32_t *utt_list;    // utterances to decode (NULL: identity)
   const int32_t *n_list;      // number of entries in utt_list (device scalar) or NULL
   int pass;                   // 0 first beam, 1 retry
@@ -153,8 +156,9 @@ constexpr int kArcCache = 8;  // arcs per token kept in registers during expansi
 
 // kListsInLds: the two token lists (state, cost) live in LDS (fast path) or, for graphs/beams whose tables would not
 // fit in 160 KiB, in the per-utterance HBM workspace.
+// (waves_per_eu 4: at most 128 VGPRs, so that the 9.5 KB first tier really gets its 16 wavefronts per CU)
 template <bool kListsInLds>
-__global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void viterbi_kernel(VitParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x;
   int utt = blockIdx.x;
@@ -183,17 +187,22 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
   u64 *s_cost = (u64 *)smem;                  // [N] best cost key per slot
   double *l_cost0 = kListsInLds ? (double *)(s_cost + N)   // [2][N] token costs (current / next list)
                                          : (double *)(p.w_cost + (size_t)utt * 2 * N);
-  u32 *slot_of = (u32 *)(s_cost + (kListsInLds ? 3 : 1) * (size_t)N);  // [S] state → slot
-  const int S2 = (S + 1) & ~1;
-  u32 *s_state = slot_of + S2;      // [N]
+  // state → slot: an open-addressing hash table (linear probing) over the states that received a candidate THIS frame —
+  // at most N of them, whatever the size of the graph, so the table is 4N entries instead of one per graph state
+  // (round 1: a direct map, 10.8 KB of the 23 KB a 2 700-state graph needed → 6 wavefronts per CU; now 16).
+  u32 *hmap = (u32 *)(s_cost + (kListsInLds ? 3 : 1) * (size_t)N);  // [HM] slot index | kEmpty | kClaim | kOver
+  const u32 HM = 1u << p.hbits, hmask = HM - 1u;
+  const int hshift = 32 - p.hbits;
+  u32 *s_state = hmap + HM;         // [N]
   u32 *s_F = s_state + N;           // [N] first creating candidate (pos<<6|k)
   u32 *s_W = s_F + N;               // [N] winning candidate
   u32 *s_aux = s_W + N;             // [N] (rank<<24)|ordinal of the bucket leader's first candidate
   u32 *t_cbase = s_aux + N;         // [N] candidate ordinal base per source token
   u32 *s_an = t_cbase + N;          // [N] (first arc << 7 | out-degree) of the slot's state
-  u32 *l_state0 = kListsInLds ? s_an + N : (u32 *)(p.w_state + (size_t)utt * 2 * N);  // [2][N] token states
+  u32 *s_bucket = s_an + N;         // [N] hash bucket the slot's state was filed under (reset at the end of the frame)
+  u32 *l_state0 = kListsInLds ? s_bucket + N : (u32 *)(p.w_state + (size_t)utt * 2 * N);  // [2][N] token states
   u32 *l_an0 = kListsInLds ? l_state0 + 2 * N : (u32 *)(p.w_state + (size_t)p.g.n_utt * 2 * N + (size_t)utt * 2 * N);
-  u32 *cntord = s_an + N + (kListsInLds ? 4 * N : 0);  // [C] bucket sizes at leader ordinals → exclusive sums
+  u32 *cntord = s_bucket + N + (kListsInLds ? 4 * N : 0);  // [C] bucket sizes at leader ordinals → exclusive sums
   float *ll_row = (float *)(cntord + C);      // [llcap] this frame's score row
   u32 *ctr = (u32 *)(ll_row + p.llcap);       // [2]: nslots, nstash
 
@@ -204,7 +213,7 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
   const u64 bp_cap = (u64)T * (u64)p.bpf;
   u32 *tokoff = p.w_tokoff + f0 + utt;
 
-  for (int i = lane; i < S; i += 64) slot_of[i] = kEmpty;
+  for (u32 i = lane; i < HM; i += 64) hmap[i] = kEmpty;
   for (int i = lane; i < C; i += 64) cntord[i] = 0;
   if (lane == 0) { ctr[0] = 0; ctr[1] = 0; }
 
@@ -353,20 +362,47 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
     // Candidate creation in three wavefront phases (each phase's LDS operations are issued back to back):
     //   look up the destination's slot → claim missing slots (CAS; the winner allocates, initialises, publishes)
     //   → re-read the published slot and lower its cost / first-creator with LDS atomics.
-    auto claim = [&](u32 d, u32 dan) {
-      u32 old = atomicCAS(&slot_of[d], kEmpty, kClaim);
-      if (old == kEmpty) {
-        u32 my = atomicAdd(&ctr[0], 1u);
-        if (my < (u32)N) { s_state[my] = d; s_an[my] = dan; s_cost[my] = kKeyInf; s_F[my] = kEmpty; s_W[my] = kEmpty; }
-        slot_of[d] = my;
+    auto hash_of = [&](u32 d) -> u32 { return (d * 2654435761u) >> hshift; };
+    // read-only lookup (after every candidate of the frame has been filed): slot of state d, or kEmpty
+    auto find = [&](u32 d) -> u32 {
+      u32 h = hash_of(d);
+      for (;;) {
+        const u32 v = hmap[h];
+        if (v == kEmpty) return kEmpty;
+        if (v < (u32)N && s_state[v] == d) return v;
+        h = (h + 1u) & hmask;
       }
     };
-    auto lower = [&](u32 d, double cnw, u32 cidx) -> u32 {
-      u32 s = slot_of[d];
-      if (s >= (u32)N) return kEmpty;
+    // One probe step of find-or-insert for a pending candidate (wavefront-collective loops below call it in rounds with
+    // a hand-over point between rounds): an empty bucket is claimed by compare-and-swap, the winner allocates a slot,
+    // initialises it and publishes the index; a lane that lost the race (kClaim seen, or its own CAS failed) looks again
+    // next round and finds either its own state (done) or a different one (moves on to the next bucket).
+    auto probe = [&](bool &pend, u32 &h, u32 &res, u32 d, u32 dan) {
+      if (!pend) return;
+      const u32 v = hmap[h];
+      if (v == kEmpty) {
+        if (atomicCAS(&hmap[h], kEmpty, kClaim) == kEmpty) {
+          const u32 my = atomicAdd(&ctr[0], 1u);
+          if (my < (u32)N) {
+            s_state[my] = d; s_an[my] = dan; s_cost[my] = kKeyInf; s_F[my] = kEmpty; s_W[my] = kEmpty; s_bucket[my] = h;
+            hmap[h] = my;
+            res = my;
+          } else {
+            hmap[h] = kOver;            // no slot left: nslots > N is reported right after the expansion
+            res = kEmpty;
+          }
+          pend = false;
+        }
+      } else if (v == kOver) {
+        res = kEmpty; pend = false;
+      } else if (v != kClaim) {
+        if (s_state[v] == d) { res = v; pend = false; }
+        else h = (h + 1u) & hmask;
+      }
+    };
+    auto lower = [&](u32 s, double cnw, u32 cidx) {
       atomicMin(&s_cost[s], dkey(cnw));
       atomicMin(&s_F[s], cidx);
-      return s;
     };
     u32 cand_base = 0;
     bool bad_degree = false;
@@ -410,10 +446,16 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
         const bool created = valid && nw < local + (double)abeam;
         const u32 cidx = (tok << kArcBits) | k;
         STAMP(4);   // running cutoff (seed, prefix-min)
-        const u32 s0 = created ? slot_of[nx] : 0u;
-        if (created && s0 == kEmpty) claim(nx, nan_);
-        WSYNC();  // claims are published before anybody re-reads the map
-        const u32 sl = created ? lower(nx, nw, cidx) : kEmpty;
+        u32 sl = kEmpty;
+        {
+          bool pend = created; u32 h = hash_of(nx);
+          while (__any(pend)) {                           // slots are published before anybody re-reads
+            probe(pend, h, sl, nx, nan_);
+            WSYNC();
+            if (ctr[0] > (u32)N) break;                   // out of slots: the frame reports the overflow below
+          }
+        }
+        if (sl != kEmpty) lower(sl, nw, cidx);
         WSYNC();  // every candidate of the frame has lowered its slot's cost
         if (sl != kEmpty && dkey(nw) == s_cost[sl]) atomicMin(&s_W[sl], cidx);
         STAMP(5);   // claim / lower / winner
@@ -472,21 +514,34 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
         // Candidate creation in three wavefront phases (each phase's LDS operations are issued back to back):
         //   look up the destination's slot → claim missing slots (CAS; the winner allocates, initialises, publishes)
         //   → re-read the published slot and lower its cost / first-creator with LDS atomics.
-        bool cr[kArcCache]; u32 s0[kArcCache];
+        bool cr[kArcCache]; u32 hk[kArcCache];
+        bool any_pend = false;
   #pragma unroll
         for (int k = 0; k < kArcCache; k++) {
           cr[k] = (k < narc) && (nw[k] < local + (double)abeam);
           if (k < narc) local = fmin(local, nw[k]);
-          s0[k] = cr[k] ? slot_of[nx[k]] : 0u;
+          hk[k] = hash_of(nx[k]);
+          any_pend |= cr[k];
         }
+        {
+          bool pend[kArcCache];
   #pragma unroll
-        for (int k = 0; k < kArcCache; k++)
-          if (k < maxarc && cr[k] && s0[k] == kEmpty) claim(nx[k], nan_[k]);
-        WSYNC();  // claims are published before anybody re-reads the map
+          for (int k = 0; k < kArcCache; k++) pend[k] = cr[k];
+          while (__any(any_pend)) {     // all arcs of all tokens of the chunk are filed in the same rounds
+            any_pend = false;
+  #pragma unroll
+            for (int k = 0; k < kArcCache; k++) {
+              probe(pend[k], hk[k], sl[k], nx[k], nan_[k]);
+              any_pend |= pend[k];
+            }
+            WSYNC();
+            if (ctr[0] > (u32)N) break;                   // out of slots: the frame reports the overflow below
+          }
+        }
   #pragma unroll
         for (int k = 0; k < kArcCache; k++) {
           if (k < maxarc) {  // uniform
-            sl[k] = cr[k] ? lower(nx[k], nw[k], ((u32)i << kArcBits) | (u32)k) : kEmpty;
+            if (sl[k] != kEmpty) lower(sl[k], nw[k], ((u32)i << kArcBits) | (u32)k);
             if (!single && sl[k] != kEmpty) {
               u32 q = atomicAdd(&ctr[1], 1u);
               if (q < (u32)C) { st_a[q] = sl[k]; st_b[q] = ((u32)i << kArcBits) | (u32)k; st_key[q] = dkey(nw[k]); }
@@ -502,9 +557,12 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
             d = a_rec[a0 + k].x;
             dan = a_rec[a0 + k].y;
           }
-          if (created && slot_of[d] == kEmpty) claim(d, dan);
-          WSYNC();
-          u32 s = created ? lower(d, cnw, ((u32)i << kArcBits) | (u32)k) : kEmpty;
+          u32 s = kEmpty;
+          {
+            bool pend = created; u32 h = hash_of(d);
+            while (__any(pend)) { probe(pend, h, s, d, dan); WSYNC(); if (ctr[0] > (u32)N) break; }
+          }
+          if (s != kEmpty) lower(s, cnw, ((u32)i << kArcBits) | (u32)k);
           if (s != kEmpty) {  // tail candidates always go through the stash
             u32 q = atomicAdd(&ctr[1], 1u);
             if (q < (u32)C) { st_a[q] = s; st_b[q] = ((u32)i << kArcBits) | (u32)k; st_key[q] = dkey(cnw); }
@@ -548,7 +606,7 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
         if ((u32)S > H) {
           nb = 0;
           for (u32 m = d % H; m < (u32)S; m += H) {
-            u32 sm = slot_of[m];
+            u32 sm = find(m);
             if (sm < (u32)N) {
               u32 Fm = s_F[sm];
               nb++;
@@ -599,7 +657,7 @@ __global__ __launch_bounds__(64) void viterbi_kernel(VitParams p) {
     WSYNC();
     for (u32 j0 = 0; j0 < nslots; j0 += 64) {
       u32 j = j0 + lane;
-      if (j < nslots) { slot_of[s_state[j]] = kEmpty; cntord[s_aux[j] & 0xFFFFFFu] = 0; }
+      if (j < nslots) { hmap[s_bucket[j]] = kEmpty; cntord[s_aux[j] & 0xFFFFFFu] = 0; }
     }
     if (lane == 0) { tokoff[t] = (u32)bp_used; ctr[0] = 0; ctr[1] = 0; }
     bp_used += nslots;
@@ -766,9 +824,11 @@ __global__ void arcnext_kernel(mfa_graph_batch g, uint4 *out) {
 }
 
 constexpr int kLlCap = 512;
+// state→slot hash table: a power of two, at least four entries per live-token slot
+int hash_bits(int N) { int b = 8; while ((1 << b) < 4 * N) b++; return b; }
 size_t lds_bytes(int S, int N, int C, bool lists_in_lds) {
-  int S2 = (S + 1) & ~1;
-  return (size_t)N * 8 + (size_t)S2 * 4 + (size_t)N * 6 * 4 + (size_t)C * 4 + (size_t)kLlCap * 4 + 16 +
+  (void)S;   // nothing in the decoder's LDS scales with the graph any more
+  return (size_t)N * 8 + ((size_t)4 << hash_bits(N)) + (size_t)N * 7 * 4 + (size_t)C * 4 + (size_t)kLlCap * 4 + 16 +
          (lists_in_lds ? (size_t)N * 32 : 0);
 }
 constexpr size_t kLdsLimit = 160 * 1024;
@@ -866,7 +926,11 @@ int align_impl(mfa_ctx *c, const mfa_graph_batch *g, const float *d_loglikes, co
   // the same beam, at the caller's full capacity.  Then the retry-beam pass for utterances that did not reach a final state.
   struct Launch { int pass, N, C, code, grow; };
   std::vector<Launch> plan;
-  constexpr int kSmallTokens = 128;
+  // First-tier capacity.  With the hashed state→slot table nothing in the decoder's LDS scales with the graph: 64 tokens
+  // need 9.5 KB → 16 wavefronts per CU (a whole batch of 4 096 resident at once on 256 CUs), 128 tokens 14.6 KB → 10.
+  // MFA_VIT_TIER overrides (diagnostics).
+  int kSmallTokens = lazy ? 64 : 128;
+  { const char *e = getenv("MFA_VIT_TIER"); if (e && atoi(e) >= 64) kSmallTokens = (atoi(e) + 63) & ~63; }
   if (N[0] > kSmallTokens) {
     int cs = std::min(C[0], 4 * kSmallTokens);
     plan.push_back({0, kSmallTokens, cs, 0, 1});
@@ -893,7 +957,7 @@ int align_impl(mfa_ctx *c, const mfa_graph_batch *g, const float *d_loglikes, co
     memset(&p, 0, sizeof(p));
     p.g = *g; p.ll = d_loglikes; p.ll_off = d_ll_off; p.ll_cols = d_ll_cols; p.frame_off = d_frame_off;
     p.beam = ps == 0 ? o->beam : o->retry_beam; p.scale = o->acoustic_scale;
-    p.nmax = L.N; p.cmax = L.C; p.bpf = bpf; p.pass = ps; p.grow = L.grow;
+    p.nmax = L.N; p.cmax = L.C; p.bpf = bpf; p.pass = ps; p.grow = L.grow; p.hbits = hash_bits(L.N);
     // workspace strides follow this launch's capacities (lists and stash are per-launch scratch)
     WsLayout wp = ws_layout(n_utt, total_frames, L.N, L.C, bpf, total_arcs);
     p.w_state = (u32 *)(base + wp.state); p.w_cost = (double *)(base + wp.cost);
