@@ -70,6 +70,13 @@ struct VitParams {
   // windowed (resumable) decoding — mfa_align_features_batch: one launch decodes frames [t_begin, t_end) of every utterance,
   // parks the live token list in the HBM workspace and leaves the band of graph depths the NEXT window can touch
   int windowed, t_begin, t_end, next_window;
+  // Two table sizes per window (first-beam pass of mfa_align_features_batch): redo_mode 1 = the small first tier — an
+  // utterance that runs out of token slots (or enters the window with more tokens than the tier holds) is flagged in
+  // w_redo and left exactly as it was parked at the window's start; redo_mode 2 = the large tier, launched right after for
+  // the SAME window: only flagged utterances run.  0: a token overflow is final (or ST_GROW).
+  int redo_mode;
+  u32 *w_redo;                         // [n_utt]
+  int npark;                           // stride (tokens) of the parked lists: the large tier's capacity, whatever tier runs
   VitState *w_vstate;                  // [n_utt]
   const int32_t *state_depth;          // [total_states][2] {fewest arcs from start, most arcs from start} (mfa_score_plan)
   int32_t *band;                       // [n_utt][2] out: {min longest-path depth of a live token, max BFS depth + next_window - 1}
@@ -166,6 +173,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     if (p.n_list && (int)blockIdx.x >= *p.n_list) return;
     utt = p.utt_list[blockIdx.x];
   }
+  if (p.redo_mode == 2 && p.w_redo[utt] == 0u) return;   // large tier: only what the small tier handed over
   const int64_t so = p.g.d_state_off[utt];
   const int S = (int)(p.g.d_state_off[utt + 1] - so);
   const int64_t ab_ = p.g.d_arc_base[utt];
@@ -226,9 +234,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   u64 bp_used = 0;
   int t = 0;
   // token lists parked in HBM between windows (the kListsInLds = false variant keeps them there all the time)
-  u32 *park_state = p.w_state + (size_t)utt * 2 * N;
-  u32 *park_an = p.w_state + (size_t)p.g.n_utt * 2 * N + (size_t)utt * 2 * N;
-  double *park_cost = p.w_cost + (size_t)utt * 2 * N;
+  const int NP = kListsInLds ? p.npark : N;
+  u32 *park_state = p.w_state + (size_t)utt * 2 * NP;
+  u32 *park_an = p.w_state + (size_t)p.g.n_utt * 2 * NP + (size_t)utt * 2 * NP;
+  double *park_cost = p.w_cost + (size_t)utt * 2 * NP;
   if (!resume) {
     // InitDecoding: one token at the start state with cost 0 (graphs are epsilon-free: ProcessNonemitting is a no-op)
     if (lane == 0) {
@@ -240,6 +249,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     const VitState vs = p.w_vstate[utt];
     if (vs.done) return;                           // finished (or failed) in an earlier window: outputs are final
     n = vs.n; H = vs.H; bp_used = vs.bp_used; t = p.t_begin;
+    if (p.redo_mode == 1 && n > N) {               // more live tokens than this tier holds: the large tier takes the window
+      if (lane == 0) p.w_redo[utt] = 1u;
+      return;
+    }
     if (n < 0 || n > N) { n = 0; status = ST_INTERNAL; }
     if (kListsInLds) {
       cur = 0;
@@ -671,6 +684,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   if (lane == 0 && p.pass == 0 && p.stamps) for (int k = 0; k < 12; k++) p.stamps[(size_t)utt * 12 + k] = stamp_acc[k];
 #endif
   __threadfence_block();  // back-pointer records (HBM) are read back by the traceback below
+  if (p.redo_mode == 1 && status == ST_TOKEN_OVERFLOW) {
+    // small tier out of slots: nothing parked has been touched (lists and decoder state are written at a window's END
+    // only; the back-pointer records of this window are simply written again) — the large tier redoes the window
+    if (lane == 0) p.w_redo[utt] = 1u;
+    return;
+  }
+  if (p.redo_mode == 2 && lane == 0) p.w_redo[utt] = 0u;
   u32 *c_state = l_state0 + cur * N;
   double *c_cost = l_cost0 + cur * N;
   if (p.windowed && status == ST_OK && t < T && n > 0) {
@@ -834,7 +854,7 @@ size_t lds_bytes(int S, int N, int C, bool lists_in_lds) {
 constexpr size_t kLdsLimit = 160 * 1024;
 
 struct WsLayout {
-  size_t arcnext, state, cost, sta, stb, stkey, bp, tokoff, hash, list, count, vstate, band, total;
+  size_t arcnext, state, cost, sta, stb, stkey, bp, tokoff, hash, list, count, vstate, band, redo, total;
 };
 WsLayout ws_layout(int n_utt, int64_t total_frames, int N, int C, int bpf, int64_t total_arcs) {
   WsLayout w; size_t o = 0;
@@ -852,6 +872,7 @@ WsLayout ws_layout(int n_utt, int64_t total_frames, int N, int C, int bpf, int64
   w.count = take(256);
   w.vstate = take((size_t)n_utt * sizeof(VitState));
   w.band = take((size_t)n_utt * 2 * 4);
+  w.redo = take((size_t)n_utt * 4);
   w.total = o;
   return w;
 }
@@ -924,14 +945,24 @@ int align_impl(mfa_ctx *c, const mfa_graph_batch *g, const float *d_loglikes, co
   // With the normal beam a frame rarely holds more than a few dozen tokens, so every utterance is first decoded with
   // small tables (kSmallTokens); the few that overflow them are marked ST_GROW and decoded again, from scratch and with
   // the same beam, at the caller's full capacity.  Then the retry-beam pass for utterances that did not reach a final state.
-  struct Launch { int pass, N, C, code, grow; };
+  struct Launch { int pass, N, C, code, grow; int N2 = 0, C2 = 0; };   // N2 > 0: a large tier redoes single windows
   std::vector<Launch> plan;
   // First-tier capacity.  With the hashed state→slot table nothing in the decoder's LDS scales with the graph: 64 tokens
   // need 9.5 KB → 16 wavefronts per CU (a whole batch of 4 096 resident at once on 256 CUs), 128 tokens 14.6 KB → 10.
   // MFA_VIT_TIER overrides (diagnostics).
   int kSmallTokens = lazy ? 64 : 128;
   { const char *e = getenv("MFA_VIT_TIER"); if (e && atoi(e) >= 64) kSmallTokens = (atoi(e) + 63) & ~63; }
-  if (N[0] > kSmallTokens) {
+  if (lazy && N[0] > kSmallTokens) {
+    // windowed first-beam pass: the small tier decodes every window; the few utterances it cannot hold in a window are
+    // decoded again — that window only, from the state parked at its start — by the large tier (LDS-resident lists,
+    // so at most 1 024 tokens; beyond that a from-scratch pass with HBM-resident lists follows, as in the dense path)
+    const int nb = std::min(N[0], 1024);
+    const int cb = std::min(C[0], 4 * nb);
+    Launch a{0, kSmallTokens, std::min(C[0], 4 * kSmallTokens), 0, nb < N[0] ? 1 : 0};
+    a.N2 = nb; a.C2 = cb;
+    plan.push_back(a);
+    if (nb < N[0]) plan.push_back({0, N[0], C[0], ST_GROW, 0});
+  } else if (N[0] > kSmallTokens) {
     int cs = std::min(C[0], 4 * kSmallTokens);
     plan.push_back({0, kSmallTokens, cs, 0, 1});
     plan.push_back({0, N[0], C[0], ST_GROW, 0});
@@ -977,7 +1008,26 @@ int align_impl(mfa_ctx *c, const mfa_graph_batch *g, const float *d_loglikes, co
     }
     p.windowed = 0; p.t_begin = 0; p.t_end = 0x7fffffff; p.next_window = 0;
     p.w_vstate = (VitState *)(base + w.vstate); p.state_depth = nullptr; p.band = nullptr;
-    if (lists_in_lds) MFA_HIP_CHECK(c, hipFuncSetAttribute((const void *)viterbi_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    p.redo_mode = 0; p.w_redo = (u32 *)(base + w.redo); p.npark = L.N2 > 0 ? L.N2 : L.N;
+    // large tier of this pass (same workspace strides as a launch of its own would have)
+    size_t lds2 = 0;
+    VitParams p2 = p;
+    if (L.N2 > 0) {
+      lds2 = lds_bytes(max_states, L.N2, L.C2, true);
+      if (lds2 > kLdsLimit) return c->fail("Viterbi large tier needs %zu bytes of LDS", lds2);
+      WsLayout w2 = ws_layout(n_utt, total_frames, L.N2, L.C2, bpf, total_arcs);
+      p2.nmax = L.N2; p2.cmax = L.C2; p2.hbits = hash_bits(L.N2);
+      // park arrays (state / cost) and the back-pointer trail are SHARED between the tiers: the layout of the large one
+      p2.w_state = (u32 *)(base + w2.state); p2.w_cost = (double *)(base + w2.cost);
+      p2.w_stash_a = (u32 *)(base + w2.sta); p2.w_stash_b = (u32 *)(base + w2.stb); p2.w_stash_key = (u64 *)(base + w2.stkey);
+      p2.w_bp = (u64 *)(base + w2.bp); p2.w_tokoff = (u32 *)(base + w2.tokoff);
+      p.w_state = p2.w_state; p.w_cost = p2.w_cost; p.w_bp = p2.w_bp; p.w_tokoff = p2.w_tokoff;
+      // the small tier's per-frame scratch lives inside the large tier's arrays too (its strides are smaller): a layout
+      // of its own would put its candidate stash on top of the other tier's parked lists
+      p.w_stash_a = p2.w_stash_a; p.w_stash_b = p2.w_stash_b; p.w_stash_key = p2.w_stash_key;
+      MFA_HIP_CHECK(c, hipMemsetAsync(base + w.redo, 0, (size_t)n_utt * 4, c->stream));
+    }
+    if (lists_in_lds) MFA_HIP_CHECK(c, hipFuncSetAttribute((const void *)viterbi_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(lds, lds2)));
     else MFA_HIP_CHECK(c, hipFuncSetAttribute((const void *)viterbi_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     auto launch_decoder = [&]() {
       KernelTimer kt(c, MFA_K_VITERBI);
@@ -1001,7 +1051,19 @@ int align_impl(mfa_ctx *c, const mfa_graph_batch *g, const float *d_loglikes, co
         if (mfa_gmm_score_window(c, lazy, &ws, d_frame_off, n_utt, d_ll_off, (float *)d_loglikes) != 0) return -1;
         MFA_DEBUG_POINT(c, "scored window t0=%d K=%d pass=%d code=%d N=%d C=%d", t0, K, ps, L.code, L.N, L.C);
         p.t_begin = t0; p.t_end = t0 + K;
-        launch_decoder();
+        if (L.N2 > 0 && lists_in_lds) {
+          p.redo_mode = 1;
+          launch_decoder();
+          p2.windowed = 1; p2.next_window = K; p2.state_depth = p.state_depth; p2.band = p.band;
+          p2.t_begin = t0; p2.t_end = t0 + K; p2.redo_mode = 2; p2.npark = p.npark; p2.grow = L.grow;
+          p2.utt_list = p.utt_list; p2.n_list = p.n_list;
+          {
+            KernelTimer kt2(c, MFA_K_VITERBI);
+            hipLaunchKernelGGL(viterbi_kernel<true>, dim3(n_utt), dim3(64), lds2, c->stream, p2);
+          }
+        } else {
+          launch_decoder();
+        }
         MFA_DEBUG_POINT(c, "decoded window t0=%d K=%d pass=%d code=%d N=%d C=%d lds=%zu in_lds=%d", t0, K, ps, L.code, L.N, L.C, lds, (int)lists_in_lds);
       }
     }
