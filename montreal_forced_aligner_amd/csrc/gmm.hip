@@ -1461,19 +1461,6 @@ __global__ __launch_bounds__(256, 2) void gmm_band_kernel(GmmParams p) {
   float *out = p.out + p.ll_off[utt];
   const int last = hi - 1;
   auto block_at = [&](int jj) { return __builtin_amdgcn_readfirstlane(p.row0[list[min(jj, last)]]) >> 5; };
-  op8 a[kSteps][kPieces];
-  f32x4 g[4];
-  {
-    const int blk = block_at(lo);
-    const uint4 *src = wsrc + (size_t)blk * kUnits;
-#pragma unroll
-    for (int q = 0; q < 4; q++) g[q] = *reinterpret_cast<const f32x4 *>(gsrc + (size_t)blk * 32 + 8 * q);
-#pragma unroll
-    for (int s_ = 0; s_ < kSteps; s_++)
-#pragma unroll
-      for (int q = 0; q < kPieces; q++) a[s_][q] = __builtin_bit_cast(op8, src[(s_ * kPieces + q) * 64]);
-  }
-  int blk_next = block_at(lo + 1);
   constexpr int kProd = kHalf ? 3 : 6;
   constexpr int pa[6] = {kHalf ? 1 : 2, kHalf ? 0 : 1, 0, 1, 0, 0}, pb[6] = {0, 1, kHalf ? 0 : 2, 0, 1, 0};
   auto flush = [&](int jdone) {                        // columns [jdone − (jdone − lo)%32, jdone] of the staged scores → HBM
@@ -1490,13 +1477,13 @@ __global__ __launch_bounds__(256, 2) void gmm_band_kernel(GmmParams p) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   };
-  for (int j = lo; j < hi; j++) {
-    const int x_next2 = p.row0[list[min(j + 2, last)]];        // lookup two blocks ahead (oldest entry of the vmcnt queue)
+  // One block: acc = gconst + W(block rows held in `ab`) · x̃; as soon as the MFMAs that read a step's operand registers
+  // have been issued, the same registers are re-loaded from `src_next` (rows of a later block), and the gconst registers
+  // from `g_next` after the first step.  Then the log-sum-exp and one staged score column.
+  auto do_block = [&](op8 (&ab)[kSteps][kPieces], f32x4 (&gb)[4], const uint4 *src_next, const float *g_next, int j) {
     f32x16 init, acc[2];
 #pragma unroll
-    for (int rr = 0; rr < 16; rr++) init[rr] = g[rr >> 2][rr & 3];
-    const uint4 *src = wsrc + (size_t)blk_next * kUnits;
-    const float *gn = gsrc + (size_t)blk_next * 32;
+    for (int rr = 0; rr < 16; rr++) init[rr] = gb[rr >> 2][rr & 3];
 #pragma unroll
     for (int s_ = 0; s_ < kSteps; s_++) {
 #pragma unroll
@@ -1504,19 +1491,17 @@ __global__ __launch_bounds__(256, 2) void gmm_band_kernel(GmmParams p) {
 #pragma unroll
         for (int n = 0; n < 2; n++) {
           const f32x16 &cin = (s_ == 0 && t6 == 0) ? init : acc[n];
-          if constexpr (kHalf) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s_][pa[t6]], b[n][s_][pb[t6]], cin, 0, 0, 0);
-          else acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s_][pa[t6]], b[n][s_][pb[t6]], cin, 0, 0, 0);
+          if constexpr (kHalf) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ab[s_][pa[t6]], b[n][s_][pb[t6]], cin, 0, 0, 0);
+          else acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab[s_][pa[t6]], b[n][s_][pb[t6]], cin, 0, 0, 0);
         }
-      // this step's operand registers (and, after the first step, the gconst registers) are free: next block's rows
       if (s_ == 0) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) g[q] = *reinterpret_cast<const f32x4 *>(gn + 8 * q);
+        for (int q = 0; q < 4; q++) gb[q] = *reinterpret_cast<const f32x4 *>(g_next + 8 * q);
       }
 #pragma unroll
-      for (int q = 0; q < kPieces; q++) a[s_][q] = __builtin_bit_cast(op8, src[(s_ * kPieces + q) * 64]);
+      for (int q = 0; q < kPieces; q++) ab[s_][q] = __builtin_bit_cast(op8, src_next[(s_ * kPieces + q) * 64]);
       __builtin_amdgcn_sched_barrier(0);
     }
-    blk_next = __builtin_amdgcn_readfirstlane(x_next2) >> 5;
     float mx[2], sum[2];
 #pragma unroll
     for (int n = 0; n < 2; n++) {
@@ -1529,6 +1514,43 @@ __global__ __launch_bounds__(256, 2) void gmm_band_kernel(GmmParams p) {
     const int jj = (j - lo) & 31;
     stage[(32 * h + col) * 33 + jj] = finish((h ? mx[1] : mx[0]) * inv_s, h ? sum[1] : sum[0]);
     if (jj == 31 || j == last) flush(j);
+  };
+  auto load_block = [&](op8 (&ab)[kSteps][kPieces], f32x4 (&gb)[4], int blk) {
+    const uint4 *src = wsrc + (size_t)blk * kUnits;
+#pragma unroll
+    for (int q = 0; q < 4; q++) gb[q] = *reinterpret_cast<const f32x4 *>(gsrc + (size_t)blk * 32 + 8 * q);
+#pragma unroll
+    for (int s_ = 0; s_ < kSteps; s_++)
+#pragma unroll
+      for (int q = 0; q < kPieces; q++) ab[s_][q] = __builtin_bit_cast(op8, src[(s_ * kPieces + q) * 64]);
+  };
+  if constexpr (kHalf && kSteps <= 5) {   // (D > 40: a second operand set no longer fits in 256 VGPRs)
+    // Two operand sets, blocks alternate between them: while block j is multiplied out of one set, block j+1 already
+    // sits in the other and the rows of block j+2 travel into the registers block j is done with — two blocks (20 KiB)
+    // in flight per wavefront.  The kernel is bound by the latency of these loads (a block takes one trip to the
+    // Infinity Cache, ≈3 µs under load, against 0.4 µs of matrix work), so what counts is the bytes in flight.
+    op8 a0[kSteps][kPieces], a1[kSteps][kPieces];
+    f32x4 g0[4], g1[4];
+    load_block(a0, g0, block_at(lo));
+    load_block(a1, g1, block_at(lo + 1));
+    int blk2 = block_at(lo + 2), blk3 = block_at(lo + 3);
+    for (int j = lo; j < hi; j += 2) {
+      const int x4 = p.row0[list[min(j + 4, last)]], x5 = p.row0[list[min(j + 5, last)]];   // lookups two trips ahead
+      do_block(a0, g0, wsrc + (size_t)blk2 * kUnits, gsrc + (size_t)blk2 * 32, j);
+      if (j + 1 < hi) do_block(a1, g1, wsrc + (size_t)blk3 * kUnits, gsrc + (size_t)blk3 * 32, j + 1);
+      blk2 = __builtin_amdgcn_readfirstlane(x4) >> 5;
+      blk3 = __builtin_amdgcn_readfirstlane(x5) >> 5;
+    }
+  } else {
+    op8 a0[kSteps][kPieces];
+    f32x4 g0[4];
+    load_block(a0, g0, block_at(lo));
+    int blk_next = block_at(lo + 1);
+    for (int j = lo; j < hi; j++) {
+      const int x_next2 = p.row0[list[min(j + 2, last)]];      // lookup two blocks ahead (oldest entry of the vmcnt queue)
+      do_block(a0, g0, wsrc + (size_t)blk_next * kUnits, gsrc + (size_t)blk_next * 32, j);
+      blk_next = __builtin_amdgcn_readfirstlane(x_next2) >> 5;
+    }
   }
 }
 
