@@ -79,7 +79,7 @@ struct GmmParams {
   const int32_t *b_utt_list; const int32_t *b_n_list;
   const int32_t *b_done; int b_done_stride, b_done_word;
   const int32_t *last_depth;   // parallel to pdf_list: running max (inside a class) of the longest-path depth of the pdf's sources
-  int b_skip0;                 // f32 band kernel: the single-block 32-row class was scored by gmm_band_kernel
+  int b_skip0;                 // f32 band kernel: classes 0, 2, 3, 4 were scored by gmm_band_kernel (it keeps 1 and 5)
   int b_chunk, b_nchunk;       // gmm_band_kernel: columns per wavefront (0 = the whole band) and chunks per sub-tile
 };
 
@@ -298,7 +298,10 @@ __device__ __forceinline__ void score_tile(const GmmParams &p, int utt, int t_ba
   // left for this launch
   if (p.skip_single >= 2) { need[2] = 0; need[3] = 0; need[4] = 0; }   // slots 16 / 8 / 4 went to gmm_split_small_kernel
   if (p.skip_single && need[2] + need[3] + need[4] + need[5] == 0) return;
-  if (p.b_skip0 && (need[1] - lo_[1]) + (need[2] - lo_[2]) + (need[3] - lo_[3]) + (need[4] - lo_[4]) + (need[5] - lo_[5]) == 0) return;
+  if (p.b_skip0) {   // band mode after gmm_band_kernel: pdfs of more than 32 Gaussians and single Gaussians are left
+    need[2] = 0; need[3] = 0; need[4] = 0; lo_[2] = 0; lo_[3] = 0; lo_[4] = 0;
+    if ((need[1] - lo_[1]) + (need[5] - lo_[5]) == 0) return;
+  }
 
   Tile<M8, kNT> tile;
   tile.load_b(p, f0, T, t_base, lane);
@@ -1437,16 +1440,38 @@ __global__ __launch_bounds__(256, 2) void gmm_band_kernel(GmmParams p) {
   const int64_t l0 = p.pdf_off[utt];
   const int P = (int)(p.pdf_off[utt + 1] - l0);
   const int32_t *list = p.pdf_list + l0;
-  const int n_all = p.class_counts[(size_t)utt * 6];
+  const int32_t *cc6 = p.class_counts + (size_t)utt * 6;
   const Band bd = band_of(p, utt);
-  int hi = 0, lo = 0;
-  for (int i0 = 0; i0 < n_all; i0 += 64) {
-    const int i = i0 + lane;
-    hi += __popcll(__ballot(i < n_all && p.first_frame[l0 + i] <= bd.hi));
-    lo += __popcll(__ballot(i < n_all && p.last_depth[l0 + i] < bd.lo));
+  // band range [lo, hi) of every class this kernel scores: 0 (one 32-row block per pdf) and 2, 3, 4 (16-, 8-, 4-row slots);
+  // classes 1 (pdfs of more than 32 Gaussians) and 5 (single Gaussians) are the f32 band kernel's
+  int lo_c[5], hi_c[5], base_c[5];
+  {
+    int off = 0;
+#pragma unroll
+    for (int cls = 0; cls < 5; cls++) {
+      const int cnt = cc6[cls];
+      int nh = 0, nl = 0;
+      if (cls != 1) {
+        for (int i0 = 0; i0 < cnt; i0 += 64) {
+          const int i = i0 + lane;
+          nh += __popcll(__ballot(i < cnt && p.first_frame[l0 + off + i] <= bd.hi));
+          nl += __popcll(__ballot(i < cnt && p.last_depth[l0 + off + i] < bd.lo));
+        }
+      }
+      lo_c[cls] = min(nl, nh); hi_c[cls] = nh; base_c[cls] = off;
+      off += cnt;
+    }
   }
-  if (p.b_chunk > 0) { lo += chunk * p.b_chunk; hi = min(hi, lo + p.b_chunk); }   // this wavefront's share of the band
-  if (lo >= hi) { if (kHalf && lane == 0) *redo_flag = 0; return; }
+  if (p.b_chunk > 0) {                                 // list passes: this wavefront's share of the band (class 0 in chunks,
+    lo_c[0] += chunk * p.b_chunk;                      // the small-slot classes with chunk 0)
+    hi_c[0] = min(hi_c[0], lo_c[0] + p.b_chunk);
+    if (chunk != 0) { hi_c[2] = lo_c[2]; hi_c[3] = lo_c[3]; hi_c[4] = lo_c[4]; }
+  }
+  const int lo = lo_c[0], hi = hi_c[0];
+  if (lo >= hi && lo_c[2] >= hi_c[2] && lo_c[3] >= hi_c[3] && lo_c[4] >= hi_c[4]) {
+    if (kHalf && lane == 0) *redo_flag = 0;
+    return;
+  }
   op8 b[2][kSteps][kPieces];
   const bool bad = split_features<kSteps, kPieces>(p, f0, T, t_base, col, h, b);
   if constexpr (kHalf) {
@@ -1454,104 +1479,203 @@ __global__ __launch_bounds__(256, 2) void gmm_band_kernel(GmmParams p) {
     if (lane == 0) *redo_flag = any_bad ? 1 : 0;
     if (any_bad) return;                                               // a scaled feature left the f16 range: bf16×3 pass
   }
-  const uint4 *wsrc = (kHalf ? p.wh : p.wb) + lane;
-  const float *gsrc = (kHalf ? p.gch : p.gc) + 4 * h;
   const float inv_s = kHalf ? p.acc_scale_inv : 1.0f;
   const float l2e_s = 1.44269504088896341f * inv_s;
   float *out = p.out + p.ll_off[utt];
-  const int last = hi - 1;
-  auto block_at = [&](int jj) { return __builtin_amdgcn_readfirstlane(p.row0[list[min(jj, last)]]) >> 5; };
   constexpr int kProd = kHalf ? 3 : 6;
   constexpr int pa[6] = {kHalf ? 1 : 2, kHalf ? 0 : 1, 0, 1, 0, 0}, pb[6] = {0, 1, kHalf ? 0 : 2, 0, 1, 0};
-  auto flush = [&](int jdone) {                        // columns [jdone − (jdone − lo)%32, jdone] of the staged scores → HBM
-    const int jj = (jdone - lo) & 31;
+  // `cnt` staged columns, the first of them score column c0 of the utterance's matrix → HBM as 128-byte row segments
+  auto flush_cols = [&](int c0, int cnt) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int j0 = jdone - jj, cnt = jj + 1;
 #pragma unroll 4
     for (int i = 0; i < 32; i++) {
       const int rr = h + 2 * i, t = t_base + rr;
-      if (col < cnt && t < T) __builtin_nontemporal_store(stage[rr * 33 + col], &out[(size_t)t * P + j0 + col]);
+      if (col < cnt && t < T) __builtin_nontemporal_store(stage[rr * 33 + col], &out[(size_t)t * P + c0 + col]);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   };
-  // One block: acc = gconst + W(block rows held in `ab`) · x̃; as soon as the MFMAs that read a step's operand registers
-  // have been issued, the same registers are re-loaded from `src_next` (rows of a later block), and the gconst registers
-  // from `g_next` after the first step.  Then the log-sum-exp and one staged score column.
-  auto do_block = [&](op8 (&ab)[kSteps][kPieces], f32x4 (&gb)[4], const uint4 *src_next, const float *g_next, int j) {
-    f32x16 init, acc[2];
+
+  // ---------------------------------------------------------------- class 0: one pdf per 32-row block
+  if (lo < hi) {
+    const uint4 *wsrc = (kHalf ? p.wh : p.wb) + lane;
+    const float *gsrc = (kHalf ? p.gch : p.gc) + 4 * h;
+    const int last = hi - 1;
+    auto block_at = [&](int jj) { return __builtin_amdgcn_readfirstlane(p.row0[list[min(jj, last)]]) >> 5; };
+    op8 a[kSteps][kPieces];
+    f32x4 g[4];
+    {
+      const int blk = block_at(lo);
+      const uint4 *src = wsrc + (size_t)blk * kUnits;
 #pragma unroll
-    for (int rr = 0; rr < 16; rr++) init[rr] = gb[rr >> 2][rr & 3];
+      for (int q = 0; q < 4; q++) g[q] = *reinterpret_cast<const f32x4 *>(gsrc + (size_t)blk * 32 + 8 * q);
 #pragma unroll
-    for (int s_ = 0; s_ < kSteps; s_++) {
+      for (int s_ = 0; s_ < kSteps; s_++)
 #pragma unroll
-      for (int t6 = 0; t6 < kProd; t6++)
-#pragma unroll
-        for (int n = 0; n < 2; n++) {
-          const f32x16 &cin = (s_ == 0 && t6 == 0) ? init : acc[n];
-          if constexpr (kHalf) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ab[s_][pa[t6]], b[n][s_][pb[t6]], cin, 0, 0, 0);
-          else acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab[s_][pa[t6]], b[n][s_][pb[t6]], cin, 0, 0, 0);
-        }
-      if (s_ == 0) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) gb[q] = *reinterpret_cast<const f32x4 *>(g_next + 8 * q);
-      }
-#pragma unroll
-      for (int q = 0; q < kPieces; q++) ab[s_][q] = __builtin_bit_cast(op8, src_next[(s_ * kPieces + q) * 64]);
-      __builtin_amdgcn_sched_barrier(0);
+        for (int q = 0; q < kPieces; q++) a[s_][q] = __builtin_bit_cast(op8, src[(s_ * kPieces + q) * 64]);
     }
-    float mx[2], sum[2];
-#pragma unroll
-    for (int n = 0; n < 2; n++) {
-      float m = reg_max<0, 16>(acc[n]);
-      m = fmaxf(m, swap32(m, h));
-      float sv = reg_expsum_fast(acc[n], m, l2e_s);
-      sv += swap32(sv, h);
-      mx[n] = m; sum[n] = sv;
-    }
-    const int jj = (j - lo) & 31;
-    stage[(32 * h + col) * 33 + jj] = finish((h ? mx[1] : mx[0]) * inv_s, h ? sum[1] : sum[0]);
-    if (jj == 31 || j == last) flush(j);
-  };
-  auto load_block = [&](op8 (&ab)[kSteps][kPieces], f32x4 (&gb)[4], int blk) {
-    const uint4 *src = wsrc + (size_t)blk * kUnits;
-#pragma unroll
-    for (int q = 0; q < 4; q++) gb[q] = *reinterpret_cast<const f32x4 *>(gsrc + (size_t)blk * 32 + 8 * q);
-#pragma unroll
-    for (int s_ = 0; s_ < kSteps; s_++)
-#pragma unroll
-      for (int q = 0; q < kPieces; q++) ab[s_][q] = __builtin_bit_cast(op8, src[(s_ * kPieces + q) * 64]);
-  };
-  if constexpr (kHalf && kSteps <= 5) {   // (D > 40: a second operand set no longer fits in 256 VGPRs)
-    // Two operand sets, blocks alternate between them: while block j is multiplied out of one set, block j+1 already
-    // sits in the other and the rows of block j+2 travel into the registers block j is done with — two blocks (20 KiB)
-    // in flight per wavefront.  The kernel is bound by the latency of these loads (a block takes one trip to the
-    // Infinity Cache, ≈3 µs under load, against 0.4 µs of matrix work), so what counts is the bytes in flight.
-    op8 a0[kSteps][kPieces], a1[kSteps][kPieces];
-    f32x4 g0[4], g1[4];
-    load_block(a0, g0, block_at(lo));
-    load_block(a1, g1, block_at(lo + 1));
-    int blk2 = block_at(lo + 2), blk3 = block_at(lo + 3);
-    for (int j = lo; j < hi; j += 2) {
-      const int x4 = p.row0[list[min(j + 4, last)]], x5 = p.row0[list[min(j + 5, last)]];   // lookups two trips ahead
-      do_block(a0, g0, wsrc + (size_t)blk2 * kUnits, gsrc + (size_t)blk2 * 32, j);
-      if (j + 1 < hi) do_block(a1, g1, wsrc + (size_t)blk3 * kUnits, gsrc + (size_t)blk3 * 32, j + 1);
-      blk2 = __builtin_amdgcn_readfirstlane(x4) >> 5;
-      blk3 = __builtin_amdgcn_readfirstlane(x5) >> 5;
-    }
-  } else {
-    op8 a0[kSteps][kPieces];
-    f32x4 g0[4];
-    load_block(a0, g0, block_at(lo));
     int blk_next = block_at(lo + 1);
     for (int j = lo; j < hi; j++) {
       const int x_next2 = p.row0[list[min(j + 2, last)]];      // lookup two blocks ahead (oldest entry of the vmcnt queue)
-      do_block(a0, g0, wsrc + (size_t)blk_next * kUnits, gsrc + (size_t)blk_next * 32, j);
+      f32x16 init, acc[2];
+#pragma unroll
+      for (int rr = 0; rr < 16; rr++) init[rr] = g[rr >> 2][rr & 3];
+      const uint4 *src = wsrc + (size_t)blk_next * kUnits;
+      const float *gn = gsrc + (size_t)blk_next * 32;
+#pragma unroll
+      for (int s_ = 0; s_ < kSteps; s_++) {
+#pragma unroll
+        for (int t6 = 0; t6 < kProd; t6++)
+#pragma unroll
+          for (int n = 0; n < 2; n++) {
+            const f32x16 &cin = (s_ == 0 && t6 == 0) ? init : acc[n];
+            if constexpr (kHalf) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s_][pa[t6]], b[n][s_][pb[t6]], cin, 0, 0, 0);
+            else acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s_][pa[t6]], b[n][s_][pb[t6]], cin, 0, 0, 0);
+          }
+        // this step's operand registers (and, after the first step, the gconst registers) are free: next block's rows.
+        // (A second operand set — two blocks in flight per wavefront — was measured: 12.70 vs 12.76 ms per step; the
+        //  kernel is bound by what the fabric delivers, ≈6.5 TB/s of 10 KiB blocks gathered from a 51 MB table.)
+        if (s_ == 0) {
+#pragma unroll
+          for (int q = 0; q < 4; q++) g[q] = *reinterpret_cast<const f32x4 *>(gn + 8 * q);
+        }
+#pragma unroll
+        for (int q = 0; q < kPieces; q++) a[s_][q] = __builtin_bit_cast(op8, src[(s_ * kPieces + q) * 64]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       blk_next = __builtin_amdgcn_readfirstlane(x_next2) >> 5;
+      float mx[2], sum[2];
+#pragma unroll
+      for (int n = 0; n < 2; n++) {
+        float m = reg_max<0, 16>(acc[n]);
+        m = fmaxf(m, swap32(m, h));
+        float sv = reg_expsum_fast(acc[n], m, l2e_s);
+        sv += swap32(sv, h);
+        mx[n] = m; sum[n] = sv;
+      }
+      const int jj = (j - lo) & 31;
+      stage[(32 * h + col) * 33 + jj] = finish((h ? mx[1] : mx[0]) * inv_s, h ? sum[1] : sum[0]);
+      if (jj == 31 || j == last) flush_cols(j - jj, jj + 1);
     }
   }
+
+  // ---------------------------------------------------------------- classes 2, 3, 4: 32 / slot pdfs per virtual block
+  // As gmm_split_small_kernel: the pdfs the list puts next to each other are gathered into one 32-row block (lane ↔ row
+  // ρ = lane mod 32 → pdf ρ / slot, its row ρ mod slot; rows past the range come from the model's dummy row), the MFMAs
+  // are those of class 0, the log-sum-exp runs over the slot's rows of each pdf — per pdf the very same expressions, so a
+  // cell scored here carries the dense kernel's bits.  The gather costs nothing extra: every lane loads through its own
+  // row pointer anyway.
+  auto run_small = [&](auto slot_c, int base, int lo_s, int hi_s) {
+    constexpr int kSlot = decltype(slot_c)::value, kPdfs = 32 / kSlot;
+    if (lo_s >= hi_s) return;
+    const uint4 *wsrc = kHalf ? p.wh : p.wb;
+    const float *gsrc = kHalf ? p.gch : p.gc;
+    const int rho = lane & 31, my_k = rho / kSlot, my_r = rho % kSlot;
+    const int jb0 = lo_s / kPdfs, jb1 = (hi_s + kPdfs - 1) / kPdfs;
+    auto row_of = [&](int jb) -> int {                 // this lane's packed row in virtual block jb (two dependent loads)
+      const int idx = min(jb, jb1 - 1) * kPdfs + my_k;
+      return idx < hi_s ? p.row0[list[base + idx]] + my_r : p.num_rows;
+    };
+    auto src_of = [&](int row) { return wsrc + (size_t)(row >> 5) * kUnits + (row & 31) + 32 * h; };
+    op8 a[kSteps][kPieces];
+    int row_cur = row_of(jb0), row_next = row_of(jb0 + 1);
+    float gcv = gsrc[row_cur];
+    {
+      const uint4 *src = src_of(row_cur);
+#pragma unroll
+      for (int s_ = 0; s_ < kSteps; s_++)
+#pragma unroll
+        for (int q = 0; q < kPieces; q++) a[s_][q] = __builtin_bit_cast(op8, src[(s_ * kPieces + q) * 64]);
+    }
+    const int col0 = base + jb0 * kPdfs;               // score column of the first staged column
+    for (int jb = jb0; jb < jb1; jb++) {
+      const int row_n2 = row_of(jb + 2);               // in flight during this block
+      f32x16 init, acc[2];
+#pragma unroll
+      for (int rr = 0; rr < 16; rr++) init[rr] = __shfl(gcv, acc_row(rr, h));
+      const uint4 *src = src_of(row_next);
+#pragma unroll
+      for (int s_ = 0; s_ < kSteps; s_++) {
+#pragma unroll
+        for (int t6 = 0; t6 < kProd; t6++)
+#pragma unroll
+          for (int n = 0; n < 2; n++) {
+            const f32x16 &cin = (s_ == 0 && t6 == 0) ? init : acc[n];
+            if constexpr (kHalf) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s_][pa[t6]], b[n][s_][pb[t6]], cin, 0, 0, 0);
+            else acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s_][pa[t6]], b[n][s_][pb[t6]], cin, 0, 0, 0);
+          }
+        if (s_ == 0) gcv = gsrc[row_next];
+#pragma unroll
+        for (int q = 0; q < kPieces; q++) a[s_][q] = __builtin_bit_cast(op8, src[(s_ * kPieces + q) * 64]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      row_next = row_n2;
+      // per-pdf log-sum-exp.  Accumulator register r of half-wave h is row (r & 3) + 8 (r >> 2) + 4 h of the block.
+      auto group_max = [&](const f32x16 &v, int r0, int cnt) {
+        float m = v[r0];
+#pragma unroll
+        for (int rr = 1; rr < cnt; rr++) m = fmaxf(m, v[r0 + rr]);
+        return m;
+      };
+      auto group_expsum = [&](const f32x16 &v, int r0, int cnt, float m) {
+        float e[8];
+#pragma unroll
+        for (int rr = 0; rr < cnt; rr++) e[rr] = __builtin_amdgcn_exp2f((v[r0 + rr] - m) * l2e_s);
+#pragma unroll
+        for (int w = 1; w < cnt; w <<= 1)
+#pragma unroll
+          for (int rr = 0; rr + w < cnt; rr += 2 * w) e[rr] += e[rr + w];
+        return e[0];
+      };
+      const int colbase = ((jb - jb0) * kPdfs) & 31;   // first staging column of this block
+#pragma unroll
+      for (int n = 0; n < 2; n++) {
+        float *srow = stage + (32 * n + col) * 33 + colbase;
+        if constexpr (kSlot == 16) {                   // pdf k: rows 16k..16k+15 = registers [8k, 8k+8) of both halves
+          float ll[2];
+#pragma unroll
+          for (int k2 = 0; k2 < 2; k2++) {
+            float m = group_max(acc[n], 8 * k2, 8);
+            m = fmaxf(m, swap32(m, h));
+            float sv = group_expsum(acc[n], 8 * k2, 8, m);
+            sv += swap32(sv, h);
+            ll[k2] = finish(m * inv_s, sv);
+          }
+          srow[h] = h ? ll[1] : ll[0];
+        } else if constexpr (kSlot == 8) {             // pdf k: rows 8k..8k+7 = registers [4k, 4k+4) of both halves
+          float ll[4];
+#pragma unroll
+          for (int k2 = 0; k2 < 4; k2++) {
+            float m = group_max(acc[n], 4 * k2, 4);
+            m = fmaxf(m, swap32(m, h));
+            float sv = group_expsum(acc[n], 4 * k2, 4, m);
+            sv += swap32(sv, h);
+            ll[k2] = finish(m * inv_s, sv);
+          }
+          srow[h] = h ? ll[1] : ll[0];
+          srow[2 + h] = h ? ll[3] : ll[2];
+        } else {                                       // slot 4: pdf 2i + h: rows 8i + 4h .. +3 = registers [4i, 4i+4)
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const float m = group_max(acc[n], 4 * i, 4);
+            const float sv = group_expsum(acc[n], 4 * i, 4, m);
+            srow[2 * i + h] = finish(m * inv_s, sv);
+          }
+        }
+      }
+      const int done = (jb - jb0 + 1) * kPdfs;         // staged columns since col0 (whole blocks)
+      if ((done & 31) == 0 || jb == jb1 - 1) {
+        const int first = (done - 1) & ~31;            // first staged column of the open window
+        const int valid = min(done, hi_s - jb0 * kPdfs) - first;   // columns of pdfs inside the class's range
+        flush_cols(col0 + first, valid);
+      }
+    }
+  };
+  run_small(std::integral_constant<int, 16>{}, base_c[2], lo_c[2], hi_c[2]);
+  run_small(std::integral_constant<int, 8>{}, base_c[3], lo_c[3], hi_c[3]);
+  run_small(std::integral_constant<int, 4>{}, base_c[4], lo_c[4], hi_c[4]);
 }
 
 // Band-mode launch of the f32 kernel's tile walk: whatever slot classes gmm_band_kernel does not cover (single-Gaussian
@@ -2142,7 +2266,8 @@ int mfa_gmm_score_window(mfa_ctx *c, const MfaLazyScoring *lazy, const MfaWindow
   const char *bf = getenv("MFA_GMM_BF16");
   const char *hf = getenv("MFA_GMM_F16");
   KernelTimer kt(c, MFA_K_GMM);
-  if (!(bf && bf[0] == '0') && c->d_wb && c->has_single32) {
+  const bool split_classes = c->has_single32 || c->has_slot_class[1] || c->has_slot_class[2] || c->has_slot_class[3];
+  if (!(bf && bf[0] == '0') && c->d_wb && split_classes) {
     const bool f16_ok = !(hf && hf[0] == '0') && c->d_wh;
     if (c->gmm_redo_cap < split_waves) {
       if (c->d_gmm_redo) { MFA_HIP_CHECK(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->d_gmm_redo); }
@@ -2165,8 +2290,8 @@ int mfa_gmm_score_window(mfa_ctx *c, const MfaLazyScoring *lazy, const MfaWindow
     p.redo_mode = 0;
     p.b_skip0 = 1;
   }
-  const bool only_single32 = c->all_single_block && !c->has_multi_block;
-  if (!(p.b_skip0 && only_single32)) {
+  const bool f32_classes = c->has_multi_block || c->has_slot_class[4];   // pdfs of more than 32 Gaussians, single Gaussians
+  if (!p.b_skip0 || f32_classes) {
     if (m8 <= 10) hipLaunchKernelGGL((gmm_band_f32_kernel<10>), grid, dim3(256), 0, c->stream, p);
     else hipLaunchKernelGGL((gmm_band_f32_kernel<12>), grid, dim3(256), 0, c->stream, p);
   }
