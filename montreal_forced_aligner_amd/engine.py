@@ -533,6 +533,18 @@ class Pipeline:
             "states": S,
         }
 
+    def _executed_share(self) -> float:
+        """Cells the scoring kernels actually computed ÷ cells the algorithmic flop count prices (the reachability-bounded
+        matrix): < 1 on the lazy path, which scores only what live decoder tokens can ask for."""
+        frac = getattr(self, "cells_scored_fraction", None)
+        if frac is None or not self.lazy:
+            return 1.0
+        T = np.diff(self.frame_off).astype(np.float64)
+        total = float((T * np.diff(self.graphs.pdf_off_host)).sum())
+        g_of_pdf = np.diff(self.e.gmm.pdf_offsets).astype(np.float64)
+        priced = self.gmm_flops / (4.0 * self.e.gmm.dim) / max(1.0, float(g_of_pdf.mean()))
+        return min(1.0, frac * total / max(1.0, priced))
+
     def roofline(self, dominant: str, ktimes: Dict[str, Dict[str, float]], steps: int, mono: bool, gauss_per_pdf: int) -> Dict:
         """Roofline object for the dominant stage of the step (bench.py): per-step stage time from the HIP-event timers."""
         import os
@@ -548,7 +560,8 @@ class Pipeline:
                     "kernel_key": "gmm", "bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4), "traffic": None,
                     "algorithmic_flops_per_step": self.gmm_flops, "mfma_flops_per_algorithmic_flop": int(mult),
-                    "executed_mfma_frac_of_peak": round(mult * ach / peak, 4), "ms_per_step": round(ms, 4),
+                    "cells_scored_fraction": getattr(self, "cells_scored_fraction", None),
+                    "executed_mfma_frac_of_peak": round(mult * ach / peak * self._executed_share(), 4), "ms_per_step": round(ms, 4),
                     "launches_per_step": launches,
                     "note": "algorithmic flops = 4*D*g per (frame, pdf) cell of the reachability-bounded matrix (SURVEY 8d)"}
         by = self.algorithmic_bytes()
