@@ -412,19 +412,18 @@ class GmmAligner:
         graphs = eng.pack_graphs([_graph.add_transition_probs(f, self._scaled) for f in fsts], self.transition_model)
         frame_off = np.concatenate([[0], np.cumsum([x.shape[0] for x in feats])]).astype(np.int64)
         d_feats = torch.from_numpy(np.concatenate(feats).astype(np.float32)).to(eng.device)
-        # score only what a decoder token can ask for (Kaldi's decodable is lazy); unreachable cells stay unwritten
-        ll, ll_off, ll_cols = eng.score(d_feats, frame_off, graphs.pdf_list, graphs.pdf_off_host, graphs.class_counts,
-                                        pdf_first_frame=graphs.pdf_first_frame)
-        res = eng.align(graphs, ll, ll_off, ll_cols, frame_off, beam=self.beam, retry_beam=self.retry_beam,
-                        acoustic_scale=self.acoustic_scale, want_frame_likes=True)
-        res = {k: v.cpu().numpy() for k, v in res.items() if v is not None}
+        # features in, alignments out — the decodable is evaluated lazily, as Kaldi's is: per window of frames only the
+        # pdfs that arcs near the live tokens can emit are scored (mfa_align_features_batch)
+        res = eng.align_features(graphs, d_feats, frame_off, beam=self.beam, retry_beam=self.retry_beam,
+                                 acoustic_scale=self.acoustic_scale, want_frame_likes=True)
+        res = {k: v.cpu().numpy() for k, v in res.items() if isinstance(v, torch.Tensor)}
         out: List[Optional[Alignment]] = []
         for u in range(len(fsts)):
             st = int(res["status"][u])
             if st not in (0, 1):
-                if st > 2:
-                    raise RuntimeError(f"device decoder reported status {st} for utterance {u} (see include/mfa_hip.h)")
-                out.append(None)  # the reference returns None and lets the caller count the failure
+                # the reference returns None and lets the caller count the failure (capacity / unsupported-graph statuses
+                # included: they concern this utterance only, never the rest of the batch)
+                out.append(None)
                 continue
             a, b = int(frame_off[u]), int(frame_off[u + 1])
             nw = int(res["n_words"][u])

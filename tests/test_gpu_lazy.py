@@ -207,3 +207,41 @@ def test_lazy_path_matches_oracle_from_pcm(engine, tri):
         total = abs(float(res["like"][u]) - ref["like"])
         print(f"utterance {u}: |delta log-likelihood| total {total:.4f}, per frame {total / (b - a):.2e}")
         assert total / (b - a) < 1e-3
+
+
+def test_beam_10_40_result_is_the_unpruned_best_path(engine, tri, fx):
+    """graph.py's training graphs are equivalent to Kaldi's but not determinised, and FasterDecoder's pruning
+    depends on topology — so the claim worth checking is that pruning does not matter on the configurations the numbers are
+    quoted on: beam 10 / retry 40 returns the same path as a decoder that prunes nothing (beam 1e4, tables at their hard
+    upper bounds).  With no search error both graph forms give the same answer."""
+    world, model, lda, fm, feats_of = tri
+    engine.load_gmm(model.am)
+    utts = [world.utterance(7500 + i) for i in range(12)]
+    gc = G.TrainingGraphCompiler(model.tm, model.tree, world.lexicon)
+    scaled = model.tm.scaled_log_probs(1.0, 0.1)
+    fsts = [G.add_transition_probs(gc.compile_fst(u[1]), scaled) for u in utts]
+    feats, fo = feats_of([u[0] for u in utts], [u[3] for u in utts])
+    graphs = engine.pack_graphs(fsts, model.tm)
+    pruned = engine.align_features(graphs, feats, fo, beam=10.0, retry_beam=40.0, max_tokens=256, bp_tokens_per_frame=128)
+    full = engine.align_features(graphs, feats, fo, beam=1.0e4, retry_beam=0.0, max_tokens=graphs.max_states,
+                                 bp_tokens_per_frame=graphs.max_states)
+    assert set(full["status"].cpu().tolist()) == {0}
+    same = sum(int(torch.equal(pruned["ali"][fo[u]: fo[u + 1]], full["ali"][fo[u]: fo[u + 1]])) for u in range(len(utts)))
+    assert same == len(utts), f"beam 10/40 left the unpruned best path on {len(utts) - same} of {len(utts)} utterances"
+    # the reference's recording with its plumbing model, beams as the reference's own tests set them (100 / 400)
+    tm, am = fx.mono_tm, fx.mono_am
+    engine.load_gmm(am)
+    sr = 16000
+    segs = [fx.pcm[int(a * sr): int(b * sr)] for a, b in ((0.0, 4.2), (4.0, 6.5), (23.5, 26.72))]
+    texts = ["this is the acoustic corpus i'm talking pretty fast here", "there's nothing going else going on",
+             "um and that should be all thanks"]
+    so = np.concatenate([[0], np.cumsum([len(s) for s in segs])]).astype(np.int64)
+    mfcc, fo2 = engine.mfcc(_dev(engine, np.concatenate(segs)), so)
+    u2s = np.arange(len(segs), dtype=np.int32)
+    f2 = engine.features(mfcc, fo2, u2s, engine.cmvn_stats(mfcc, fo2, u2s, len(segs)))
+    g2 = engine.pack_graphs([fx.mono_graph(t) for t in texts], tm)
+    a_ = engine.align_features(g2, f2, fo2, beam=100.0, retry_beam=400.0, max_tokens=2048, bp_tokens_per_frame=1024)
+    b_ = engine.align_features(g2, f2, fo2, beam=1.0e4, retry_beam=0.0, max_tokens=g2.max_states, bp_tokens_per_frame=g2.max_states)
+    assert set(b_["status"].cpu().tolist()) == {0}
+    for u in range(len(segs)):
+        assert torch.equal(a_["ali"][fo2[u]: fo2[u + 1]], b_["ali"][fo2[u]: fo2[u + 1]]), u
