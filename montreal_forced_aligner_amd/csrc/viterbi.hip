@@ -52,7 +52,7 @@ struct VitParams {
   const float *ll; const int64_t *ll_off; const int32_t *ll_cols; const int64_t *frame_off;
   float beam, scale;
   int nmax, cmax, bpf;        // live-token capacity, candidate capacity, back-pointer tokens per frame
-  int hbits;                  // log2 of the state→slot hash table size (>= 4 x nmax entries)
+  int hbits;                  // log2 of the state→slot hash table size (>= 4 x nmax entries); 0: direct map, one entry per state
   const int32_t *utt_list;    // utterances to decode (NULL: identity)
   const int32_t *n_list;      // number of entries in utt_list (device scalar) or NULL
   int pass;                   // 0 first beam, 1 retry
@@ -199,8 +199,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   // at most N of them, whatever the size of the graph, so the table is 4N entries instead of one per graph state
   // (round 1: a direct map, 10.8 KB of the 23 KB a 2 700-state graph needed → 6 wavefronts per CU; now 16).
   u32 *hmap = (u32 *)(s_cost + (kListsInLds ? 3 : 1) * (size_t)N);  // [HM] slot index | kEmpty | kClaim | kOver
-  const u32 HM = 1u << p.hbits, hmask = HM - 1u;
-  const int hshift = 32 - p.hbits;
+  // (large tiers, whose 4N-entry table would be bigger than one entry per graph state, address the table by state id:
+  //  hbits = 0 — same code, no collisions)
+  const bool hdirect = p.hbits == 0;
+  const u32 HM = hdirect ? (u32)((S + 1) & ~1) : 1u << p.hbits, hmask = hdirect ? 0xFFFFFFFFu : HM - 1u;
+  const int hshift = hdirect ? 0 : 32 - p.hbits;
   u32 *s_state = hmap + HM;         // [N]
   u32 *s_F = s_state + N;           // [N] first creating candidate (pos<<6|k)
   u32 *s_W = s_F + N;               // [N] winning candidate
@@ -375,7 +378,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     // Candidate creation in three wavefront phases (each phase's LDS operations are issued back to back):
     //   look up the destination's slot → claim missing slots (CAS; the winner allocates, initialises, publishes)
     //   → re-read the published slot and lower its cost / first-creator with LDS atomics.
-    auto hash_of = [&](u32 d) -> u32 { return (d * 2654435761u) >> hshift; };
+    auto hash_of = [&](u32 d) -> u32 { return hdirect ? d : (d * 2654435761u) >> hshift; };
     // read-only lookup (after every candidate of the frame has been filed): slot of state d, or kEmpty
     auto find = [&](u32 d) -> u32 {
       u32 h = hash_of(d);
@@ -845,10 +848,16 @@ __global__ void arcnext_kernel(mfa_graph_batch g, uint4 *out) {
 
 constexpr int kLlCap = 512;
 // state→slot hash table: a power of two, at least four entries per live-token slot
-int hash_bits(int N) { int b = 8; while ((1 << b) < 4 * N) b++; return b; }
+// — unless one entry per graph state is smaller (the large tiers of the rare passes): then 0 = direct map
+int hash_bits(int S, int N) {
+  int b = 8;
+  while ((1 << b) < 4 * N) b++;
+  return ((size_t)4 << b) <= (size_t)((S + 1) & ~1) * 4 ? b : 0;
+}
 size_t lds_bytes(int S, int N, int C, bool lists_in_lds) {
-  (void)S;   // nothing in the decoder's LDS scales with the graph any more
-  return (size_t)N * 8 + ((size_t)4 << hash_bits(N)) + (size_t)N * 7 * 4 + (size_t)C * 4 + (size_t)kLlCap * 4 + 16 +
+  const int hb = hash_bits(S, N);
+  const size_t table = hb ? ((size_t)4 << hb) : (size_t)((S + 1) & ~1) * 4;
+  return (size_t)N * 8 + table + (size_t)N * 7 * 4 + (size_t)C * 4 + (size_t)kLlCap * 4 + 16 +
          (lists_in_lds ? (size_t)N * 32 : 0);
 }
 constexpr size_t kLdsLimit = 160 * 1024;
@@ -988,7 +997,7 @@ int align_impl(mfa_ctx *c, const mfa_graph_batch *g, const float *d_loglikes, co
     memset(&p, 0, sizeof(p));
     p.g = *g; p.ll = d_loglikes; p.ll_off = d_ll_off; p.ll_cols = d_ll_cols; p.frame_off = d_frame_off;
     p.beam = ps == 0 ? o->beam : o->retry_beam; p.scale = o->acoustic_scale;
-    p.nmax = L.N; p.cmax = L.C; p.bpf = bpf; p.pass = ps; p.grow = L.grow; p.hbits = hash_bits(L.N);
+    p.nmax = L.N; p.cmax = L.C; p.bpf = bpf; p.pass = ps; p.grow = L.grow; p.hbits = hash_bits(max_states, L.N);
     // workspace strides follow this launch's capacities (lists and stash are per-launch scratch)
     WsLayout wp = ws_layout(n_utt, total_frames, L.N, L.C, bpf, total_arcs);
     p.w_state = (u32 *)(base + wp.state); p.w_cost = (double *)(base + wp.cost);
@@ -1016,7 +1025,7 @@ int align_impl(mfa_ctx *c, const mfa_graph_batch *g, const float *d_loglikes, co
       lds2 = lds_bytes(max_states, L.N2, L.C2, true);
       if (lds2 > kLdsLimit) return c->fail("Viterbi large tier needs %zu bytes of LDS", lds2);
       WsLayout w2 = ws_layout(n_utt, total_frames, L.N2, L.C2, bpf, total_arcs);
-      p2.nmax = L.N2; p2.cmax = L.C2; p2.hbits = hash_bits(L.N2);
+      p2.nmax = L.N2; p2.cmax = L.C2; p2.hbits = hash_bits(max_states, L.N2);
       // park arrays (state / cost) and the back-pointer trail are SHARED between the tiers: the layout of the large one
       p2.w_state = (u32 *)(base + w2.state); p2.w_cost = (double *)(base + w2.cost);
       p2.w_stash_a = (u32 *)(base + w2.sta); p2.w_stash_b = (u32 *)(base + w2.stb); p2.w_stash_key = (u64 *)(base + w2.stkey);
