@@ -191,6 +191,18 @@ MFA_API int mfa_align_batch(mfa_ctx *ctx, const mfa_graph_batch *graphs, const f
                             const int32_t *d_ll_cols, const int64_t *d_frame_off, int64_t total_frames,
                             int64_t total_arcs, int32_t max_states, int32_t max_arcs, const mfa_align_opts *opts, int32_t *d_ali, int32_t *d_words, int32_t *d_n_words,
                             float *d_like, float *d_frame_like, int32_t *d_status);
+/* ---- The same alignment for graphs the wavefront-parallel decoder does not take: EPSILON INPUT ARCS (ilabel 0; training
+ * graphs compiled by kalpy / Kaldi can hold them — FstArchive handed to export_alignments,
+ * MFA/alignment/multiprocessing.py:846-853) and states with more than 64 arcs.  FasterDecoder exactly as Kaldi runs it,
+ * ProcessNonemitting included (LIFO queue, hash-list insertion order), one GPU thread per utterance with every structure in a
+ * per-utterance HBM workspace: a correctness path (tens of milliseconds per 10 s utterance, thousands in parallel), results
+ * bit-identical to the oracle's.  Graph layout as for mfa_align_batch; d_arc_col of an epsilon arc is ignored.
+ * h_frame_off: host copy of d_frame_off (workspace sizing without a synchronisation on device data). */
+MFA_API int mfa_align_general_batch(mfa_ctx *ctx, const mfa_graph_batch *graphs, const float *d_loglikes,
+                                    const int64_t *d_ll_off, const int32_t *d_ll_cols, const int64_t *d_frame_off,
+                                    const int64_t *h_frame_off, int32_t max_states, int32_t max_arcs,
+                                    const mfa_align_opts *opts, int32_t *d_ali, int32_t *d_words, int32_t *d_n_words,
+                                    float *d_like, float *d_frame_like, int32_t *d_status);
 /* Bytes of device workspace mfa_align_batch will hold for a batch shape (so callers can budget HBM). */
 MFA_API size_t mfa_align_workspace_bytes(mfa_ctx *ctx, int32_t n_utt, int64_t total_frames, const mfa_align_opts *opts);
 

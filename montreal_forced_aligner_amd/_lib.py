@@ -12,7 +12,7 @@ from pathlib import Path
 
 _PKG = Path(__file__).resolve().parent
 _SO = _PKG / "libmfa_hip.so"
-_SOURCES = ["api.hip", "mfcc.hip", "feats.hip", "gmm.hip", "viterbi.hip", "fmllr.hip"]
+_SOURCES = ["api.hip", "mfcc.hip", "feats.hip", "gmm.hip", "viterbi.hip", "viterbi_general.hip", "fmllr.hip"]
 _LIB = None
 
 
@@ -103,6 +103,8 @@ SIGNATURES = {
     "mfa_gmm_score_batch": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mfa_align_batch": (C.c_int, [_vp, C.POINTER(GraphBatch), _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, C.POINTER(AlignOpts),
                                   _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mfa_align_general_batch": (C.c_int, [_vp, C.POINTER(GraphBatch), _vp, _vp, _vp, _vp, _vp, _i32, _i32, C.POINTER(AlignOpts),
+                                          _vp, _vp, _vp, _vp, _vp, _vp]),
     "mfa_align_features_batch": (C.c_int, [_vp, C.POINTER(GraphBatch), C.POINTER(ScorePlan), _vp, _vp, _i32, _i64, _i64, _i32, _i32,
                                            C.POINTER(AlignOpts), _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mfa_fst_last_depths": (C.c_int, [_i32, _vp, _vp, _i32, _vp, _vp]),

@@ -215,19 +215,37 @@ class CorpusAligner:
         kept = []
         for idx_all in self._batches(utts):
             fsts_all = [_graph.add_transition_probs(self.compiler.compile_fst(utts[i].text), self.scaled) for i in idx_all]
-            idx, fsts = [], []
-            for i, f in zip(idx_all, fsts_all):       # graphs the device decoder does not take: this utterance only
-                reason = None
-                if f.num_arcs == 0 or f.num_states == 0:
-                    reason = "empty training graph"
-                elif np.any(f.arcs["ilabel"] <= 0):
-                    reason = "training graph has epsilon input arcs"
-                elif int(np.diff(f.arc_offsets).max()) > 64:
-                    reason = "a graph state has more than 64 arcs"
-                if reason is None:
-                    idx.append(i); fsts.append(f)
+            idx, fsts, gidx, gfsts = [], [], [], []
+            for i, f in zip(idx_all, fsts_all):
+                if f.num_arcs == 0 or f.num_states == 0 or np.any(f.arcs["ilabel"] < 0):
+                    self.failure_reasons[utts[i].utt_id] = "empty or malformed training graph"   # this utterance only
+                elif eng.needs_general_decoder(f):    # epsilon input arcs / a state with more than 64 arcs
+                    gidx.append(i); gfsts.append(f)
                 else:
-                    self.failure_reasons[utts[i].utt_id] = reason
+                    idx.append(i); fsts.append(f)
+            if gidx:
+                # FasterDecoder as Kaldi runs it, ProcessNonemitting included (mfa_align_general_batch): the slow, exact path
+                mfcc, fo = self._mfcc(utts, gidx)
+                rows = np.array([spk_ids[utts[i].speaker] for i in gidx], dtype=np.int32)
+                feats = self._final_features(mfcc, fo, rows, cmvn, d_lda, fmllr)
+                gg = eng.pack_graphs_general(gfsts, self.tm)
+                rg = eng.align_general(gg, feats, fo, beam=o.beam, retry_beam=o.retry_beam, acoustic_scale=o.acoustic_scale,
+                                       bp_tokens_per_frame=max(o.bp_tokens_per_frame, 512))
+                st_g, ali_g, w_g = rg["status"].cpu().numpy(), rg["ali"].cpu().numpy(), rg["words"].cpu().numpy()
+                nw_g, like_g = rg["n_words"].cpu().numpy(), rg["like"].cpu().numpy()
+                for k, i in enumerate(gidx):
+                    a, b = int(fo[k]), int(fo[k + 1])
+                    if st_g[k] in (0, 1):
+                        results[i] = dict(ali=ali_g[a:b].copy(), words=w_g[a: a + int(nw_g[k])].copy(), like=float(like_g[k]), frames=b - a)
+                    else:
+                        self.failure_reasons[utts[i].utt_id] = ("no alignment within the retry beam" if st_g[k] == 2 else
+                                                               f"general decoder status {int(st_g[k])} (include/mfa_hip.h)")
+                if want_feats:
+                    ali_dev = rg["ali"].clone()
+                    for k in range(len(gidx)):
+                        if st_g[k] not in (0, 1):
+                            ali_dev[int(fo[k]): int(fo[k + 1])] = 0
+                    kept.append((gidx, feats, ali_dev, fo, rows))
             if not idx:
                 continue
             mfcc, fo = self._mfcc(utts, idx)

@@ -79,6 +79,8 @@ struct mfa_ctx {
   // Viterbi workspace
   void *d_ws = nullptr;
   size_t ws_bytes = 0;
+  void *d_gen_ws = nullptr;    // workspace of the general-graph decoder (viterbi_general.hip)
+  size_t gen_ws_bytes = 0;
 
   int fail(const char *fmt, ...) {
     char buf[1024];

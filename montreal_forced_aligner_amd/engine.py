@@ -246,6 +246,75 @@ class AlignmentEngine:
                                                      _ptr(out)), "mfa_gmm_score_batch")
         return out, ll_off, self._dev(P.astype(np.int32))
 
+    def pack_graphs_general(self, fsts: Sequence[Fst], tm: TransitionModel) -> PackedGraphs:
+        """Device layout for the general-graph decoder (mfa_align_general_batch): graphs may hold epsilon input arcs
+        (ilabel 0) and states of any out-degree.  One score column per pdf, no depth keys (scores are computed densely)."""
+        n = len(fsts)
+        S = np.array([f.num_states for f in fsts], dtype=np.int64)
+        A = np.array([f.num_arcs for f in fsts], dtype=np.int64)
+        state_off = np.concatenate([[0], np.cumsum(S)]).astype(np.int64)
+        arc_base = np.concatenate([[0], np.cumsum(A)]).astype(np.int64)
+        arc_off = np.concatenate([f.arc_offsets.astype(np.int32) for f in fsts]) if n else np.zeros(0, np.int32)
+        final = np.concatenate([f.final for f in fsts]).astype(np.float32)
+        arcs = np.concatenate([f.arcs for f in fsts])
+        if np.any(arcs["ilabel"] < 0) or np.any(arcs["ilabel"] > tm.num_transition_ids):
+            raise _lib.MfaHipError("a graph arc carries an input label outside the model's transition-ids")
+        pdf_of_arc = tm.id2pdf[arcs["ilabel"]]            # -1 for epsilon arcs
+        cols = np.zeros(arcs.shape[0], dtype=np.int32)
+        pdf_lists, counts = [], []
+        lut = np.full(tm.num_pdfs, -1, dtype=np.int32)
+        for u in range(n):
+            a0, a1 = int(arc_base[u]), int(arc_base[u + 1])
+            pa = pdf_of_arc[a0:a1]
+            emit = pa >= 0
+            pl, cc = self.sort_pdf_list(np.unique(pa[emit])) if emit.any() else (np.zeros(0, np.int32), np.zeros(6, np.int32))
+            lut[pl] = np.arange(pl.shape[0], dtype=np.int32)
+            cols[a0:a1] = np.where(emit, lut[np.maximum(pa, 0)], 0)
+            pdf_lists.append(pl)
+            counts.append(cc)
+        pdf_off = np.concatenate([[0], np.cumsum([len(p) for p in pdf_lists])]).astype(np.int64)
+        t = dict(
+            state_off=self._dev(state_off), arc_base=self._dev(arc_base),
+            start=self._dev(np.array([f.start for f in fsts], dtype=np.int32)),
+            arc_off=self._dev(arc_off), final=self._dev(final),
+            arc_next=self._dev(arcs["nextstate"].astype(np.int32)), arc_weight=self._dev(arcs["weight"].astype(np.float32)),
+            arc_col=self._dev(cols), arc_ilabel=self._dev(arcs["ilabel"].astype(np.int32)),
+            arc_olabel=self._dev(arcs["olabel"].astype(np.int32)),
+        )
+        return PackedGraphs(n, int(S.max()) if n else 0, int(A.max()) if n else 0, int(A.sum()), t,
+                            self._dev(np.concatenate(pdf_lists).astype(np.int32) if n else np.zeros(0, np.int32)),
+                            self._dev(pdf_off), self._dev(np.stack(counts).astype(np.int32)), pdf_off, pdf_lists)
+
+    def align_general(self, graphs: PackedGraphs, feats: torch.Tensor, frame_off: np.ndarray, beam: float = 10.0,
+                      retry_beam: float = 40.0, acoustic_scale: float = 0.1, bp_tokens_per_frame: int = 512,
+                      want_frame_likes: bool = False):
+        """Alignment over graphs with epsilon input arcs / wide states: dense scores, then FasterDecoder as Kaldi runs it
+        (ProcessNonemitting included), one GPU thread per utterance — mfa_align_general_batch."""
+        n = graphs.n_utt
+        total = int(frame_off[-1])
+        dev = self.device
+        ll, ll_off, ll_cols = self.score(feats, frame_off, graphs.pdf_list, graphs.pdf_off_host, graphs.class_counts)
+        ali = torch.zeros(total, dtype=torch.int32, device=dev)
+        words = torch.zeros(total, dtype=torch.int32, device=dev)
+        n_words = torch.zeros(n, dtype=torch.int32, device=dev)
+        like = torch.zeros(n, dtype=torch.float32, device=dev)
+        status = torch.full((n,), -1, dtype=torch.int32, device=dev)
+        flike = torch.zeros(total, dtype=torch.float32, device=dev) if want_frame_likes else None
+        opts = AlignOpts(beam, retry_beam, acoustic_scale, 0, bp_tokens_per_frame)
+        gs = graphs.struct()
+        d_lo, d_fo = self._dev(ll_off), self._dev(frame_off)
+        h_fo = np.ascontiguousarray(frame_off, dtype=np.int64)
+        check(self.ctx, self.lib.mfa_align_general_batch(self.ctx, C.byref(gs), _ptr(ll), _ptr(d_lo), _ptr(ll_cols), _ptr(d_fo),
+                                                         h_fo.ctypes.data, graphs.max_states, graphs.max_arcs, C.byref(opts),
+                                                         _ptr(ali), _ptr(words), _ptr(n_words), _ptr(like), _ptr(flike),
+                                                         _ptr(status)), "mfa_align_general_batch")
+        return dict(ali=ali, words=words, n_words=n_words, like=like, status=status, frame_like=flike)
+
+    @staticmethod
+    def needs_general_decoder(fst: Fst) -> bool:
+        """True for graphs the wavefront-parallel decoder does not take: epsilon input arcs, a state with > 64 arcs."""
+        return bool(fst.num_arcs and (np.any(fst.arcs["ilabel"] == 0) or int(np.diff(fst.arc_offsets).max()) > 64))
+
     def pack_graphs(self, fsts: Sequence[Fst], tm: TransitionModel, cluster_gap: Optional[int] = 32) -> PackedGraphs:
         """Concatenate per-utterance graphs (with transition probabilities already applied) into the device layout.
 

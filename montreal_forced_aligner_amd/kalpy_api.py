@@ -409,16 +409,37 @@ class GmmAligner:
         import torch
 
         eng = self._engine()
-        graphs = eng.pack_graphs([_graph.add_transition_probs(f, self._scaled) for f in fsts], self.transition_model)
+        general = [k for k, f in enumerate(fsts) if eng.needs_general_decoder(f)]
+        if general and len(general) < len(fsts):       # mixed batch: the two decoders take their own utterances
+            fast = [k for k in range(len(fsts)) if k not in set(general)]
+            out: List[Optional[Alignment]] = [None] * len(fsts)
+            for part in (fast, general):
+                ids = [utterance_ids[k] for k in part] if utterance_ids else None
+                for k, r in zip(part, self.align_utterances([fsts[k] for k in part], [feats[k] for k in part], ids)):
+                    out[k] = r
+            return out
         frame_off = np.concatenate([[0], np.cumsum([x.shape[0] for x in feats])]).astype(np.int64)
         d_feats = torch.from_numpy(np.concatenate(feats).astype(np.float32)).to(eng.device)
+        if general:
+            # graphs with epsilon input arcs (kalpy-compiled fsts.*.ark) or very wide states: FasterDecoder as Kaldi runs
+            # it, ProcessNonemitting included (mfa_align_general_batch)
+            graphs = eng.pack_graphs_general([_graph.add_transition_probs(f, self._scaled) for f in fsts], self.transition_model)
+            res = eng.align_general(graphs, d_feats, frame_off, beam=self.beam, retry_beam=self.retry_beam,
+                                    acoustic_scale=self.acoustic_scale, want_frame_likes=True)
+            res = {k: v.cpu().numpy() for k, v in res.items() if isinstance(v, torch.Tensor)}
+            return self._collect(res, frame_off, len(fsts), utterance_ids)
+        graphs = eng.pack_graphs([_graph.add_transition_probs(f, self._scaled) for f in fsts], self.transition_model)
         # features in, alignments out — the decodable is evaluated lazily, as Kaldi's is: per window of frames only the
         # pdfs that arcs near the live tokens can emit are scored (mfa_align_features_batch)
         res = eng.align_features(graphs, d_feats, frame_off, beam=self.beam, retry_beam=self.retry_beam,
                                  acoustic_scale=self.acoustic_scale, want_frame_likes=True)
         res = {k: v.cpu().numpy() for k, v in res.items() if isinstance(v, torch.Tensor)}
+        return self._collect(res, frame_off, len(fsts), utterance_ids)
+
+    @staticmethod
+    def _collect(res, frame_off, n, utterance_ids) -> List[Optional[Alignment]]:
         out: List[Optional[Alignment]] = []
-        for u in range(len(fsts)):
+        for u in range(n):
             st = int(res["status"][u])
             if st not in (0, 1):
                 # the reference returns None and lets the caller count the failure (capacity / unsupported-graph statuses

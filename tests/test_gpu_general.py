@@ -1,0 +1,163 @@
+"""Graphs with epsilon input arcs (and states wider than 64 arcs) through mfa_align_general_batch — FasterDecoder with
+ProcessNonemitting, one GPU thread per utterance — against the oracle, which implements the same rules
+(oracle/mfa_oracle.cpp: ProcessNonemitting, HashList).  kalpy-compiled training graphs (FstArchive handed to
+export_alignments, MFA/alignment/multiprocessing.py:846-853) can hold such arcs.  Bit-exact or it fails."""
+import numpy as np
+import pytest
+import torch
+
+from montreal_forced_aligner_amd import graph as G
+from montreal_forced_aligner_amd import kaldi_io as K
+from oracle import oracle as O
+from tests import helpers
+from tests.test_gpu_parity import _random_graph
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(e, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(e.device)
+
+
+def _with_eps(rng, f, frac=0.3):
+    """An equivalent graph with epsilon input arcs: a share of the arcs s -il:ol/w-> d is split into
+    s -eps:ol/w-> m -il:eps/0-> d through a fresh state m (the word label and the weight travel on the epsilon arc)."""
+    S = f.num_states
+    arcs_by_state = [[] for _ in range(S)]
+    for s in range(S):
+        for a in range(int(f.arc_offsets[s]), int(f.arc_offsets[s + 1])):
+            arcs_by_state[s].append(tuple(f.arcs[a]))
+    extra = []
+    final = list(f.final)
+    for s in range(S):
+        new = []
+        for (il, ol, w, d) in arcs_by_state[s]:
+            if il != 0 and d != s and rng.random() < frac:
+                m = S + len(extra)
+                extra.append([(il, 0, 0.0, d)])
+                final.append(np.inf)
+                new.append((0, ol, w, m))
+            else:
+                new.append((il, ol, w, d))
+        arcs_by_state[s] = new
+    allst = arcs_by_state + extra
+    offs = np.concatenate([[0], np.cumsum([len(x) for x in allst])]).astype(np.int64)
+    arr = np.zeros(int(offs[-1]), dtype=K.ARC_DTYPE)
+    k = 0
+    for lst in allst:
+        for t in lst:
+            arr[k] = t
+            k += 1
+    return K.Fst(f.start, offs, arr, np.asarray(final, dtype=np.float32))
+
+
+def _oracle(tm, am, f, x, beam, retry):
+    emit = f.arcs["ilabel"] > 0
+    pl = np.unique(tm.id2pdf[f.arcs["ilabel"][emit]])
+    ll = O.gmm_loglikes(x, am.gconsts, am.means_invvars, am.inv_vars, am.pdf_offsets, pl)
+    return helpers.oracle_align(tm, f, ll, pl, beam=beam, retry_beam=retry)
+
+
+def _check(engine, tm, am, fsts, feats, beam, retry):
+    engine.load_gmm(am)
+    fo = np.concatenate([[0], np.cumsum([x.shape[0] for x in feats])]).astype(np.int64)
+    g = engine.pack_graphs_general(fsts, tm)
+    res = engine.align_general(g, _dev(engine, np.concatenate(feats)), fo, beam=beam, retry_beam=retry, want_frame_likes=True)
+    res = {k: v.cpu().numpy() for k, v in res.items() if v is not None}
+    seen = set()
+    for u, f in enumerate(fsts):
+        ref = _oracle(tm, am, f, feats[u], beam, retry)
+        assert int(res["status"][u]) == ref["status"], (u, int(res["status"][u]), ref["status"])
+        seen.add(ref["status"])
+        if ref["status"] in (0, 1):
+            a, b = int(fo[u]), int(fo[u + 1])
+            assert np.array_equal(res["ali"][a:b], ref["ali"]), u
+            nw = int(res["n_words"][u])
+            assert np.array_equal(res["words"][a: a + nw], ref["words"]), u
+            # scores: the device's f32 kernel vs the oracle's chain are bit-identical for single Gaussians
+            assert res["like"][u] == np.float32(ref["like"]), (u, res["like"][u], ref["like"])
+            assert np.array_equal(res["frame_like"][a:b], ref["per_frame"]), u
+    return seen
+
+
+def test_training_graphs_with_epsilon_arcs_match_the_oracle(engine, fx):
+    """The reference's recording and plumbing model; training graphs rewritten with epsilon arcs on a third of their
+    arcs: same alignment as the oracle on the same graph, and — the rewriting being an equivalence — the same transition-ids
+    as the epsilon-free graph gives on the fast path when nothing is pruned."""
+    tm, am = fx.mono_tm, fx.mono_am
+    rng = np.random.default_rng(2)
+    sr = 16000
+    cuts = [(0.0, 4.2), (4.0, 6.5), (23.5, 26.72)]
+    texts = ["this is the acoustic corpus i'm talking pretty fast here", "there's nothing going else going on",
+             "um and that should be all thanks"]
+    feats = [fx.mono_feats(fx.pcm[int(a * sr): int(b * sr)]) for a, b in cuts]
+    plain = [fx.mono_graph(t) for t in texts]
+    fsts = [_with_eps(rng, f) for f in plain]
+    assert all((f.arcs["ilabel"] == 0).any() for f in fsts)
+    for beam, retry in ((100.0, 400.0), (10.0, 40.0), (1.0e4, 0.0)):
+        _check(engine, tm, am, fsts, feats, beam, retry)
+    # equivalence with the epsilon-free graphs on the fast path (no pruning: beam 1e4)
+    engine.load_gmm(am)
+    fo = np.concatenate([[0], np.cumsum([x.shape[0] for x in feats])]).astype(np.int64)
+    d_feats = _dev(engine, np.concatenate(feats))
+    gp = engine.pack_graphs(plain, tm)
+    fast = engine.align_features(gp, d_feats, fo, beam=1.0e4, retry_beam=0.0, max_tokens=gp.max_states, bp_tokens_per_frame=gp.max_states)
+    gen = engine.align_general(engine.pack_graphs_general(fsts, tm), d_feats, fo, beam=1.0e4, retry_beam=0.0)
+    assert torch.equal(fast["ali"], gen["ali"]) and torch.equal(fast["n_words"], gen["n_words"])
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_general_decoder_fuzz_with_epsilon_arcs(engine, fx, seed):
+    """Random graphs (cycles, dead ends, out-degrees up to 90, exact cost ties) in which a fifth of the arcs are epsilon arcs —
+    epsilon chains and zero-weight epsilon cycles included — against the oracle: hash-list order, LIFO closure, min_active,
+    retry beam, failures."""
+    tm, am = fx.mono_tm, fx.mono_am
+    rng = np.random.default_rng(3000 + seed)
+    fsts, feats = [], []
+    for u in range(16):
+        S = int(rng.choice([3, 8, 40, 150, 400, 1100]))
+        f = _random_graph(rng, tm, S)
+        arcs = f.arcs.copy()
+        eps = rng.random(len(arcs)) < 0.2
+        arcs["ilabel"][eps] = 0
+        if u % 4 == 0 and S >= 8:          # a state wider than the fast decoder's 64 arcs
+            wide = np.zeros(90, dtype=K.ARC_DTYPE)
+            for k in range(90):
+                wide[k] = (int(rng.integers(1, tm.num_transition_ids + 1)), 0, float(rng.integers(0, 8)) * 0.25, int(rng.integers(0, S)))
+            a0 = int(f.arc_offsets[1])
+            arcs = np.concatenate([arcs[:a0], wide, arcs[a0:]])
+            offs = f.arc_offsets.copy()
+            offs[2:] += 90
+            f = K.Fst(f.start, offs, arcs, f.final)
+        else:
+            f = K.Fst(f.start, f.arc_offsets, arcs, f.final)
+        fsts.append(f)
+        feats.append(rng.normal(0, 3.0, size=(int(rng.integers(2, 120)), 39)).astype(np.float32))
+    beam, retry = [(1.0, 4.0), (8.0, 32.0), (50.0, 0.0)][seed]
+    seen = _check(engine, tm, am, fsts, feats, beam, retry)
+    assert seen & {0, 1}
+
+
+def test_kalpy_facade_routes_epsilon_graphs(engine, fx):
+    """GmmAligner.align_utterance(fst, feats) takes an epsilon graph like any other (the general decoder behind it), also
+    in a batch mixed with epsilon-free graphs."""
+    from montreal_forced_aligner_amd import kalpy_api as KA
+
+    tm, am = fx.mono_tm, fx.mono_am
+    rng = np.random.default_rng(8)
+    x = fx.mono_feats(fx.pcm[: 16000 * 4])
+    plain = fx.mono_gc.compile_fst("this is the acoustic corpus")
+    eps = _with_eps(rng, plain)
+    al = KA.GmmAligner.__new__(KA.GmmAligner)
+    al.acoustic_model_path = "mono"; al.transition_model, al.acoustic_model = tm, am
+    al.beam, al.retry_beam = 100.0, 400.0
+    al.transition_scale, al.acoustic_scale, al.self_loop_scale = 1.0, 0.1, 0.1
+    al.disambiguation_symbols = []
+    al._scaled = tm.scaled_log_probs(1.0, 0.1)
+    al._loaded = False
+    KA._ENGINE = engine
+    out = al.align_utterances([plain, eps, plain], [x, x, x], ["a", "b", "c"])
+    assert all(o is not None for o in out)
+    ref = _oracle(tm, am, G.add_transition_probs(eps, al._scaled), x, 100.0, 400.0)
+    assert out[1].alignment == ref["ali"].tolist() and out[1].words == ref["words"].tolist()
+    assert out[0].alignment == out[2].alignment
