@@ -81,6 +81,10 @@ struct GmmParams {
   const int32_t *last_depth;   // parallel to pdf_list: running max (inside a class) of the longest-path depth of the pdf's sources
   int b_skip0;                 // f32 band kernel: classes 0, 2, 3, 4 were scored by gmm_band_kernel (it keeps 1 and 5)
   int b_chunk, b_nchunk;       // gmm_band_kernel: columns per wavefront (0 = the whole band) and chunks per sub-tile
+  int dbg_nostore;             // timing experiments only (MFA_GMM_NOSTORE=1): band kernel computes but does not store
+  int b_xcd;                   // gmm_band_kernel: 1 = eight wavefronts per sub-tile, wavefront x (in a workgroup with blockIdx % 8 == x,
+                               // i.e. on one XCD) scores the band's pdfs with id % 8 == x: an XCD's L2 then only ever sees an
+                               // eighth of the model
 };
 
 // Band of one (utterance, window): pdf j of a class is needed iff first_frame[j] <= hi and last_depth[j] >= lo; both keys
@@ -94,7 +98,7 @@ __device__ __forceinline__ Band band_of(const GmmParams &p, int utt) {
 }
 // wavefront → (utterance, 64-frame sub-tile) of a band-mode launch; false: nothing to do
 __device__ __forceinline__ bool band_item(const GmmParams &p, int wave, int &utt, int &r, int *chunk = nullptr) {
-  int witem = blockIdx.x * 4 + wave;
+  int witem = (p.b_xcd ? (int)(blockIdx.x >> 3) : (int)blockIdx.x) * 4 + wave;
   if (chunk) { const int q = witem / p.b_nchunk; *chunk = witem - q * p.b_nchunk; witem = q; }
   const int item = witem / p.b_sub;
   r = witem - item * p.b_sub;
@@ -1426,8 +1430,12 @@ __global__ __launch_bounds__(256, 2) void gmm_band_kernel(GmmParams p) {
   using op8 = std::conditional_t<kHalf, f16x8, bf16x8>;
   constexpr int kUnits = kSteps * kPieces * 2 * 32;    // 16-byte units per block
   __shared__ float stage_all[4][64 * 33];
+  constexpr int kMineCap = 128;
+  __shared__ int mine_all[4][kMineCap];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float *stage = stage_all[wave];
+  int *mine = mine_all[wave];
+  const int xsel = p.b_xcd ? (int)(blockIdx.x & 7u) : -1;
   int utt, r, chunk = 0;
   if (!band_item(p, wave, utt, r, &chunk)) return;
   const int64_t f0 = p.frame_off[utt];
@@ -1467,6 +1475,7 @@ __global__ __launch_bounds__(256, 2) void gmm_band_kernel(GmmParams p) {
     hi_c[0] = min(hi_c[0], lo_c[0] + p.b_chunk);
     if (chunk != 0) { hi_c[2] = lo_c[2]; hi_c[3] = lo_c[3]; hi_c[4] = lo_c[4]; }
   }
+  if (xsel > 0) { hi_c[2] = lo_c[2]; hi_c[3] = lo_c[3]; hi_c[4] = lo_c[4]; }   // the small-slot classes stay with wavefront 0
   const int lo = lo_c[0], hi = hi_c[0];
   if (lo >= hi && lo_c[2] >= hi_c[2] && lo_c[3] >= hi_c[3] && lo_c[4] >= hi_c[4]) {
     if (kHalf && lane == 0) *redo_flag = 0;
@@ -1492,12 +1501,101 @@ __global__ __launch_bounds__(256, 2) void gmm_band_kernel(GmmParams p) {
 #pragma unroll 4
     for (int i = 0; i < 32; i++) {
       const int rr = h + 2 * i, t = t_base + rr;
-      if (col < cnt && t < T) __builtin_nontemporal_store(stage[rr * 33 + col], &out[(size_t)t * P + c0 + col]);
+      if (col < cnt && t < T && !p.dbg_nostore) __builtin_nontemporal_store(stage[rr * 33 + col], &out[(size_t)t * P + c0 + col]);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   };
 
+  // ---------------------------------------------------------------- class 0, one XCD's share of the band
+  if (xsel >= 0 && lo < hi) {
+    const uint4 *wsrc = (kHalf ? p.wh : p.wb) + lane;
+    const float *gsrc = (kHalf ? p.gch : p.gc) + 4 * h;
+    int jpos = lo;
+    while (jpos < hi) {                                  // rounds of at most kMineCap of this wavefront's columns
+      int cnt = 0;
+      while (jpos < hi && cnt <= kMineCap - 64) {
+        const int j = jpos + lane;
+        const bool m = j < hi && (list[min(j, hi - 1)] & 7) == xsel;
+        const unsigned long long mask = __ballot(m);
+        if (m) mine[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = j;
+        cnt += __popcll(mask);
+        jpos += 64;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (cnt == 0) continue;
+      const int last = cnt - 1;
+      auto block_at = [&](int i) { return __builtin_amdgcn_readfirstlane(p.row0[list[mine[min(i, last)]]]) >> 5; };
+      op8 a[kSteps][kPieces];
+      f32x4 g[4];
+      {
+        const int blk = block_at(0);
+        const uint4 *src = wsrc + (size_t)blk * kUnits;
+#pragma unroll
+        for (int q = 0; q < 4; q++) g[q] = *reinterpret_cast<const f32x4 *>(gsrc + (size_t)blk * 32 + 8 * q);
+#pragma unroll
+        for (int s_ = 0; s_ < kSteps; s_++)
+#pragma unroll
+          for (int q = 0; q < kPieces; q++) a[s_][q] = __builtin_bit_cast(op8, src[(s_ * kPieces + q) * 64]);
+      }
+      int blk_next = block_at(1);
+      int mycol = 0;                                     // score column of staging slot `col`
+      for (int i = 0; i < cnt; i++) {
+        const int j = __builtin_amdgcn_readfirstlane(mine[i]);
+        const int x_next2 = p.row0[list[mine[min(i + 2, last)]]];
+        f32x16 init, acc[2];
+#pragma unroll
+        for (int rr = 0; rr < 16; rr++) init[rr] = g[rr >> 2][rr & 3];
+        const uint4 *src = wsrc + (size_t)blk_next * kUnits;
+        const float *gn = gsrc + (size_t)blk_next * 32;
+#pragma unroll
+        for (int s_ = 0; s_ < kSteps; s_++) {
+#pragma unroll
+          for (int t6 = 0; t6 < kProd; t6++)
+#pragma unroll
+            for (int n = 0; n < 2; n++) {
+              const f32x16 &cin = (s_ == 0 && t6 == 0) ? init : acc[n];
+              if constexpr (kHalf) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s_][pa[t6]], b[n][s_][pb[t6]], cin, 0, 0, 0);
+              else acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s_][pa[t6]], b[n][s_][pb[t6]], cin, 0, 0, 0);
+            }
+          if (s_ == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) g[q] = *reinterpret_cast<const f32x4 *>(gn + 8 * q);
+          }
+#pragma unroll
+          for (int q = 0; q < kPieces; q++) a[s_][q] = __builtin_bit_cast(op8, src[(s_ * kPieces + q) * 64]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        blk_next = __builtin_amdgcn_readfirstlane(x_next2) >> 5;
+        float mx[2], sum[2];
+#pragma unroll
+        for (int n = 0; n < 2; n++) {
+          float m = reg_max<0, 16>(acc[n]);
+          m = fmaxf(m, swap32(m, h));
+          float sv = reg_expsum_fast(acc[n], m, l2e_s);
+          sv += swap32(sv, h);
+          mx[n] = m; sum[n] = sv;
+        }
+        const int jj = i & 31;
+        if (col == jj) mycol = j;
+        stage[(32 * h + col) * 33 + jj] = finish((h ? mx[1] : mx[0]) * inv_s, h ? sum[1] : sum[0]);
+        if (jj == 31 || i == last) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 4
+          for (int q = 0; q < 32; q++) {
+            const int rr = h + 2 * q, t = t_base + rr;
+            if (col <= jj && t < T && !p.dbg_nostore) __builtin_nontemporal_store(stage[rr * 33 + col], &out[(size_t)t * P + mycol]);
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+    }
+  } else
   // ---------------------------------------------------------------- class 0: one pdf per 32-row block
   if (lo < hi) {
     const uint4 *wsrc = (kHalf ? p.wh : p.wb) + lane;
@@ -2261,7 +2359,9 @@ int mfa_gmm_score_window(mfa_ctx *c, const MfaLazyScoring *lazy, const MfaWindow
   p.b_chunk = ws->cols_per_wave > 0 ? ws->cols_per_wave : 0;
   p.b_nchunk = p.b_chunk > 0 ? (lazy->plan.max_cols + p.b_chunk - 1) / p.b_chunk : 1;
   const int64_t split_waves = waves * p.b_nchunk;
-  const dim3 split_grid((unsigned)((split_waves + 3) / 4));
+  { const char *e = getenv("MFA_GMM_NOSTORE"); p.dbg_nostore = (e && e[0] == '1') ? 1 : 0; }
+  { const char *e = getenv("MFA_GMM_XCD"); p.b_xcd = (p.b_chunk == 0 && e && e[0] == '1') ? 1 : 0; }
+  const dim3 split_grid((unsigned)((split_waves + 3) / 4) * (p.b_xcd ? 8u : 1u));
   const int m8 = c->kpad / 8;
   const char *bf = getenv("MFA_GMM_BF16");
   const char *hf = getenv("MFA_GMM_F16");
@@ -2290,6 +2390,7 @@ int mfa_gmm_score_window(mfa_ctx *c, const MfaLazyScoring *lazy, const MfaWindow
     p.redo_mode = 0;
     p.b_skip0 = 1;
   }
+  p.b_xcd = 0;   // (the f32 band kernel keeps one wavefront per sub-tile)
   const bool f32_classes = c->has_multi_block || c->has_slot_class[4];   // pdfs of more than 32 Gaussians, single Gaussians
   if (!p.b_skip0 || f32_classes) {
     if (m8 <= 10) hipLaunchKernelGGL((gmm_band_f32_kernel<10>), grid, dim3(256), 0, c->stream, p);

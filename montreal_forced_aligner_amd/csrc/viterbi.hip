@@ -301,6 +301,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 #endif
 #ifdef VIT_STAMPS
     stamp_acc[10] += (unsigned long long)n;   // tokens entering the frame
+    stamp_acc[11] += 1;                       // frames
 #endif
     STAMP(0);   // score row staged
     // Two address spaces, two loads, never a pointer select: a select turns into a FLAT load, whose wait
@@ -684,7 +685,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     STAMP(8);   // new list, back-pointers, table reset
   }
 #ifdef VIT_STAMPS
-  if (lane == 0 && p.pass == 0 && p.stamps) for (int k = 0; k < 12; k++) p.stamps[(size_t)utt * 12 + k] = stamp_acc[k];
+  // accumulated over the windows of the first tier (the caller zeroes the buffer); [11] = frames decoded
+  if (lane == 0 && p.pass == 0 && p.stamps && p.redo_mode != 2 && p.utt_list == nullptr)
+    for (int k = 0; k < 12; k++) p.stamps[(size_t)utt * 12 + k] += stamp_acc[k];
 #endif
   __threadfence_block();  // back-pointer records (HBM) are read back by the traceback below
   if (p.redo_mode == 1 && status == ST_TOKEN_OVERFLOW) {

@@ -109,8 +109,10 @@ class LexiconCompiler:
         position_dependent_phones: bool = False,
         ignore_case: bool = True,
         phones: Optional[Iterable[str]] = None,
+        share_suffixes: bool = True,
     ):
         self.disambiguation = disambiguation
+        self.share_suffixes = share_suffixes  # merge indistinguishable states of the per-utterance phone graph
         self.silence_probability = silence_probability
         self.initial_silence_probability = initial_silence_probability
         self.final_silence_correction = final_silence_correction
@@ -321,6 +323,8 @@ class LexiconCompiler:
         if n == 0:
             g.final[start] = eps_cost + g.final[NS[0]]
         g.trim()
+        if self.share_suffixes:
+            g.merge_suffixes()
         return g
 
 
@@ -393,6 +397,45 @@ class PhoneGraph:
         self.final = {new_id[u]: w for u, w in self.final.items() if keep[u] and new_id[u] != -1 and math.isfinite(w)}
         self.arcs = arcs
         self.start = 0
+
+    def merge_suffixes(self) -> None:
+        """Merge nodes whose futures are identical (same final cost, same outgoing (phone, word, cost, successor) set).
+
+        The chains a pronunciation hangs off NS_i and off S_i (and off the start) differ only in their first arc — the
+        source-dependent cost sits there — so from the second node on they are the same automaton; the reference's
+        pipeline removes the copies with MinimizeEncoded after DeterminizeStarInLog (Kaldi training-graph-compiler.cc,
+        reached through kalpy TrainingGraphCompiler).  The graph is acyclic (phones only move forward through the
+        transcript), so one pass in reverse topological order with hash-consing of (final, arcs) is a full backward
+        minimisation.  Every path keeps its labels and its cost bit for bit; only states nobody can tell apart go."""
+        n = len(self.arcs)
+        indeg = [0] * n
+        for a in self.arcs:
+            for (v, *_r) in a:
+                indeg[v] += 1
+        topo = [u for u in range(n) if indeg[u] == 0]
+        qi = 0
+        while qi < len(topo):
+            u = topo[qi]
+            qi += 1
+            for (v, *_r) in self.arcs[u]:
+                indeg[v] -= 1
+                if indeg[v] == 0:
+                    topo.append(v)
+        if len(topo) != n:
+            return          # a cycle (caller-built graph): leave it alone
+        rep = list(range(n))
+        seen: Dict[tuple, int] = {}
+        for u in reversed(topo):
+            arcs = []
+            for (v, ph, ol, w) in self.arcs[u]:
+                a = (rep[v], ph, ol, w)
+                if a not in arcs:
+                    arcs.append(a)
+            self.arcs[u] = arcs
+            sig = (self.final.get(u), tuple(sorted(arcs)))
+            rep[u] = seen.setdefault(sig, u)
+        self.start = rep[self.start]
+        self.trim()
 
 
 class TrainingGraphCompiler:

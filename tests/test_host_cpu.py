@@ -205,3 +205,54 @@ def test_lexicon_fst_equals_the_references_expected_file():
     target = canon(arcs_b, fin_b, list(range(nb)))
     assert any(canon(arcs_a, fin_a, (0,) + perm) == target for perm in itertools.permutations(range(1, na))), \
         "no renumbering of states maps the generated L.fst onto the reference's expected one"
+
+
+def test_suffix_sharing_keeps_every_path_of_the_phone_graph(fx):
+    """LexiconCompiler(share_suffixes=True) (default) merges states with identical futures, as the reference's
+    MinimizeEncoded step does (kalpy TrainingGraphCompiler → Kaldi training-graph-compiler.cc).  The multiset of
+    (phone sequence, word sequence, cost) paths must not change: enumerated exhaustively on short transcripts, and on
+    the long one the unpruned best path through the compiled graph keeps its cost and its labels."""
+    import copy
+
+    from montreal_forced_aligner_amd import graph as G
+    from oracle import oracle as O
+
+    lex = fx.mono_lex
+    plain = copy.copy(lex)
+    plain.share_suffixes = False
+    assert lex.share_suffixes
+
+    def paths(pg):
+        out = []
+
+        def walk(u, phones, words, cost):
+            if u in pg.final:
+                out.append((tuple(phones), tuple(words), round(cost + pg.final[u], 9)))
+            for (v, ph, ol, w) in pg.arcs[u]:
+                walk(v, phones + [ph], words + ([ol] if ol else []), cost + w)
+
+        walk(pg.start, [], [], 0.0)
+        return sorted(out)
+
+    for text in ("this is", "the acoustic corpus", "i'm"):
+        a, b = plain.phone_graph(text.split()), lex.phone_graph(text.split())
+        pa, pb = paths(a), paths(b)
+        assert sorted(set(pa)) == sorted(set(pb)) and len(pb) == len(set(pb))
+        assert len(b.arcs) < len(a.arcs)
+    text = " ".join(fx.text.split()[:12])
+    tm = fx.mono_tm
+    scaled = tm.scaled_log_probs(1.0, 0.1)
+    gc_plain = G.TrainingGraphCompiler(tm, fx.mono_tree, plain)
+    f_a = G.add_transition_probs(gc_plain.compile_fst(text), scaled)
+    f_b = fx.mono_graph(text)
+    assert f_b.num_states < 0.7 * f_a.num_states
+    x = fx.mono_feats(fx.pcm[: 16000 * 5])
+    am = fx.mono_am
+    pl = np.arange(am.num_pdfs)
+    ll = O.gmm_loglikes(x, am.gconsts, am.means_invvars, am.inv_vars, am.pdf_offsets, pl)
+    from tests import helpers
+    r_a = helpers.oracle_align(tm, f_a, ll, pl, beam=1e9, retry_beam=0.0)
+    r_b = helpers.oracle_align(tm, f_b, ll, pl, beam=1e9, retry_beam=0.0)
+    assert r_a["status"] == 0 and r_b["status"] == 0
+    assert np.array_equal(r_a["words"], r_b["words"]) and np.array_equal(r_a["ali"], r_b["ali"])
+    assert abs(r_a["like"] - r_b["like"]) < 1e-2

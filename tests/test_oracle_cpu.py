@@ -228,9 +228,9 @@ def test_parallel_formulation_of_the_decoder_matches_sequential_oracle(fx):
         T = int(3 * nph * rng.uniform(1.0, 2.5)) + 2
         sd = float(rng.choice([0.0, 3.0, 12.0, 40.0]))
         cases.append((fx.mono_graph(text), rng.normal(-60.0, sd, size=(T, tm.num_pdfs)).astype(np.float32)))
-    big = fx.mono_graph(" ".join(fx.text.split()[:24]))
+    big = fx.mono_graph(" ".join(fx.text.split()[:44]))
     assert big.num_states > 1000
-    cases.append((big, rng.normal(-60.0, 6.0, size=(330, tm.num_pdfs)).astype(np.float32)))
+    cases.append((big, rng.normal(-60.0, 6.0, size=(600, tm.num_pdfs)).astype(np.float32)))
     n_ok = 0
     for f, ll in cases:
         for beam in (0.7, 3.0, 10.0, 200.0):

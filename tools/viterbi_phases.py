@@ -8,7 +8,7 @@ import sys
 import numpy as np
 
 a = np.load(sys.argv[1]).astype(np.float64)
-frames = float(sys.argv[2]) if len(sys.argv) > 2 else 1000.0
+frames = float(sys.argv[2]) if len(sys.argv) > 2 else float(a[:, 11].mean())   # [11] = frames each utterance decoded
 names = ["score row staged", "GetCutoff", "candidate layout (scan, owner map)", "arc gather + score + cost",
          "running cutoff (seed, prefix-min)", "claim / lower / winner", "general path + stash winners",
          "list order (bucket ranks, ordinal scan)", "new list, back-pointers, reset"]
