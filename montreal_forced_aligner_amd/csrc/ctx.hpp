@@ -41,11 +41,12 @@ struct mfa_ctx {
   mfa_mfcc_opts mfcc{};
   bool mfcc_ready = false;
   int win = 0, shift = 0, nfft = 0;
-  float *d_window = nullptr;   // [win]
-  float *d_twiddle = nullptr;  // [nfft/2][2] cos,sin of -2*pi*k/nfft ... see mfcc.hip
-  float *d_melw = nullptr;     // [nbins][2] packed sparse: see mfcc.hip
-  int32_t *d_melidx = nullptr;  // [64][4] per-lane filterbank plan, see mfcc.hip
-  int n_melw = 0;
+  float *d_window = nullptr;   // [16][16][2] window pairs in lane order, see mfcc.hip
+  float *d_twiddle = nullptr;  // [2][16][16][2] W256^(i k1), W512^(i + 16 k2) in lane order, see mfcc.hip
+  float *d_melw = nullptr;     // [pieces][taps] filterbank piece weights, see mfcc.hip
+  int32_t *d_melidx = nullptr;  // [128] first FFT bin per piece + [32] (first piece | pieces << 8) per mel bin
+  int n_melw = 0;              // filterbank pieces
+  int mel_piece_taps = 0, mel_np_max = 1;
   float *d_dct = nullptr;      // [nceps][nbins] with lifter folded separately
   float *d_lifter = nullptr;   // [nceps]
 

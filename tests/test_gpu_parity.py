@@ -197,7 +197,7 @@ def test_viterbi_real_audio_identical_to_oracle(engine, fx):
     pdfs = np.arange(am.num_pdfs, dtype=np.int32)
     lls = [O.gmm_loglikes(x, am.gconsts, am.means_invvars, am.inv_vars, am.pdf_offsets, pdfs) for x in feats]
     fsts = [fx.mono_graph(t) for t in texts]
-    assert fsts[2].num_states > 2000  # more states than the decoder's 1000 hash buckets: bucket-order path
+    assert fsts[2].num_states > 1000  # more states than the decoder's 1000 hash buckets: bucket-order path
     for beam, retry in ((100.0, 400.0), (10.0, 40.0), (30.0, 120.0)):
         res = _align_case(engine, tm, am, fsts, lls, beam, retry, max_tokens=2048)
         assert set(res["status"].tolist()) <= {0, 1, 2}
