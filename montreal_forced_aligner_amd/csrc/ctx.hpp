@@ -44,9 +44,9 @@ struct mfa_ctx {
   float *d_window = nullptr;   // [16][16][2] window pairs in lane order, see mfcc.hip
   float *d_twiddle = nullptr;  // [2][16][16][2] W256^(i k1), W512^(i + 16 k2) in lane order, see mfcc.hip
   float *d_melw = nullptr;     // [pieces][taps] filterbank piece weights, see mfcc.hip
-  int32_t *d_melidx = nullptr;  // [128] first FFT bin per piece + [32] (first piece | pieces << 8) per mel bin
+  int32_t *d_melidx = nullptr;  // [96] first FFT bin per piece + [32] (first piece | pieces << 8) per mel bin
   int n_melw = 0;              // filterbank pieces
-  int mel_piece_taps = 0, mel_np_max = 1;
+  int mel_np_max = 1;
   float *d_dct = nullptr;      // [nceps][nbins] with lifter folded separately
   float *d_lifter = nullptr;   // [nceps]
 

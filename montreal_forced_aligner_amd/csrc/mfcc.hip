@@ -34,23 +34,27 @@ constexpr int kFramesPerBlock = kWavesPerBlock * kFramesPerWave;
 constexpr int kMaxBins = 32;
 constexpr int kMaxCeps = 16;            // one lane of a row per cepstral coefficient
 constexpr int kMaxDct = 384;            // coefficients × bins
-constexpr int kMaxPieces = 128;         // filterbank pieces (16 lanes × at most 8 rounds)
-constexpr int kMaxMelW = 768;           // pieces × taps per piece (zero padded)
+constexpr int kMaxPieces = 96;          // filterbank pieces (16 lanes × at most 6 rounds)
+constexpr int kPieceTaps = 8;           // FFT bins per piece (short pieces are zero padded)
+constexpr int kMaxMelW = kMaxPieces * kPieceTaps;
 constexpr int kRowPad = 17;             // float2 row stride of the transposition tile: 34 dwords ≡ 2 (mod 32)
 constexpr int kTileFloats = 4 * 16 * kRowPad * 2;   // one wavefront's LDS tile: 2 176 floats
-constexpr int kPStride = 272;           // power spectrum of one frame: 256 bins + room for a piece's zero-weight tail
-constexpr int kPartOff = 4 * kPStride;  // [4][kMaxPieces] piece sums
-constexpr int kMelOff = kPartOff + 4 * kMaxPieces;   // [4][kMaxBins] log mel energies
-static_assert(kMelOff + 4 * kMaxBins <= kTileFloats, "tile reuse");
+// row strides of the reused tile are chosen so that the two rows of a 32-lane LDS group land on different banks
+constexpr int kPStride = 273;           // power spectrum of one frame: 256 bins + room for a piece's zero-weight tail
+constexpr int kPartStride = kMaxPieces + 8;
+constexpr int kMelStride = kMaxBins + 8;
+constexpr int kPartOff = 4 * kPStride;  // [4][kPartStride] piece sums
+constexpr int kMelOff = kPartOff + 4 * kPartStride;   // [4][kMelStride] log mel energies
+static_assert(kMelOff + 4 * kMelStride <= kTileFloats, "tile reuse");
 
 struct MfccParams {
   int win, shift, nbins, nceps, snip_edges, remove_dc;
-  int n_pieces, piece_taps, n_rounds, np_max;
+  int n_pieces, n_rounds, np_max;
   float preemph;
   const float *window;      // [16][16][2]: window[2m], window[2m+1] for m = i + 16 j (0 beyond the window)
   const float *tw256;       // [16][16][2]: W256^(i·k1) at [k1][i]
-  const float *tw512;       // [16][16][2]: W512^(i + 16 k2) at [k2][i]
-  const float *melw;        // [n_pieces][piece_taps] (zero padded)
+  const float *tw512;       // [16][16][2]: −i · W512^(i + 16 k2) at [k2][i]
+  const float *melw;        // [n_pieces][kPieceTaps] (zero padded)
   const int32_t *melinfo;   // [kMaxPieces] first FFT bin of the piece, then [kMaxBins] (first piece | pieces << 8) per bin
   const float *dct;         // [nceps][nbins]
   const float *lifter;      // [nceps]
@@ -69,6 +73,11 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_f32(float old, float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, 0xF, 0xF, false));
 }
+// permutations that give every lane a source: no `old` value to keep (and no register copy to set one up)
+template <int CTRL>
+__device__ __forceinline__ float dpp_perm(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true));
+}
 // Σ over the 16 lanes of a row, returned in every lane of the row.  The addends are integer-valued and the total stays
 // below 2^24, so the order of the additions does not matter.
 __device__ __forceinline__ float row_sum_exact(float v) {
@@ -83,7 +92,10 @@ __device__ __forceinline__ v2f splat(float x) { return (v2f){x, x}; }
 // a·b (complex): one packed multiply (operand halves picked by op_sel) and two fused multiply-adds
 __device__ __forceinline__ v2f cmul(v2f a, v2f b) {
   const v2f t = splat(a.y) * (v2f){b.y, b.x};                       // (a.y b.y, a.y b.x)
-  return (v2f){fmaf(a.x, b.x, -t.x), fmaf(a.x, b.y, t.y)};
+  float re = fmaf(a.x, b.x, -t.x);
+  const float im = fmaf(a.x, b.y, t.y);
+  asm("" : "+v"(re));   // keeps the two apart: paired into one v_pk_fma the compiler first builds (−t.x, t.y) with three more instructions
+  return (v2f){re, im};
 }
 // 4-point DFT in place (W4 = −i): a_k ← Σ_n a_n (−i)^(nk).  kZero3: a3 is known to be zero (samples beyond the window).
 template <bool kZero3 = false>
@@ -147,7 +159,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void mfcc_kernel(MfccParams
     s_tw512[k] = (v2f){p.tw512[2 * k], p.tw512[2 * k + 1]};
     s_wnd[k] = (v2f){p.window[2 * k], p.window[2 * k + 1]};
   }
-  for (int k = threadIdx.x; k < p.n_pieces * p.piece_taps; k += 64 * kWavesPerBlock) s_melw[k] = p.melw[k];
+  for (int k = threadIdx.x; k < p.n_pieces * kPieceTaps; k += 64 * kWavesPerBlock) s_melw[k] = p.melw[k];
   for (int k = threadIdx.x; k < p.nceps * p.nbins; k += 64 * kWavesPerBlock) s_dct[k] = p.dct[k];
   for (int k = threadIdx.x; k < kMaxPieces + kMaxBins; k += 64 * kWavesPerBlock) s_info[k] = p.melinfo[k];
   float *tile = s_tile[wave];
@@ -162,8 +174,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void mfcc_kernel(MfccParams
   const float lift_k = i < p.nceps ? p.lifter[i] : 0.0f;
   v2f *tq = (v2f *)tile + q * (16 * kRowPad);     // this row's transposition tile
   float *pq = tile + q * kPStride;                  // … power spectrum
-  float *partq = tile + kPartOff + q * kMaxPieces;  // … filterbank piece sums
-  float *melq = tile + kMelOff + q * kMaxBins;      // … log mel energies
+  float *partq = tile + kPartOff + q * kPartStride;  // … filterbank piece sums
+  float *melq = tile + kMelOff + q * kMelStride;     // … log mel energies
 
   // samples of frame f as packed pairs (x[2m] | x[2m+1] << 16), m = i + 16 j
   auto load_frame = [&](int f, unsigned (&raw)[kJ]) {
@@ -229,7 +241,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void mfcc_kernel(MfccParams
       float prev_e[kJ];
 #pragma unroll
       for (int j = 0; j < kJ; j++) {
-        const float carry = j == 0 ? a[0].x : dpp_f32<0x121>(0.0f, a[j > 0 ? j - 1 : 0].y);   // row_ror:1
+        const float up = a[j > 0 ? j - 1 : 0].y;
+        const float carry = j == 0 ? a[0].x : dpp_perm<0x121>(up);                            // row_ror:1
         prev_e[j] = dpp_f32<0x111>(carry, a[j].y);                                            // row_shr:1, lane 0 keeps `carry`
       }
 #pragma unroll
@@ -255,11 +268,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void mfcc_kernel(MfccParams
 #pragma unroll
     for (int k2 = 0; k2 < 16; k2++) {
       const v2f zk = a[k2], own = a[(16 - k2) & 15], far = a[15 - k2];
-      const float cx = dpp_f32<0x111>(own.x, dpp_f32<0x140>(0.0f, far.x));
-      const float cy = dpp_f32<0x111>(own.y, dpp_f32<0x140>(0.0f, far.y));
-      const v2f e = (v2f){zk.x + cx, zk.y - cy};
-      const v2f o = (v2f){zk.y + cy, cx - zk.x};
-      const v2f xk = e + cmul(tw512[16 * k2], o);
+      const float cx = dpp_f32<0x111>(own.x, dpp_perm<0x140>(far.x));
+      const float cy = dpp_f32<0x111>(own.y, dpp_perm<0x140>(far.y));
+      // 2E = (zk.x + cx, zk.y − cy), D = (zk.x − cx, zk.y + cy), 2O = −i·D: the table holds −i·w^k, so 2X = 2E + (−i w^k)·D
+      float ex = zk.x + cx, ey = zk.y - cy, dx = zk.x - cx, dy = zk.y + cy;
+      asm("" : "+v"(ex), "+v"(dx));   // (kept scalar: packed, the mixed signs cost three moves per pair)
+      const v2f xk = (v2f){ex, ey} + cmul(tw512[16 * k2], (v2f){dx, dy});
       float pw = 0.25f * fmaf(xk.y, xk.y, xk.x * xk.x);
       if (k2 == 0 && i == 0) pw = 0.25f * (xk.x * xk.x);      // Kaldi ComputePowerSpectrum: bin 0 = DC² (the Nyquist bin is never used)
       pq[16 * k2 + i] = pw;
@@ -269,10 +283,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void mfcc_kernel(MfccParams
     for (int r = 0; r < p.n_rounds; r++) {
       const int piece = 16 * r + i;
       const int pc = min(piece, p.n_pieces - 1);
-      const float *wv = s_melw + pc * p.piece_taps;
+      const float *wv = s_melw + pc * kPieceTaps;
       const float *pv = pq + s_info[pc];
       float acc = 0.0f;
-      for (int t = 0; t < p.piece_taps; t++) acc = fmaf(wv[t], pv[t], acc);
+#pragma unroll
+      for (int t = 0; t < kPieceTaps; t++) acc = fmaf(wv[t], pv[t], acc);
       if (piece < p.n_pieces) partq[piece] = acc;
     }
     WAVE_SYNC();
@@ -337,8 +352,9 @@ MFA_API int mfa_mfcc_configure(mfa_ctx *c, const mfa_mfcc_opts *o) {
       const double a256 = 2.0 * M_PI * (double)(i * k) / 256.0, a512 = 2.0 * M_PI * (double)(i + 16 * k) / 512.0;
       tw[2 * (16 * k + i)] = (float)cos(a256);
       tw[2 * (16 * k + i) + 1] = (float)(-sin(a256));
-      tw[512 + 2 * (16 * k + i)] = (float)cos(a512);
-      tw[512 + 2 * (16 * k + i) + 1] = (float)(-sin(a512));
+      // −i · W512^k = (Im w, −Re w) with w = (cos, −sin): the real-FFT step multiplies D = Z[k] − conj(Z[N−k]) by it
+      tw[512 + 2 * (16 * k + i)] = (float)(-sin(a512));
+      tw[512 + 2 * (16 * k + i) + 1] = (float)(-cos(a512));
     }
   // Kaldi MelBanks (float arithmetic as in mel-computations.cc)
   float nyquist = 0.5f * o->sample_frequency;
@@ -368,18 +384,14 @@ MFA_API int mfa_mfcc_configure(mfa_ctx *c, const mfa_mfcc_opts *o) {
     woff_of[bin] = (int32_t)melw.size();
     melw.insert(melw.end(), w.begin() + first, w.begin() + last + 1);
   }
-  // Filterbank plan: every triangle is cut into pieces of at most `taps` consecutive FFT bins; piece p is summed by lane
-  // p mod 16 of a row in round p / 16 (all pieces run `taps` multiply-adds: short ones are zero padded), the pieces of a
-  // bin are then added in ascending order.  `taps` is the value that needs the fewest multiply-adds per lane.
-  int best_taps = 0, best_cost = 1 << 30;
-  for (int taps = 4; taps <= 16; taps++) {
-    int np = 0, worst = 0;
-    for (int b = 0; b < nb; b++) { const int k = (len_of[b] + taps - 1) / taps; np += k; worst = std::max(worst, k); }
-    if (np > kMaxPieces || np * taps > kMaxMelW || worst > 255) continue;
-    const int cost = ((np + 15) / 16) * taps;
-    if (cost < best_cost) { best_cost = cost; best_taps = taps; }
+  // Filterbank plan: every triangle is cut into pieces of kPieceTaps consecutive FFT bins (the last one zero padded);
+  // piece p is summed by lane p mod 16 of a row in round p / 16, the pieces of a bin are then added in ascending order.
+  const int best_taps = kPieceTaps;
+  {
+    int np = 0;
+    for (int b = 0; b < nb; b++) np += (len_of[b] + best_taps - 1) / best_taps;
+    if (np > kMaxPieces) return c->fail("mel filterbank needs %d pieces of %d bins (kernel table holds %d)", np, best_taps, kMaxPieces);
   }
-  if (best_taps == 0) return c->fail("cannot lay %d mel bins out on the filterbank plan", nb);
   std::vector<float> piecew;
   std::vector<int32_t> melinfo(kMaxPieces + kMaxBins, 0);
   int n_pieces = 0, np_max = 1;
@@ -413,7 +425,7 @@ MFA_API int mfa_mfcc_configure(mfa_ctx *c, const mfa_mfcc_opts *o) {
   if (upload((void **)&c->d_twiddle, tw.data(), tw.size() * 4)) return -1;
   if (upload((void **)&c->d_melw, piecew.data(), piecew.size() * 4)) return -1;
   if (upload((void **)&c->d_melidx, melinfo.data(), melinfo.size() * 4)) return -1;
-  c->n_melw = n_pieces; c->mel_piece_taps = best_taps; c->mel_np_max = np_max;
+  c->n_melw = n_pieces; c->mel_np_max = np_max;
   if (upload((void **)&c->d_dct, dct.data(), dct.size() * 4)) return -1;
   if (upload((void **)&c->d_lifter, lifter.data(), lifter.size() * 4)) return -1;
   c->mfcc = *o;
@@ -438,7 +450,7 @@ MFA_API int mfa_mfcc_batch(mfa_ctx *c, const int16_t *d_pcm, const int64_t *d_sa
   p.snip_edges = c->mfcc.snip_edges; p.remove_dc = c->mfcc.remove_dc_offset; p.preemph = c->mfcc.preemphasis;
   p.window = c->d_window; p.tw256 = c->d_twiddle; p.tw512 = c->d_twiddle + 512;
   p.melw = c->d_melw; p.melinfo = c->d_melidx; p.dct = c->d_dct; p.lifter = c->d_lifter;
-  p.n_pieces = c->n_melw; p.piece_taps = c->mel_piece_taps; p.n_rounds = (c->n_melw + 15) / 16; p.np_max = c->mel_np_max;
+  p.n_pieces = c->n_melw; p.n_rounds = (c->n_melw + 15) / 16; p.np_max = c->mel_np_max;
   dim3 grid((max_frames + kFramesPerBlock - 1) / kFramesPerBlock, n_utt);
   KernelTimer kt(c, MFA_K_MFCC);
   if (c->win <= 32 * 13)
