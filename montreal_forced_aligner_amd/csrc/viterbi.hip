@@ -159,6 +159,101 @@ __device__ __forceinline__ double cand_cost(float w, double cost, float ll, floa
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
   } while (0)
 
+// ReachedFinal / best final token, traceback, outputs (transition-ids, words, likelihood) of one utterance whose frame
+// loop has ended with `n` tokens in (c_state, c_cost) after `t` frames.  One wavefront; shared by the frame-loop kernels
+// and by viterbi_finish_kernel.
+template <class StateP, class CostP>
+__device__ __forceinline__ void finalize_utterance(const VitParams &p, int utt, int lane, int status, int t, int T, int n,
+                                                   StateP c_state, CostP c_cost, const float *final_w, const u64 *bp,
+                                                   const u32 *tokoff, int64_t f0, int64_t ab_, const float *a_w,
+                                                   const int32_t *a_col, const float *ll, int P) {
+  // ---------------- ReachedFinal / best final token (first in list order on ties)
+  int32_t out_status = status;
+  double bestc = INFINITY; u32 bpos = kEmpty;
+  if (status == ST_OK) {
+    if (t < T || n == 0) out_status = ST_FAILED;
+    else {
+      for (int c0 = 0; c0 < n; c0 += 64) {
+        int i = c0 + lane;
+        double tc = INFINITY;
+        if (i < n) {
+          float fw = final_w[c_state[i]];
+          if (fw != INFINITY) tc = c_cost[i] + (double)fw;
+        }
+        double m = wave_min_f64(tc);
+        if (m < bestc) {
+          const u64 hit = __ballot(i < n && tc == m);
+          bpos = (u32)c0 + (u32)__ffsll((long long)hit) - 1u;
+          bestc = m;
+        }
+      }
+      if (bpos == kEmpty) out_status = ST_FAILED;
+    }
+  }
+  if (out_status != ST_OK) {
+    if (lane == 0) {
+      // a first-pass failure stays pending for the retry pass; other codes are final
+      p.status[utt] = (p.pass == 0 && out_status == ST_FAILED) ? ST_PENDING
+                      : (p.grow && out_status == ST_TOKEN_OVERFLOW) ? ST_GROW : out_status;
+      p.n_words[utt] = 0; p.like[utt] = 0.0f;
+    }
+    return;
+  }
+
+  // ---------------- traceback (one lane chases the pointers), arc index per frame parked in ali[]
+  int32_t *ali = p.ali + f0;
+  const u32 fstate = c_state[bpos];
+  if (lane == 0) {
+    u32 pos = bpos;
+    for (int tt = T - 1; tt >= 0; tt--) {
+      u64 rec = bp[(u64)tokoff[tt] + pos];
+      ali[tt] = (int32_t)(rec >> 32);
+      pos = (u32)(rec & 0xFFFFFFFFu);
+    }
+  }
+  __threadfence_block();
+  WSYNC();
+  // ---------------- outputs: transition-ids, words (ordered compaction), likelihood (Kaldi's float accumulation)
+  const int32_t *a_il = p.g.d_arc_ilabel + ab_, *a_ol = p.g.d_arc_olabel + ab_;
+  int32_t *words = p.words + f0;
+  float *flike = p.frame_like ? p.frame_like + f0 : nullptr;
+  u32 nw_out = 0;
+  double cost = 0.0; float w1 = 0.0f, w2 = 0.0f;
+  const float inv_scale = -1.0f / p.scale;
+  for (int c0 = 0; c0 < T; c0 += 64) {
+    const int tt = c0 + lane;
+    int arc = tt < T ? ali[tt] : 0;
+    int il = 0, ol = 0; float w = 0.0f, ac = 0.0f;
+    if (tt < T) {
+      il = a_il[arc]; ol = a_ol[arc]; w = a_w[arc];
+      ac = -(p.scale * ll[(size_t)tt * P + a_col[arc]]);
+    }
+    // words in path order
+    const u64 mask = __ballot(ol != 0);
+    if (ol != 0) words[nw_out + __popcll(mask & ((1ull << lane) - 1ull))] = ol;
+    nw_out += (u32)__popcll(mask);
+    // cost chain, sequential in frame order (every lane runs the same chain on broadcast operands)
+    float my_fl = 0.0f;
+    const int lim = min(64, T - c0);
+    for (int j = 0; j < lim; j++) {
+      float wj = __shfl(w, j), acj = __shfl(ac, j);
+      double nc = ((double)wj + cost) + (double)acj;
+      float tot = (float)(nc - cost);
+      float acost = tot - wj;
+      w1 += wj; w2 += acost;
+      cost = nc;
+      if (lane == j) my_fl = acost * inv_scale;
+    }
+    if (tt < T) { ali[tt] = il; if (flike) flike[tt] = my_fl; }
+  }
+  if (lane == 0) {
+    w1 += final_w[fstate];
+    p.like[utt] = -(w1 + w2) / p.scale;
+    p.n_words[utt] = (int32_t)nw_out;
+    p.status[utt] = p.pass == 0 ? ST_OK : ST_RETRIED;
+  }
+}
+
 constexpr int kArcCache = 8;  // arcs per token kept in registers during expansion (deeper states take a slow tail loop)
 
 // kListsInLds: the two token lists (state, cost) live in LDS (fast path) or, for graphs/beams whose tables would not
@@ -736,91 +831,371 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   }
   if (p.pass == 0 && lane == 0) p.w_hash[utt] = H;
 
-  // ---------------- ReachedFinal / best final token (first in list order on ties)
-  int32_t out_status = status;
-  double bestc = INFINITY; u32 bpos = kEmpty;
-  if (status == ST_OK) {
-    if (t < T || n == 0) out_status = ST_FAILED;
-    else {
-      for (int c0 = 0; c0 < n; c0 += 64) {
-        int i = c0 + lane;
-        double tc = INFINITY;
-        if (i < n) {
-          float fw = final_w[c_state[i]];
-          if (fw != INFINITY) tc = c_cost[i] + (double)fw;
+  finalize_utterance(p, utt, lane, status, t, T, n, c_state, c_cost, final_w, bp, tokoff, f0, ab_, a_w, a_col, ll, P);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// First tier of the windowed first-beam pass (mfa_align_features_batch), written for what that tier actually sees: at
+// most 64 live tokens (one per lane) and at most 64·kRounds candidates per frame (one per lane and round).  Same decoder,
+// same decisions, bit for bit — but straight-line wavefront code: the general kernel above carries a token-chunk loop, an
+// arc cache of eight per lane, an HBM candidate stash and the retry/grow bookkeeping through every frame (6 000
+// instructions, 139 spilled scalars), this one a third of that.  Anything outside its envelope (more tokens, more
+// candidates, a state of more than 64 arcs) flags the utterance for the large tier, which redoes the window from the
+// state parked at its start — exactly the hand-over the general kernel's first tier uses.  An utterance that reaches its
+// last frame is parked with done = 2; viterbi_finish_kernel then does ReachedFinal, traceback and outputs.
+//   GetCutoff's min_active rule: the (min_active + 1 − k)-th smallest cost outside the beam by ballot quickselect (a
+//   handful of compare+ballot steps) instead of ranking every token against every other.
+constexpr int kSmallN = 64;
+template <int kRounds>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void viterbi_small_kernel(VitParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int N = kSmallN, C = 64 * kRounds;
+  constexpr u32 HM = 256u, hmask = HM - 1u;
+  constexpr int hshift = 24;
+  const int lane = threadIdx.x;
+  const int utt = blockIdx.x;
+  const VitState vs0 = p.w_vstate[utt];
+  const bool resume = p.t_begin > 0;
+  if (resume && vs0.done) return;                  // finished (or failed, or waiting for the finish kernel)
+  const int64_t so = p.g.d_state_off[utt];
+  const int S = (int)(p.g.d_state_off[utt + 1] - so);
+  const int64_t ab_ = p.g.d_arc_base[utt];
+  const int32_t *arc_off = p.g.d_arc_off + so + utt;
+  const uint4 *a_rec = p.w_arcnext + ab_;
+  const int64_t f0 = p.frame_off[utt];
+  const int T = (int)(p.frame_off[utt + 1] - f0);
+  const float *ll = p.ll + p.ll_off[utt];
+  const int P = p.ll_cols[utt];
+  const int NP = p.npark;
+  u32 *park_state = p.w_state + (size_t)utt * 2 * NP;
+  u32 *park_an = p.w_state + (size_t)p.g.n_utt * 2 * NP + (size_t)utt * 2 * NP;
+  double *park_cost = p.w_cost + (size_t)utt * 2 * NP;
+  auto hand_over = [&]() { if (lane == 0) p.w_redo[utt] = 1u; };   // nothing parked has been touched: the large tier redoes the window
+
+  int n = 1, t = 0;
+  u32 H = 1000u;
+  u64 bp_used = 0;
+  const int start = p.g.d_start[utt];
+  if (S <= 0 || start < 0 || start >= S || T <= 0) { hand_over(); return; }   // (the general kernel reports the failure)
+  if (resume) {
+    n = vs0.n; H = vs0.H; bp_used = vs0.bp_used; t = p.t_begin;
+    if (n > N || n <= 0) { hand_over(); return; }
+  }
+
+  // ---- LDS carve (as the general kernel's, with its token capacity fixed at 64)
+  u64 *s_cost = (u64 *)smem;                 // [N]
+  double *l_cost0 = (double *)(s_cost + N);  // [2][N]
+  u32 *hmap = (u32 *)(l_cost0 + 2 * N);      // [HM]
+  u32 *s_state = hmap + HM;                  // [N]
+  u32 *s_F = s_state + N;
+  u32 *s_W = s_F + N;
+  u32 *t_cbase = s_W + N;
+  u32 *s_an = t_cbase + N;
+  u32 *s_bucket = s_an + N;
+  u32 *l_state0 = s_bucket + N;              // [2][N]
+  u32 *l_an0 = l_state0 + 2 * N;             // [2][N]
+  u32 *cntord = l_an0 + 2 * N;               // [C]: owner map of the candidate ordinals, then bucket sizes → exclusive sums
+  float *ll_row = (float *)(cntord + C);     // [llcap]
+  u32 *ctr = (u32 *)(ll_row + p.llcap);      // [2]
+
+  u64 *bp = p.w_bp + (size_t)f0 * p.bpf;
+  const u64 bp_cap = (u64)T * (u64)p.bpf;
+  u32 *tokoff = p.w_tokoff + f0 + utt;
+
+  for (u32 i = lane; i < HM; i += 64) hmap[i] = kEmpty;
+  for (int i = lane; i < C; i += 64) cntord[i] = 0;
+  if (lane == 0) ctr[0] = 0;
+  int cur = 0;
+  if (!resume) {
+    if (lane == 0) { l_state0[0] = (u32)start; l_cost0[0] = 0.0; l_an0[0] = ((u32)arc_off[start] << 7) | (u32)(arc_off[start + 1] - arc_off[start]); }
+  } else if (lane < n) {
+    l_state0[lane] = park_state[lane]; l_an0[lane] = park_an[lane]; l_cost0[lane] = park_cost[lane];
+  }
+  const int t_stop = min(T, p.t_end);
+  constexpr int kPre = 8;
+  const bool row_cached = P <= p.llcap && P <= 64 * kPre;
+  float pre[kPre];
+#pragma unroll
+  for (int r = 0; r < kPre; r++) pre[r] = (row_cached && t < T && lane + 64 * r < P) ? ll[(size_t)t * P + lane + 64 * r] : 0.0f;
+  WSYNC();
+
+  bool overflow = false;
+  for (; t < t_stop; t++) {
+    const float *llt = ll + (size_t)t * P;
+    u32 *n_state = l_state0 + (cur ^ 1) * N;
+    u32 *c_an = l_an0 + cur * N, *n_an = l_an0 + (cur ^ 1) * N;
+    double *c_cost = l_cost0 + cur * N, *n_cost = l_cost0 + (cur ^ 1) * N;
+    auto score = [&](int col) -> float {
+      float v = ll_row[row_cached ? col : 0];
+      if (!row_cached) v = *(const volatile float *)&llt[col];
+      return v;
+    };
+    // ---------------- GetCutoff
+    const double cst = lane < n ? c_cost[lane] : INFINITY;
+    const u32 an = lane < n ? c_an[lane] : 0u;
+    const double best = wave_min_f64(cst);
+    const u32 best_i = (u32)__ffsll((long long)__ballot(lane < n && cst == best)) - 1u;
+    double wcut = INFINITY; float abeam = INFINITY;
+    if (n > kMinActive) {
+      const double beam_cut = best + p.beam;
+      const u64 inside = __ballot(lane < n && cst <= beam_cut);
+      const int kle = __popcll(inside);
+      if (kle > kMinActive) { wcut = beam_cut; abeam = p.beam; }
+      else {
+        // the (min_active + 1 − kle)-th smallest cost outside the beam: ballot quickselect (ties resolved by counting < and <=)
+        u64 A = __ballot(lane < n) & ~inside;
+        int r = kMinActive + 1 - kle;
+        double v = INFINITY;
+        while (A != 0ull) {
+          const int pl = __ffsll((long long)A) - 1;
+          const double pv = readlane_f64(cst, pl);
+          const u64 lt = __ballot(cst < pv) & A, le = __ballot(cst <= pv) & A;
+          const int clt = __popcll(lt), cle = __popcll(le);
+          if (r <= clt) A = lt;
+          else if (r <= cle) { v = pv; break; }
+          else { A &= ~le; r -= cle; }
         }
-        double m = wave_min_f64(tc);
-        if (m < bestc) {
-          const u64 hit = __ballot(i < n && tc == m);
-          bpos = (u32)c0 + (u32)__ffsll((long long)hit) - 1u;
-          bestc = m;
+        wcut = v;
+        abeam = (float)(v - best + (double)kBeamDelta);
+      }
+    }
+    { u32 want = (u32)((float)n * kHashRatio); if (want > H) H = want; }
+    // ---------------- candidate layout: ordinal base per token, owner of every ordinal
+    const bool act = lane < n && cst < wcut;
+    const u32 narc = act ? (an & 127u) : 0u;
+    const u32 narc_incl = incl_scan_sum(narc);
+    const u32 cb = narc_incl - narc;
+    const u32 ctot = (u32)__builtin_amdgcn_readlane((int)narc_incl, 63);
+    if (__any(narc > (u32)kMaxArcsPerState) || ctot > (u32)C) { overflow = true; break; }
+    if (lane < n) t_cbase[lane] = cb;
+    if (narc > 0u) cntord[cb] = (u32)lane + 1u;       // head of each token's candidate run (cntord is all zero between frames)
+    WSYNC();
+    const int rounds = (int)((ctot + 63u) >> 6);
+    // ---------------- arc gather (all rounds' loads in flight together)
+    u32 tokv[kRounds], kv[kRounds], nx[kRounds], nan_[kRounds]; int colv[kRounds]; float wv[kRounds]; double tcost[kRounds];
+    {
+      u32 carry = 0;
+#pragma unroll
+      for (int r = 0; r < kRounds; r++) {
+        tokv[r] = 0; kv[r] = 0; nx[r] = 0; nan_[r] = 0; colv[r] = 0; wv[r] = 0.0f; tcost[r] = INFINITY;
+        if (r < rounds) {   // uniform
+          const u32 c = (u32)lane + 64u * r;
+          const u32 own = max(incl_scan_max(cntord[c]), carry);
+          carry = (u32)__builtin_amdgcn_readlane((int)own, 63);
+          const bool valid = c < ctot;
+          const u32 tok = valid ? own - 1u : 0u;
+          tokv[r] = tok;
+          tcost[r] = valid ? c_cost[tok] : INFINITY;
+          const u32 tan = c_an[tok];
+          kv[r] = valid ? c - t_cbase[tok] : 0u;
+          if (valid) { const uint4 rec = a_rec[(tan >> 7) + kv[r]]; nx[r] = rec.x; nan_[r] = rec.y; colv[r] = (int)rec.z; wv[r] = __uint_as_float(rec.w); }
         }
       }
-      if (bpos == kEmpty) out_status = ST_FAILED;
     }
+    WSYNC();
+    if (narc > 0u) cntord[cb] = 0u;                   // owner map read by every round: back to zero for the ordering pass
+    if (row_cached) {
+#pragma unroll
+      for (int r = 0; r < kPre; r++) if (lane + 64 * r < P) ll_row[lane + 64 * r] = pre[r];
+      WSYNC();
+    }
+    double nw[kRounds];
+#pragma unroll
+    for (int r = 0; r < kRounds; r++)
+      nw[r] = ((u32)lane + 64u * r < ctot) ? cand_cost(wv[r], tcost[r], score(colv[r]), p.scale) : INFINITY;
+    // ---------------- running cutoff: seed from the best token's candidates, then an exclusive prefix-min in ordinal order
+    double run = INFINITY;
+#pragma unroll
+    for (int r = 0; r < kRounds; r++)
+      if (r < rounds) run = fmin(run, wave_min_f64(((u32)lane + 64u * r < ctot && tokv[r] == best_i) ? nw[r] : INFINITY));
+    bool created[kRounds];
+#pragma unroll
+    for (int r = 0; r < kRounds; r++) {
+      created[r] = false;
+      if (r < rounds) {
+        const double m_incl = incl_scan_min(nw[r]);
+        const double local = fmin(run, shift_in_min(m_incl));
+        run = fmin(run, readlane_f64(m_incl, 63));
+        created[r] = ((u32)lane + 64u * r < ctot) && nw[r] < local + (double)abeam;
+      }
+    }
+    // ---------------- find-or-insert the destination's slot, lower its cost / first creator, settle the winner
+    u32 sl[kRounds], hk[kRounds];
+    bool pend[kRounds];
+    bool any_pend = false;
+#pragma unroll
+    for (int r = 0; r < kRounds; r++) { sl[r] = kEmpty; pend[r] = created[r]; hk[r] = (nx[r] * 2654435761u) >> hshift; any_pend |= pend[r]; }
+    while (__any(any_pend)) {
+      any_pend = false;
+#pragma unroll
+      for (int r = 0; r < kRounds; r++) {
+        if (pend[r]) {
+          const u32 v = hmap[hk[r]];
+          if (v == kEmpty) {
+            if (atomicCAS(&hmap[hk[r]], kEmpty, kClaim) == kEmpty) {
+              const u32 my = atomicAdd(&ctr[0], 1u);
+              if (my < (u32)N) {
+                s_state[my] = nx[r]; s_an[my] = nan_[r]; s_cost[my] = kKeyInf; s_F[my] = kEmpty; s_W[my] = kEmpty; s_bucket[my] = hk[r];
+                hmap[hk[r]] = my;
+                sl[r] = my;
+              } else {
+                hmap[hk[r]] = kOver;
+              }
+              pend[r] = false;
+            }
+          } else if (v == kOver) {
+            pend[r] = false;
+          } else if (v != kClaim) {
+            if (s_state[v] == nx[r]) { sl[r] = v; pend[r] = false; }
+            else hk[r] = (hk[r] + 1u) & hmask;
+          }
+        }
+        any_pend |= pend[r];
+      }
+      WSYNC();
+      if (ctr[0] > (u32)N) break;
+    }
+    u32 cidx[kRounds];
+#pragma unroll
+    for (int r = 0; r < kRounds; r++) {
+      cidx[r] = (tokv[r] << kArcBits) | kv[r];
+      if (sl[r] != kEmpty) { atomicMin(&s_cost[sl[r]], dkey(nw[r])); atomicMin(&s_F[sl[r]], cidx[r]); }
+    }
+    WSYNC();
+#pragma unroll
+    for (int r = 0; r < kRounds; r++)
+      if (sl[r] != kEmpty && dkey(nw[r]) == s_cost[sl[r]]) atomicMin(&s_W[sl[r]], cidx[r]);
+    if (row_cached && t + 1 < t_stop) {
+      const float *nx_row = llt + P;
+#pragma unroll
+      for (int r = 0; r < kPre; r++) if (lane + 64 * r < P) pre[r] = nx_row[lane + 64 * r];
+    }
+    WSYNC();
+    const u32 nslots = ctr[0];
+    if (nslots > (u32)N || bp_used + nslots > bp_cap) { overflow = true; break; }
+    if (nslots == 0) { n = 0; t++; break; }            // everything pruned: no surviving token
+    // ---------------- Kaldi list order of the new tokens (one slot per lane)
+    u32 aux = 0;
+    if ((u32)lane < nslots) {
+      const u32 d = s_state[lane], Fj = s_F[lane];
+      u32 Fb = Fj, nb = 1, rank = 0;
+      if ((u32)S > H) {
+        nb = 0;
+        for (u32 m = d % H; m < (u32)S; m += H) {
+          u32 h = (m * 2654435761u) >> hshift, sm = kEmpty;
+          for (;;) {
+            const u32 v = hmap[h];
+            if (v == kEmpty) break;
+            if (v < (u32)N && s_state[v] == m) { sm = v; break; }
+            h = (h + 1u) & hmask;
+          }
+          if (sm < (u32)N) {
+            const u32 Fm = s_F[sm];
+            nb++;
+            if (Fm < Fj) rank++;
+            if (Fm < Fb) Fb = Fm;
+          }
+        }
+      }
+      const u32 ord_b = t_cbase[Fb >> kArcBits] + (Fb & (kMaxArcsPerState - 1));
+      aux = (rank << 24) | ord_b;
+      if (Fb == Fj) cntord[ord_b] = nb;
+    }
+    WSYNC();
+    {
+      u32 carry = 0;
+#pragma unroll
+      for (int r = 0; r < kRounds; r++) {
+        if (r < rounds) {
+          const u32 o = (u32)lane + 64u * r;
+          const u32 v = cntord[o];
+          const u32 inc = incl_scan_sum(v);
+          if (v != 0) cntord[o] = carry + inc - v;
+          carry += (u32)__builtin_amdgcn_readlane((int)inc, 63);
+        }
+      }
+    }
+    WSYNC();
+    // ---------------- write the new list + back-pointers, reset the tables
+    bool broken = false;
+    if ((u32)lane < nslots) {
+      const u32 pos = cntord[aux & 0xFFFFFFu] + (aux >> 24);
+      const u32 d = s_state[lane], W = s_W[lane];
+      const u32 ppos = W >> kArcBits, k = W & (kMaxArcsPerState - 1);
+      if (pos >= nslots || ppos >= (u32)n || d >= (u32)S) broken = true;
+      else {
+        const u32 arc = (c_an[ppos] >> 7) + k;
+        n_state[pos] = d;
+        n_an[pos] = s_an[lane];
+        n_cost[pos] = dunkey(s_cost[lane]);
+        bp[bp_used + pos] = ((u64)arc << 32) | (u64)ppos;
+      }
+    }
+    if (__any(broken)) { overflow = true; break; }     // (cannot happen; the large tier would report ST_INTERNAL)
+    WSYNC();
+    if ((u32)lane < nslots) { hmap[s_bucket[lane]] = kEmpty; cntord[aux & 0xFFFFFFu] = 0; }
+    if (lane == 0) { tokoff[t] = (u32)bp_used; ctr[0] = 0; }
+    bp_used += nslots;
+    n = (int)nslots;
+    cur ^= 1;
+    WSYNC();
   }
-  if (out_status != ST_OK) {
+  if (overflow) { hand_over(); return; }
+  __threadfence_block();
+  u32 *c_state = l_state0 + cur * N;
+  double *c_costp = l_cost0 + cur * N;
+  const u32 *c_anp = l_an0 + cur * N;
+  if (n == 0) {   // no surviving token: pending for the retry pass, as the general kernel's finalisation reports it
     if (lane == 0) {
-      // a first-pass failure stays pending for the retry pass; other codes are final
-      p.status[utt] = (p.pass == 0 && out_status == ST_FAILED) ? ST_PENDING
-                      : (p.grow && out_status == ST_TOKEN_OVERFLOW) ? ST_GROW : out_status;
-      p.n_words[utt] = 0; p.like[utt] = 0.0f;
+      VitState vs; vs.n = 0; vs.cur = 0; vs.done = 1; vs.pad0 = 0; vs.H = H; vs.pad1 = 0; vs.bp_used = bp_used;
+      p.w_vstate[utt] = vs;
+      p.w_hash[utt] = H;
+      p.status[utt] = ST_PENDING; p.n_words[utt] = 0; p.like[utt] = 0.0f;
     }
     return;
   }
+  // ---------------- park the list (window end, or last frame: done = 2 hands the utterance to viterbi_finish_kernel)
+  u32 dmax = 0, dmin_inv = 0;
+  if (lane < n) {
+    const u32 s_ = c_state[lane];
+    park_state[lane] = s_; park_an[lane] = c_anp[lane]; park_cost[lane] = c_costp[lane];
+    if (p.state_depth && t < T) {
+      const int32_t *sd = p.state_depth + 2 * (so + (int64_t)s_);
+      dmax = (u32)sd[0]; dmin_inv = ~(u32)sd[1];
+    }
+  }
+  dmax = wave_max_u32(dmax);
+  dmin_inv = wave_max_u32(dmin_inv);
+  if (lane == 0) {
+    VitState vs;
+    vs.n = n; vs.cur = 0; vs.done = t < T ? 0 : 2; vs.pad0 = 0; vs.H = H; vs.pad1 = 0; vs.bp_used = bp_used;
+    p.w_vstate[utt] = vs;
+    if (t >= T) p.w_hash[utt] = H;
+    if (p.band && t < T) {
+      const long long hi = (long long)dmax + (long long)p.next_window - 1;
+      p.band[2 * utt] = p.state_depth ? (int32_t)~dmin_inv : 0;
+      p.band[2 * utt + 1] = p.state_depth ? (int32_t)min(hi, (long long)INT32_MAX) : INT32_MAX;
+    }
+  }
+}
 
-  // ---------------- traceback (one lane chases the pointers), arc index per frame parked in ali[]
-  int32_t *ali = p.ali + f0;
-  const u32 fstate = c_state[bpos];
-  if (lane == 0) {
-    u32 pos = bpos;
-    for (int tt = T - 1; tt >= 0; tt--) {
-      u64 rec = bp[(u64)tokoff[tt] + pos];
-      ali[tt] = (int32_t)(rec >> 32);
-      pos = (u32)(rec & 0xFFFFFFFFu);
-    }
-  }
-  __threadfence_block();
-  WSYNC();
-  // ---------------- outputs: transition-ids, words (ordered compaction), likelihood (Kaldi's float accumulation)
-  const int32_t *a_il = p.g.d_arc_ilabel + ab_, *a_ol = p.g.d_arc_olabel + ab_;
-  int32_t *words = p.words + f0;
-  float *flike = p.frame_like ? p.frame_like + f0 : nullptr;
-  u32 nw_out = 0;
-  double cost = 0.0; float w1 = 0.0f, w2 = 0.0f;
-  const float inv_scale = -1.0f / p.scale;
-  for (int c0 = 0; c0 < T; c0 += 64) {
-    const int tt = c0 + lane;
-    int arc = tt < T ? ali[tt] : 0;
-    int il = 0, ol = 0; float w = 0.0f, ac = 0.0f;
-    if (tt < T) {
-      il = a_il[arc]; ol = a_ol[arc]; w = a_w[arc];
-      ac = -(p.scale * ll[(size_t)tt * P + a_col[arc]]);
-    }
-    // words in path order
-    const u64 mask = __ballot(ol != 0);
-    if (ol != 0) words[nw_out + __popcll(mask & ((1ull << lane) - 1ull))] = ol;
-    nw_out += (u32)__popcll(mask);
-    // cost chain, sequential in frame order (every lane runs the same chain on broadcast operands)
-    float my_fl = 0.0f;
-    const int lim = min(64, T - c0);
-    for (int j = 0; j < lim; j++) {
-      float wj = __shfl(w, j), acj = __shfl(ac, j);
-      double nc = ((double)wj + cost) + (double)acj;
-      float tot = (float)(nc - cost);
-      float acost = tot - wj;
-      w1 += wj; w2 += acost;
-      cost = nc;
-      if (lane == j) my_fl = acost * inv_scale;
-    }
-    if (tt < T) { ali[tt] = il; if (flike) flike[tt] = my_fl; }
-  }
-  if (lane == 0) {
-    w1 += final_w[fstate];
-    p.like[utt] = -(w1 + w2) / p.scale;
-    p.n_words[utt] = (int32_t)nw_out;
-    p.status[utt] = p.pass == 0 ? ST_OK : ST_RETRIED;
-  }
+// ReachedFinal, traceback and outputs for the utterances viterbi_small_kernel decoded to their last frame (done = 2).
+__global__ __launch_bounds__(64) void viterbi_finish_kernel(VitParams p) {
+  const int lane = threadIdx.x;
+  const int utt = blockIdx.x;
+  const VitState vs = p.w_vstate[utt];
+  if (vs.done != 2) return;
+  const int64_t so = p.g.d_state_off[utt];
+  const int64_t ab_ = p.g.d_arc_base[utt];
+  const int64_t f0 = p.frame_off[utt];
+  const int T = (int)(p.frame_off[utt + 1] - f0);
+  const int NP = p.npark;
+  const u32 *c_state = p.w_state + (size_t)utt * 2 * NP;
+  const double *c_cost = p.w_cost + (size_t)utt * 2 * NP;
+  if (lane == 0) { VitState d = vs; d.done = 1; p.w_vstate[utt] = d; }
+  finalize_utterance(p, utt, lane, ST_OK, T, T, vs.n, c_state, c_cost, p.g.d_final + so, p.w_bp + (size_t)f0 * p.bpf,
+                     p.w_tokoff + f0 + utt, f0, ab_, p.g.d_arc_weight + ab_, p.g.d_arc_col + ab_, p.ll + p.ll_off[utt],
+                     p.ll_cols[utt]);
 }
 
 // Build the retry list: utterances left pending by the first pass.
@@ -1046,6 +1421,11 @@ int align_impl(mfa_ctx *c, const mfa_graph_batch *g, const float *d_loglikes, co
       if (lists_in_lds) hipLaunchKernelGGL(viterbi_kernel<true>, dim3(n_utt), dim3(64), lds, c->stream, p);
       else hipLaunchKernelGGL(viterbi_kernel<false>, dim3(n_utt), dim3(64), lds, c->stream, p);
     };
+    // first tier of the windowed pass: the dedicated 64-token kernel (MFA_VIT_LEAN=0: the general kernel as first tier)
+    constexpr int kSmallRounds = 3;
+    const size_t lds_small = (size_t)kSmallN * (8 + 16 + 6 * 4 + 8 + 8) + 256 * 4 + (size_t)64 * kSmallRounds * 4 + (size_t)kLlCap * 4 + 16;
+    bool lean = lazy && L.N2 > 0 && lists_in_lds && L.code == 0 && L.N == kSmallN;
+    { const char *e = getenv("MFA_VIT_LEAN"); if (e && e[0] == '0') lean = false; }
     if (!lazy) {
       launch_decoder();
       MFA_DEBUG_POINT(c, "decoded pass=%d code=%d N=%d C=%d lds=%zu in_lds=%d", ps, L.code, L.N, L.C, lds, (int)lists_in_lds);
@@ -1065,7 +1445,12 @@ int align_impl(mfa_ctx *c, const mfa_graph_batch *g, const float *d_loglikes, co
         p.t_begin = t0; p.t_end = t0 + K;
         if (L.N2 > 0 && lists_in_lds) {
           p.redo_mode = 1;
-          launch_decoder();
+          if (lean) {
+            KernelTimer kt1(c, MFA_K_VITERBI);
+            hipLaunchKernelGGL(viterbi_small_kernel<kSmallRounds>, dim3(n_utt), dim3(64), lds_small, c->stream, p);
+          } else {
+            launch_decoder();
+          }
           p2.windowed = 1; p2.next_window = K; p2.state_depth = p.state_depth; p2.band = p.band;
           p2.t_begin = t0; p2.t_end = t0 + K; p2.redo_mode = 2; p2.npark = p.npark; p2.grow = L.grow;
           p2.utt_list = p.utt_list; p2.n_list = p.n_list;
@@ -1077,6 +1462,10 @@ int align_impl(mfa_ctx *c, const mfa_graph_batch *g, const float *d_loglikes, co
           launch_decoder();
         }
         MFA_DEBUG_POINT(c, "decoded window t0=%d K=%d pass=%d code=%d N=%d C=%d lds=%zu in_lds=%d", t0, K, ps, L.code, L.N, L.C, lds, (int)lists_in_lds);
+      }
+      if (lean) {   // utterances the first tier decoded to their last frame: ReachedFinal, traceback, outputs
+        KernelTimer kt3(c, MFA_K_VITERBI);
+        hipLaunchKernelGGL(viterbi_finish_kernel, dim3(n_utt), dim3(64), 0, c->stream, p);
       }
     }
     MFA_HIP_CHECK(c, hipGetLastError());
