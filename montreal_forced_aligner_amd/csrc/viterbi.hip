@@ -895,8 +895,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
   u32 *l_state0 = s_bucket + N;              // [2][N]
   u32 *l_an0 = l_state0 + 2 * N;             // [2][N]
   u32 *cntord = l_an0 + 2 * N;               // [C]: owner map of the candidate ordinals, then bucket sizes → exclusive sums
-  float *ll_row = (float *)(cntord + C);     // [llcap]
-  u32 *ctr = (u32 *)(ll_row + p.llcap);      // [2]
+  u32 *ctr = cntord + C;                     // [2]
+  // (no staged score row: a candidate reads its score straight from L2 — measured faster than the general kernel's LDS
+  //  row cache here, and 2 KB less LDS per wavefront leaves room for a scoring workgroup next to sixteen of these)
 
   u64 *bp = p.w_bp + (size_t)f0 * p.bpf;
   const u64 bp_cap = (u64)T * (u64)p.bpf;
@@ -912,11 +913,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     l_state0[lane] = park_state[lane]; l_an0[lane] = park_an[lane]; l_cost0[lane] = park_cost[lane];
   }
   const int t_stop = min(T, p.t_end);
-  constexpr int kPre = 8;
-  const bool row_cached = P <= p.llcap && P <= 64 * kPre;
-  float pre[kPre];
-#pragma unroll
-  for (int r = 0; r < kPre; r++) pre[r] = (row_cached && t < T && lane + 64 * r < P) ? ll[(size_t)t * P + lane + 64 * r] : 0.0f;
   WSYNC();
 
   bool overflow = false;
@@ -925,11 +921,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     u32 *n_state = l_state0 + (cur ^ 1) * N;
     u32 *c_an = l_an0 + cur * N, *n_an = l_an0 + (cur ^ 1) * N;
     double *c_cost = l_cost0 + cur * N, *n_cost = l_cost0 + (cur ^ 1) * N;
-    auto score = [&](int col) -> float {
-      float v = ll_row[row_cached ? col : 0];
-      if (!row_cached) v = *(const volatile float *)&llt[col];
-      return v;
-    };
     // ---------------- GetCutoff
     const double cst = lane < n ? c_cost[lane] : INFINITY;
     const u32 an = lane < n ? c_an[lane] : 0u;
@@ -994,15 +985,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     }
     WSYNC();
     if (narc > 0u) cntord[cb] = 0u;                   // owner map read by every round: back to zero for the ordering pass
-    if (row_cached) {
-#pragma unroll
-      for (int r = 0; r < kPre; r++) if (lane + 64 * r < P) ll_row[lane + 64 * r] = pre[r];
-      WSYNC();
-    }
     double nw[kRounds];
 #pragma unroll
     for (int r = 0; r < kRounds; r++)
-      nw[r] = ((u32)lane + 64u * r < ctot) ? cand_cost(wv[r], tcost[r], score(colv[r]), p.scale) : INFINITY;
+      nw[r] = ((u32)lane + 64u * r < ctot) ? cand_cost(wv[r], tcost[r], llt[colv[r]], p.scale) : INFINITY;
     // ---------------- running cutoff: seed from the best token's candidates, then an exclusive prefix-min in ordinal order
     double run = INFINITY;
 #pragma unroll
@@ -1065,11 +1051,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 #pragma unroll
     for (int r = 0; r < kRounds; r++)
       if (sl[r] != kEmpty && dkey(nw[r]) == s_cost[sl[r]]) atomicMin(&s_W[sl[r]], cidx[r]);
-    if (row_cached && t + 1 < t_stop) {
-      const float *nx_row = llt + P;
-#pragma unroll
-      for (int r = 0; r < kPre; r++) if (lane + 64 * r < P) pre[r] = nx_row[lane + 64 * r];
-    }
     WSYNC();
     const u32 nslots = ctr[0];
     if (nslots > (u32)N || bp_used + nslots > bp_cap) { overflow = true; break; }
@@ -1423,7 +1404,7 @@ int align_impl(mfa_ctx *c, const mfa_graph_batch *g, const float *d_loglikes, co
     };
     // first tier of the windowed pass: the dedicated 64-token kernel (MFA_VIT_LEAN=0: the general kernel as first tier)
     constexpr int kSmallRounds = 3;
-    const size_t lds_small = (size_t)kSmallN * (8 + 16 + 6 * 4 + 8 + 8) + 256 * 4 + (size_t)64 * kSmallRounds * 4 + (size_t)kLlCap * 4 + 16;
+    const size_t lds_small = (size_t)kSmallN * (8 + 16 + 6 * 4 + 8 + 8) + 256 * 4 + (size_t)64 * kSmallRounds * 4 + 16;
     bool lean = lazy && L.N2 > 0 && lists_in_lds && L.code == 0 && L.N == kSmallN;
     { const char *e = getenv("MFA_VIT_LEAN"); if (e && e[0] == '0') lean = false; }
     if (!lazy) {

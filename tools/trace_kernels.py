@@ -3,6 +3,7 @@
 (the launches after the last mfcc_kernel), in launch order.  usage: trace_kernels.py <dir with *_kernel_trace.csv>"""
 import csv
 import glob
+import re
 import sys
 
 path = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
@@ -13,7 +14,8 @@ step = rows[last:]
 t0 = int(step[0]["Start_Timestamp"])
 out = {}
 for r in step:
-    name = r["Kernel_Name"].split("(")[0].split("<")[0].replace("void ", "").replace("(anonymous namespace)::", "")
+    m = re.search(r"(\w+_kernel(?:<[^>]*>)?)", r["Kernel_Name"])
+    name = m.group(1) if m else r["Kernel_Name"][:40]
     out.setdefault(name, []).append(((int(r["Start_Timestamp"]) - t0) / 1e6, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6))
 for name, v in out.items():
     tot = sum(d for _, d in v)
