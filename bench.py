@@ -297,6 +297,17 @@ def main():
     cells_scored = int((pipe.loglikes != 0).sum().item())
     pipe.cells_scored_fraction = cells_scored / max(1, pipe.loglikes.numel())
     log(rank, f"score cells written: {cells_scored}/{pipe.loglikes.numel()} = {pipe.cells_scored_fraction:.4f}")
+    if os.environ.get("MFA_GMM_STAMPS"):  # diagnostic (library built with -DGMM_BAND_STAMPS): band kernel phase ticks (100 MHz)
+        import ctypes as C
+        acc = torch.zeros(16, dtype=torch.int64, device=dev)
+        eng.lib.mfa_debug_gmm_trace(eng.ctx, C.c_void_p(acc.data_ptr()))
+        pipe.step()
+        torch.cuda.synchronize()
+        eng.lib.mfa_debug_gmm_trace(eng.ctx, None)
+        a = acc.cpu().numpy().astype(np.float64)
+        w = max(a[3], 1.0)
+        log(rank, f"band kernel per wavefront: search {a[0] / w / 100:.2f} us, feature split {a[1] / w / 100:.2f} us, block loop "
+                  f"{a[2] / w / 100:.2f} us over {a[4] / w:.1f} blocks ({a[2] / max(a[4], 1) / 100:.3f} us per block); {int(a[3])} wavefronts")
     if os.environ.get("MFA_VIT_STAMPS"):  # diagnostic (library built with -DVIT_STAMPS): decoder phase cycles → .npy
         import ctypes as C
         stamps = torch.zeros(pipe.n_utt * 12, dtype=torch.int64, device=dev)

@@ -227,6 +227,9 @@ typedef struct {
   const int32_t *d_pdf_last_depth;
   const int32_t *d_state_depth;
   int32_t max_cols;                 /* largest column count of an utterance of the batch (host value) */
+  int32_t groups;                   /* 0 or 1: class 0 in one run ordered by first depth; G > 1 (mfa_build_score_plan_grouped):
+                                       G runs (pdf id mod G), each ordered by first depth */
+  const int32_t *d_group_counts;    /* [n_utt][groups] class-0 columns per run (NULL when groups <= 1) */
 } mfa_score_plan;
 
 MFA_API int mfa_align_features_batch(mfa_ctx *ctx, const mfa_graph_batch *graphs, const mfa_score_plan *plan,
@@ -259,6 +262,18 @@ MFA_API int mfa_build_score_plan(int32_t n_states, const int32_t *h_arc_off, con
                                  const int32_t *h_arc_pdf, int32_t start, int32_t num_pdfs, const int32_t *h_pdf_class,
                                  int32_t cluster_span, int32_t *h_state_depth, int32_t *h_arc_col, int32_t *h_col_pdf,
                                  int32_t *h_col_first, int32_t *h_col_last, int32_t *h_class_counts, int32_t *h_n_cols);
+/* The same with the class-0 columns (one 32-row model block per pdf — the bulk of a context-dependent model) laid out in
+ * `groups` runs, run g holding the pdfs with id mod groups == g, each run in ascending first depth with its own running
+ * max in h_col_last; h_group_counts[groups] = columns per run.  With groups = 8 the lazy scoring kernel gives run g of every
+ * utterance to workgroups of one XCD, whose 4 MiB L2 then only ever sees an eighth of the model (MI355X: 8 XCDs; a
+ * 5k-pdf model is 51 MB of operands, re-read from the Infinity Cache otherwise).  The band rule holds per run.
+ * groups = 1 is mfa_build_score_plan.  Returns -3 for groups outside 1..MFA_PLAN_MAX_GROUPS. */
+#define MFA_PLAN_MAX_GROUPS 8
+MFA_API int mfa_build_score_plan_grouped(int32_t n_states, const int32_t *h_arc_off, const int32_t *h_arc_next,
+                                         const int32_t *h_arc_pdf, int32_t start, int32_t num_pdfs, const int32_t *h_pdf_class,
+                                         int32_t cluster_span, int32_t groups, int32_t *h_state_depth, int32_t *h_arc_col,
+                                         int32_t *h_col_pdf, int32_t *h_col_first, int32_t *h_col_last, int32_t *h_class_counts,
+                                         int32_t *h_group_counts, int32_t *h_n_cols);
 
 /* ---- fMLLR statistics: replaces the accumulation of CalcFmllrFunction / kalpy FmllrComputer
  *      (MFA/corpus/features.py:506-527; Kaldi FmllrDiagGmmAccs) between the two alignment passes

@@ -43,7 +43,7 @@ class ScorePlan(C.Structure):
     _fields_ = [
         ("d_pdf_list", C.c_void_p), ("d_pdf_off", C.c_void_p), ("d_class_counts", C.c_void_p),
         ("d_pdf_first_frame", C.c_void_p), ("d_pdf_last_depth", C.c_void_p), ("d_state_depth", C.c_void_p),
-        ("max_cols", C.c_int32),
+        ("max_cols", C.c_int32), ("groups", C.c_int32), ("d_group_counts", C.c_void_p),
     ]
 
 
@@ -109,6 +109,7 @@ SIGNATURES = {
                                            C.POINTER(AlignOpts), _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mfa_fst_last_depths": (C.c_int, [_i32, _vp, _vp, _i32, _vp, _vp]),
     "mfa_build_score_plan": (C.c_int, [_i32, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mfa_build_score_plan_grouped": (C.c_int, [_i32, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mfa_fmllr_acc_batch": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
     "mfa_fmllr_acc_ali_batch": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
     "mfa_fmllr_stats_model": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp]),

@@ -61,6 +61,10 @@ struct mfa_ctx {
   float gmm_acc_scale = 1.0f;  // S: the f16 path's accumulators are S × the log-likelihood terms (power of two)
   int *d_gmm_redo = nullptr;   // tiles the f16 pass handed to the bf16×3 pass
   int64_t gmm_redo_cap = 0;
+  void *d_xsplit = nullptr;    // lazy scoring: f16 hi/lo operands of every 64-frame tile in register layout (gmm_presplit_kernel)
+  int *d_xsplit_bad = nullptr; // … and the tile's "a scaled feature left the f16 range" flag
+  int64_t xsplit_tiles = 0;
+  bool xsplit_ready = false;   // d_xsplit holds the operands of the batch mfa_align_features_batch is working on
   float *d_gc = nullptr;       // [num_rows]
   int32_t *d_row0 = nullptr;   // [num_pdfs] first packed row
   int32_t *d_nblk = nullptr;   // [num_pdfs] number of 32-row blocks (slot 32) else 1
@@ -154,6 +158,7 @@ struct MfaWindowScore {
   int done_stride, done_word;
   int cols_per_wave;            // 0: one wavefront walks a sub-tile's whole band; n: one wavefront per n columns of it
 };
+int mfa_gmm_presplit(mfa_ctx *c, const MfaLazyScoring *lazy, const int64_t *d_frame_off, int n_utt, int64_t total_frames);
 int mfa_gmm_lazy_supported(mfa_ctx *ctx);   // the loaded model fits the MFMA kernels (dim <= 48)
 // Score, for every listed utterance, the (frame, pdf) cells of the window that lie inside the band.  Enqueues on ctx->stream.
 int mfa_gmm_score_window(mfa_ctx *ctx, const MfaLazyScoring *lazy, const MfaWindowScore *ws, const int64_t *d_frame_off,

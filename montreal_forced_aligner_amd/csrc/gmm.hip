@@ -81,10 +81,15 @@ struct GmmParams {
   const int32_t *last_depth;   // parallel to pdf_list: running max (inside a class) of the longest-path depth of the pdf's sources
   int b_skip0;                 // f32 band kernel: classes 0, 2, 3, 4 were scored by gmm_band_kernel (it keeps 1 and 5)
   int b_chunk, b_nchunk;       // gmm_band_kernel: columns per wavefront (0 = the whole band) and chunks per sub-tile
-  int dbg_nostore;             // timing experiments only (MFA_GMM_NOSTORE=1): band kernel computes but does not store
-  int b_xcd;                   // gmm_band_kernel: 1 = eight wavefronts per sub-tile, wavefront x (in a workgroup with blockIdx % 8 == x,
-                               // i.e. on one XCD) scores the band's pdfs with id % 8 == x: an XCD's L2 then only ever sees an
-                               // eighth of the model
+  const uint4 *xsplit;         // band kernel: pre-split f16 operands [tile][2][kSteps][2][64 lanes] (gmm_presplit_kernel) or NULL
+  const int *xsplit_bad;       // [tile]: 1 = a scaled feature of the tile left the f16 range (the bf16×3 pass takes it)
+  // Grouped plans (mfa_build_score_plan_grouped): class 0 of every utterance is laid out in `groups` runs (pdf id mod groups),
+  // each ordered by first depth.  gmm_band_kernel then runs `groups` wavefronts per sub-tile, wavefront x — in a workgroup
+  // with blockIdx % groups == x, i.e. (groups = 8) always on the same XCD — scoring run x: that XCD's L2 only ever sees
+  // an eighth of the model.
+  int groups;                  // 0/1: ungrouped
+  const int32_t *group_counts; // [n_utt][groups]
+  int b_split;                 // 1: this launch's grid holds `groups` workgroups per four sub-tiles (gmm_band_kernel)
 };
 
 // Band of one (utterance, window): pdf j of a class is needed iff first_frame[j] <= hi and last_depth[j] >= lo; both keys
@@ -98,7 +103,7 @@ __device__ __forceinline__ Band band_of(const GmmParams &p, int utt) {
 }
 // wavefront → (utterance, 64-frame sub-tile) of a band-mode launch; false: nothing to do
 __device__ __forceinline__ bool band_item(const GmmParams &p, int wave, int &utt, int &r, int *chunk = nullptr) {
-  int witem = (p.b_xcd ? (int)(blockIdx.x >> 3) : (int)blockIdx.x) * 4 + wave;
+  int witem = (p.b_split ? (int)(blockIdx.x / (unsigned)p.groups) : (int)blockIdx.x) * 4 + wave;
   if (chunk) { const int q = witem / p.b_nchunk; *chunk = witem - q * p.b_nchunk; witem = q; }
   const int item = witem / p.b_sub;
   r = witem - item * p.b_sub;
@@ -108,6 +113,9 @@ __device__ __forceinline__ bool band_item(const GmmParams &p, int wave, int &utt
   if (p.b_t_begin > 0 && p.b_done && p.b_done[(size_t)utt * p.b_done_stride + p.b_done_word] != 0) return false;
   return true;
 }
+
+// one past the last index (i0 + lane) whose bit is set in a 64-lane ballot, 0 if none
+__device__ __forceinline__ int prefix_end(unsigned long long mask, int i0) { return mask ? i0 + 64 - __clzll((long long)mask) : 0; }
 
 // row index (within a 32-row MFMA block) held by accumulator register r of a lane in half h
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
@@ -283,12 +291,14 @@ __device__ __forceinline__ void score_tile(const GmmParams &p, int utt, int t_ba
     for (int cls = 0; cls < 6; cls++) {
       const int cnt = cc6[cls];
       int nd = cnt, lw = 0;
+      if (cls == 0 && p.groups > 1) { need[0] = 0; lo_[0] = 0; off += cnt; continue; }   // grouped plan: searched run by run below
       if (p.first_frame) {
         nd = 0;
         for (int i0 = 0; i0 < cnt; i0 += 64) {
           const int i = i0 + lane;
           const bool ok = i < cnt && p.first_frame[l0 + off + i] <= t_last;
-          nd += __popcll(__ballot(ok));
+          nd = max(nd, prefix_end(__ballot(ok), i0));   // = the count for a class ordered by first frame; a superset prefix when
+                                                        // the caller passes a grouped plan's lists without its run counts
           if (p.b_mode) lw += __popcll(__ballot(i < cnt && p.last_depth[l0 + off + i] < d_lo));
         }
       }
@@ -310,8 +320,29 @@ __device__ __forceinline__ void score_tile(const GmmParams &p, int utt, int t_ba
   Tile<M8, kNT> tile;
   tile.load_b(p, f0, T, t_base, lane);
   f32x16 acc[kNT];
-  const int n_single = (p.skip_single || p.b_skip0) ? 0 : need[0];
-  const int first32 = lo_[0];   // band mode: the class-0 range starts here (0 otherwise)
+  // Class 0 is one run ordered by first depth, or (grouped plan) `groups` runs — searched and walked one after the other.
+  const bool skip0 = p.skip_single || p.b_skip0;
+  const int nruns = p.groups > 1 ? p.groups : 1;
+  int run_off = 0;
+  for (int run = 0; run < nruns; run++) {
+  int n_single = skip0 ? 0 : need[0];
+  int first32 = lo_[0];         // band mode: the class-0 range starts here (0 otherwise)
+  if (p.groups > 1 && !skip0) {
+    const int cnt = p.group_counts[(size_t)utt * p.groups + run];
+    int nd = cnt, lw = 0;
+    if (p.first_frame) {
+      int t_last = min(T, t_base + kFramesPerWave) - 1 + p.ff_bias, d_lo = 0;
+      if (p.b_mode) { const Band bd = band_of(p, utt); t_last = bd.hi; d_lo = bd.lo; }
+      nd = 0;
+      for (int i0 = 0; i0 < cnt; i0 += 64) {
+        const int i = i0 + lane;
+        nd += __popcll(__ballot(i < cnt && p.first_frame[l0 + run_off + i] <= t_last));
+        if (p.b_mode) lw += __popcll(__ballot(i < cnt && p.last_depth[l0 + run_off + i] < d_lo));
+      }
+    }
+    first32 = run_off + min(lw, nd); n_single = run_off + nd;
+    run_off += cnt;
+  }
 
   // ---- single-block 32-row pdfs (the bulk of a context-dependent model): one pdf per MFMA block.
   // Software pipeline, no extra registers: as soon as the MFMAs that read operand group a[m] of block j have been issued,
@@ -419,6 +450,7 @@ __device__ __forceinline__ void score_tile(const GmmParams &p, int utt, int t_ba
       }
     }
   }
+  }   // runs of class 0
 
   // ---- 32-row pdfs with more than 32 Gaussians: several blocks, two passes (max, then the sum against that max)
   const int n32 = cc[0];
@@ -651,16 +683,36 @@ __device__ __forceinline__ bool split_features(const GmmParams &p, int64_t f0, i
     t = t < T ? t : T - 1;
     t = t < 0 ? 0 : t;
     const float *x = p.feats + (f0 + t) * p.dim;
+    const bool vec8 = (p.dim & 7) == 0;   // every group of 8 operand columns then lies wholly in x, in x² or in the padding
 #pragma unroll
     for (int s = 0; s < kSteps; s++) {
+      float xv8[8], fs8[8];
+      {
+        const int k0 = 16 * s + 8 * h;
+        if (vec8) {   // two 16-byte loads per group instead of eight 4-byte ones (same values)
+          const int i0 = k0 < p.dim ? k0 : (k0 < 2 * p.dim ? k0 - p.dim : 0);
+          const float4 lo4 = *reinterpret_cast<const float4 *>(x + i0), hi4 = *reinterpret_cast<const float4 *>(x + i0 + 4);
+          xv8[0] = lo4.x; xv8[1] = lo4.y; xv8[2] = lo4.z; xv8[3] = lo4.w; xv8[4] = hi4.x; xv8[5] = hi4.y; xv8[6] = hi4.z; xv8[7] = hi4.w;
+          if constexpr (kPieces == 2) {
+            const float4 f0_ = *reinterpret_cast<const float4 *>(p.fscale + k0), f1_ = *reinterpret_cast<const float4 *>(p.fscale + k0 + 4);
+            fs8[0] = f0_.x; fs8[1] = f0_.y; fs8[2] = f0_.z; fs8[3] = f0_.w; fs8[4] = f1_.x; fs8[5] = f1_.y; fs8[6] = f1_.z; fs8[7] = f1_.w;
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; e++) {
+            const int k = k0 + e;
+            xv8[e] = x[k < p.dim ? k : (k < 2 * p.dim ? k - p.dim : 0)];
+            if constexpr (kPieces == 2) fs8[e] = p.fscale[k];
+          }
+        }
+      }
 #pragma unroll
       for (int e = 0; e < 8; e++) {
         const int k = 16 * s + 8 * h + e;
-        const int idx = k < p.dim ? k : (k < 2 * p.dim ? k - p.dim : 0);
-        const float xv = x[idx];
+        const float xv = xv8[e];
         const float v = k < p.dim ? xv : (k < 2 * p.dim ? xv * xv : 0.0f);
         if constexpr (kPieces == 2) {
-          const float sv = v * p.fscale[k];
+          const float sv = v * fs8[e];
           bad |= !(fabsf(sv) <= 65000.0f);
           const _Float16 v1 = (_Float16)sv;
           b[n][s][0][e] = v1; b[n][s][1][e] = (_Float16)(sv - (float)v1);
@@ -775,8 +827,10 @@ __global__ __launch_bounds__(256, 2) void gmm_bf16_kernel(GmmParams p) {
           const int ff = i < cc0 + cc1 ? p.first_frame[l0 + i] : 0x7fffffff;
           const unsigned long long all = __ballot(ff <= t_last), mine = __ballot(ff <= t_mine);
           const unsigned long long c0m = __ballot(i < cc0);
-          n0 += __popcll(all & c0m); n1 += __popcll(all & ~c0m);
-          n0_mine += __popcll(mine & c0m); n1_mine += __popcll(mine & ~c0m);
+          // class 0: the prefix up to the LAST pdf that can be asked for (= the count when the class is ordered by first
+          // frame; a superset of what is needed when a grouped plan lays it out in several ordered runs)
+          n0 = max(n0, prefix_end(all & c0m, i0)); n1 += __popcll(all & ~c0m);
+          n0_mine = max(n0_mine, prefix_end(mine & c0m, i0)); n1_mine += __popcll(mine & ~c0m);
         }
       }
       if (p.skip_cc0) { n0 = 0; n0_mine = 0; }         // columns keep their places: multi-block pdfs start at column cc0
@@ -993,8 +1047,8 @@ __global__ __launch_bounds__(256, 2) void gmm_split_single_kernel(GmmParams p) {
         for (int i0 = 0; i0 < n_all; i0 += 64) {
           const int i = i0 + lane;
           const int ff = i < n_all ? p.first_frame[l0 + i] : 0x7fffffff;
-          n_single += __popcll(__ballot(ff <= t_last));
-          n_mine += __popcll(__ballot(ff <= t_mine));
+          n_single = max(n_single, prefix_end(__ballot(ff <= t_last), i0));   // (see gmm_bf16_kernel: superset for grouped plans)
+          n_mine = max(n_mine, prefix_end(__ballot(ff <= t_mine), i0));
         }
       }
       float *out = p.out + p.ll_off[utt];
@@ -1269,8 +1323,8 @@ __global__ __launch_bounds__(256, 2) void gmm_split_small_kernel(GmmParams p) {
         for (int i0 = 0; i0 < n_all; i0 += 64) {
           const int i = i0 + lane;
           const int ff = i < n_all ? p.first_frame[l0 + base + i] : 0x7fffffff;
-          n_single += __popcll(__ballot(ff <= t_last));
-          n_mine += __popcll(__ballot(ff <= t_mine));
+          n_single = max(n_single, prefix_end(__ballot(ff <= t_last), i0));   // (see gmm_bf16_kernel: superset for grouped plans)
+          n_mine = max(n_mine, prefix_end(__ballot(ff <= t_mine), i0));
         }
       }
       float *out = p.out + p.ll_off[utt];
@@ -1410,6 +1464,37 @@ __global__ __launch_bounds__(256, 2) void gmm_split_small_kernel(GmmParams p) {
   }
 }
 
+// Index of the 64-frame tile `tile` of utterance `utt` in the pre-split operand buffer: ⌊frame_off/64⌋ + utt + tile is
+// monotone and leaves every utterance room for ⌈T/64⌉ tiles without a separate offset table.
+__device__ __forceinline__ int64_t xsplit_tile_index(int64_t frame_off_u, int utt, int tile) { return (frame_off_u >> 6) + utt + tile; }
+
+// Lazy scoring pre-pass: the f16 hi/lo operands [x, x²]·scale of every 64-frame tile, in the register layout the band
+// kernel's MFMAs read (b[n][step][piece] of lane l at ((n·kSteps + step)·2 + piece)·64 + l), so that a wavefront starts
+// a window with twenty coalesced 1 KiB loads instead of 160 strided 4-byte loads and the split arithmetic — the values are
+// those of split_features bit for bit.  One wavefront per tile.
+template <int kSteps>
+__global__ __launch_bounds__(256) void gmm_presplit_kernel(GmmParams p, uint4 *out, int *bad_out, int tiles_per_utt) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t item = (int64_t)blockIdx.x * 4 + wave;
+  const int utt = (int)(item / tiles_per_utt), tile = (int)(item - (int64_t)utt * tiles_per_utt);
+  if (utt >= p.n_utt) return;
+  const int64_t f0 = p.frame_off[utt];
+  const int T = (int)(p.frame_off[utt + 1] - f0);
+  if (tile * 64 >= T) return;
+  f16x8 b[2][kSteps][2];
+  const bool bad = split_features<kSteps, 2>(p, f0, T, tile * 64, lane & 31, lane >> 5, b);
+  const int64_t ti = xsplit_tile_index(f0, utt, tile);
+  uint4 *dst = out + ti * (2 * kSteps * 2 * 64) + lane;
+#pragma unroll
+  for (int n = 0; n < 2; n++)
+#pragma unroll
+    for (int s_ = 0; s_ < kSteps; s_++)
+#pragma unroll
+      for (int q = 0; q < 2; q++) dst[((n * kSteps + s_) * 2 + q) * 64] = __builtin_bit_cast(uint4, b[n][s_][q]);
+  const bool any_bad = __ballot(bad) != 0ull;
+  if (lane == 0) bad_out[ti] = any_bad ? 1 : 0;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Lazy (windowed) scoring — mfa_gmm_score_window.  Kaldi evaluates its decodable lazily: a score exists only if a live
 // token's arc asked for it.  The dense kernels above score every pdf of the utterance's graph for every frame from the
@@ -1430,12 +1515,14 @@ __global__ __launch_bounds__(256, 2) void gmm_band_kernel(GmmParams p) {
   using op8 = std::conditional_t<kHalf, f16x8, bf16x8>;
   constexpr int kUnits = kSteps * kPieces * 2 * 32;    // 16-byte units per block
   __shared__ float stage_all[4][64 * 33];
-  constexpr int kMineCap = 128;
-  __shared__ int mine_all[4][kMineCap];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float *stage = stage_all[wave];
-  int *mine = mine_all[wave];
-  const int xsel = p.b_xcd ? (int)(blockIdx.x & 7u) : -1;
+  const int grp = p.b_split ? (int)(blockIdx.x % (unsigned)p.groups) : 0;      // the run of class 0 this wavefront scores
+#ifdef GMM_BAND_STAMPS
+  // phase accounting (-DGMM_BAND_STAMPS, buffer from mfa_debug_gmm_trace): Σ 100 MHz ticks of {item + band search, feature
+  // split, block loop}, wavefronts with work, blocks
+  const unsigned long long st0 = wall_clock64();
+#endif
   int utt, r, chunk = 0;
   if (!band_item(p, wave, utt, r, &chunk)) return;
   const int64_t f0 = p.frame_off[utt];
@@ -1457,17 +1544,33 @@ __global__ __launch_bounds__(256, 2) void gmm_band_kernel(GmmParams p) {
     int off = 0;
 #pragma unroll
     for (int cls = 0; cls < 5; cls++) {
-      const int cnt = cc6[cls];
+      const int cnt_cls = cc6[cls];
+      int cnt = cnt_cls, seg = 0;       // the run searched: the whole class, or (class 0 of a grouped plan) this wavefront's run
+      if (cls == 0 && p.b_split) {
+        const int32_t *gc = p.group_counts + (size_t)utt * p.groups;
+        for (int g = 0; g < grp; g++) seg += gc[g];
+        cnt = gc[grp];
+      }
       int nh = 0, nl = 0;
       if (cls != 1) {
-        for (int i0 = 0; i0 < cnt; i0 += 64) {
-          const int i = i0 + lane;
-          nh += __popcll(__ballot(i < cnt && p.first_frame[l0 + off + i] <= bd.hi));
-          nl += __popcll(__ballot(i < cnt && p.last_depth[l0 + off + i] < bd.lo));
+        // four chunks per trip, every load issued before the first ballot waits (one memory round trip per 256 pdfs, not four)
+        for (int i0 = 0; i0 < cnt; i0 += 256) {
+          int ff[4], ld[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int i = min(i0 + 64 * u + lane, cnt - 1);
+            ff[u] = p.first_frame[l0 + off + seg + i]; ld[u] = p.last_depth[l0 + off + seg + i];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const bool in = i0 + 64 * u + lane < cnt;
+            nh += __popcll(__ballot(in && ff[u] <= bd.hi));
+            nl += __popcll(__ballot(in && ld[u] < bd.lo));
+          }
         }
       }
-      lo_c[cls] = min(nl, nh); hi_c[cls] = nh; base_c[cls] = off;
-      off += cnt;
+      lo_c[cls] = seg + min(nl, nh); hi_c[cls] = seg + nh; base_c[cls] = off;
+      off += cnt_cls;
     }
   }
   if (p.b_chunk > 0) {                                 // list passes: this wavefront's share of the band (class 0 in chunks,
@@ -1475,14 +1578,34 @@ __global__ __launch_bounds__(256, 2) void gmm_band_kernel(GmmParams p) {
     hi_c[0] = min(hi_c[0], lo_c[0] + p.b_chunk);
     if (chunk != 0) { hi_c[2] = lo_c[2]; hi_c[3] = lo_c[3]; hi_c[4] = lo_c[4]; }
   }
-  if (xsel > 0) { hi_c[2] = lo_c[2]; hi_c[3] = lo_c[3]; hi_c[4] = lo_c[4]; }   // the small-slot classes stay with wavefront 0
+  if (grp > 0) { hi_c[2] = lo_c[2]; hi_c[3] = lo_c[3]; hi_c[4] = lo_c[4]; }    // the small-slot classes stay with run 0's wavefront
   const int lo = lo_c[0], hi = hi_c[0];
   if (lo >= hi && lo_c[2] >= hi_c[2] && lo_c[3] >= hi_c[3] && lo_c[4] >= hi_c[4]) {
     if (kHalf && lane == 0) *redo_flag = 0;
     return;
   }
+#ifdef GMM_BAND_STAMPS
+  const unsigned long long st1 = wall_clock64();
+#endif
   op8 b[2][kSteps][kPieces];
-  const bool bad = split_features<kSteps, kPieces>(p, f0, T, t_base, col, h, b);
+  bool bad = false;
+  if (kHalf && p.xsplit) {                                             // operands split once per utterance by gmm_presplit_kernel
+    const int64_t ti = xsplit_tile_index(f0, utt, t_base >> 6);
+    const uint4 *src = p.xsplit + ti * (2 * kSteps * 2 * 64) + lane;
+#pragma unroll
+    for (int n = 0; n < 2; n++)
+#pragma unroll
+      for (int s_ = 0; s_ < kSteps; s_++)
+#pragma unroll
+        for (int q = 0; q < kPieces; q++) b[n][s_][q] = __builtin_bit_cast(op8, src[((n * kSteps + s_) * 2 + (q & 1)) * 64]);
+    bad = p.xsplit_bad[ti] != 0;
+  } else {
+    bad = split_features<kSteps, kPieces>(p, f0, T, t_base, col, h, b);
+  }
+#ifdef GMM_BAND_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const unsigned long long st2 = wall_clock64();
+#endif
   if constexpr (kHalf) {
     const bool any_bad = __ballot(bad) != 0ull;
     if (lane == 0) *redo_flag = any_bad ? 1 : 0;
@@ -1501,101 +1624,12 @@ __global__ __launch_bounds__(256, 2) void gmm_band_kernel(GmmParams p) {
 #pragma unroll 4
     for (int i = 0; i < 32; i++) {
       const int rr = h + 2 * i, t = t_base + rr;
-      if (col < cnt && t < T && !p.dbg_nostore) __builtin_nontemporal_store(stage[rr * 33 + col], &out[(size_t)t * P + c0 + col]);
+      if (col < cnt && t < T) __builtin_nontemporal_store(stage[rr * 33 + col], &out[(size_t)t * P + c0 + col]);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   };
 
-  // ---------------------------------------------------------------- class 0, one XCD's share of the band
-  if (xsel >= 0 && lo < hi) {
-    const uint4 *wsrc = (kHalf ? p.wh : p.wb) + lane;
-    const float *gsrc = (kHalf ? p.gch : p.gc) + 4 * h;
-    int jpos = lo;
-    while (jpos < hi) {                                  // rounds of at most kMineCap of this wavefront's columns
-      int cnt = 0;
-      while (jpos < hi && cnt <= kMineCap - 64) {
-        const int j = jpos + lane;
-        const bool m = j < hi && (list[min(j, hi - 1)] & 7) == xsel;
-        const unsigned long long mask = __ballot(m);
-        if (m) mine[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = j;
-        cnt += __popcll(mask);
-        jpos += 64;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      if (cnt == 0) continue;
-      const int last = cnt - 1;
-      auto block_at = [&](int i) { return __builtin_amdgcn_readfirstlane(p.row0[list[mine[min(i, last)]]]) >> 5; };
-      op8 a[kSteps][kPieces];
-      f32x4 g[4];
-      {
-        const int blk = block_at(0);
-        const uint4 *src = wsrc + (size_t)blk * kUnits;
-#pragma unroll
-        for (int q = 0; q < 4; q++) g[q] = *reinterpret_cast<const f32x4 *>(gsrc + (size_t)blk * 32 + 8 * q);
-#pragma unroll
-        for (int s_ = 0; s_ < kSteps; s_++)
-#pragma unroll
-          for (int q = 0; q < kPieces; q++) a[s_][q] = __builtin_bit_cast(op8, src[(s_ * kPieces + q) * 64]);
-      }
-      int blk_next = block_at(1);
-      int mycol = 0;                                     // score column of staging slot `col`
-      for (int i = 0; i < cnt; i++) {
-        const int j = __builtin_amdgcn_readfirstlane(mine[i]);
-        const int x_next2 = p.row0[list[mine[min(i + 2, last)]]];
-        f32x16 init, acc[2];
-#pragma unroll
-        for (int rr = 0; rr < 16; rr++) init[rr] = g[rr >> 2][rr & 3];
-        const uint4 *src = wsrc + (size_t)blk_next * kUnits;
-        const float *gn = gsrc + (size_t)blk_next * 32;
-#pragma unroll
-        for (int s_ = 0; s_ < kSteps; s_++) {
-#pragma unroll
-          for (int t6 = 0; t6 < kProd; t6++)
-#pragma unroll
-            for (int n = 0; n < 2; n++) {
-              const f32x16 &cin = (s_ == 0 && t6 == 0) ? init : acc[n];
-              if constexpr (kHalf) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s_][pa[t6]], b[n][s_][pb[t6]], cin, 0, 0, 0);
-              else acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s_][pa[t6]], b[n][s_][pb[t6]], cin, 0, 0, 0);
-            }
-          if (s_ == 0) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) g[q] = *reinterpret_cast<const f32x4 *>(gn + 8 * q);
-          }
-#pragma unroll
-          for (int q = 0; q < kPieces; q++) a[s_][q] = __builtin_bit_cast(op8, src[(s_ * kPieces + q) * 64]);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        blk_next = __builtin_amdgcn_readfirstlane(x_next2) >> 5;
-        float mx[2], sum[2];
-#pragma unroll
-        for (int n = 0; n < 2; n++) {
-          float m = reg_max<0, 16>(acc[n]);
-          m = fmaxf(m, swap32(m, h));
-          float sv = reg_expsum_fast(acc[n], m, l2e_s);
-          sv += swap32(sv, h);
-          mx[n] = m; sum[n] = sv;
-        }
-        const int jj = i & 31;
-        if (col == jj) mycol = j;
-        stage[(32 * h + col) * 33 + jj] = finish((h ? mx[1] : mx[0]) * inv_s, h ? sum[1] : sum[0]);
-        if (jj == 31 || i == last) {
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll 4
-          for (int q = 0; q < 32; q++) {
-            const int rr = h + 2 * q, t = t_base + rr;
-            if (col <= jj && t < T && !p.dbg_nostore) __builtin_nontemporal_store(stage[rr * 33 + col], &out[(size_t)t * P + mycol]);
-          }
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-        }
-      }
-    }
-  } else
   // ---------------------------------------------------------------- class 0: one pdf per 32-row block
   if (lo < hi) {
     const uint4 *wsrc = (kHalf ? p.wh : p.wb) + lane;
@@ -1774,6 +1808,13 @@ __global__ __launch_bounds__(256, 2) void gmm_band_kernel(GmmParams p) {
   run_small(std::integral_constant<int, 16>{}, base_c[2], lo_c[2], hi_c[2]);
   run_small(std::integral_constant<int, 8>{}, base_c[3], lo_c[3], hi_c[3]);
   run_small(std::integral_constant<int, 4>{}, base_c[4], lo_c[4], hi_c[4]);
+#ifdef GMM_BAND_STAMPS
+  if (p.trace && lane == 0 && kHalf) {
+    const unsigned long long st3 = wall_clock64();
+    atomicAdd(&p.trace[0], st1 - st0); atomicAdd(&p.trace[1], st2 - st1); atomicAdd(&p.trace[2], st3 - st2);
+    atomicAdd(&p.trace[3], 1ull); atomicAdd(&p.trace[4], (unsigned long long)(hi - lo));
+  }
+#endif
 }
 
 // Band-mode launch of the f32 kernel's tile walk: whatever slot classes gmm_band_kernel does not cover (single-Gaussian
@@ -2133,6 +2174,17 @@ MFA_API int mfa_build_score_plan(int32_t n_states, const int32_t *h_arc_off, con
                                  const int32_t *h_arc_pdf, int32_t start, int32_t num_pdfs, const int32_t *h_pdf_class,
                                  int32_t cluster_span, int32_t *h_state_depth, int32_t *h_arc_col, int32_t *h_col_pdf,
                                  int32_t *h_col_first, int32_t *h_col_last, int32_t *h_class_counts, int32_t *h_n_cols) {
+  return mfa_build_score_plan_grouped(n_states, h_arc_off, h_arc_next, h_arc_pdf, start, num_pdfs, h_pdf_class, cluster_span,
+                                      1, h_state_depth, h_arc_col, h_col_pdf, h_col_first, h_col_last, h_class_counts, nullptr,
+                                      h_n_cols);
+}
+
+MFA_API int mfa_build_score_plan_grouped(int32_t n_states, const int32_t *h_arc_off, const int32_t *h_arc_next,
+                                         const int32_t *h_arc_pdf, int32_t start, int32_t num_pdfs, const int32_t *h_pdf_class,
+                                         int32_t cluster_span, int32_t groups, int32_t *h_state_depth, int32_t *h_arc_col,
+                                         int32_t *h_col_pdf, int32_t *h_col_first, int32_t *h_col_last, int32_t *h_class_counts,
+                                         int32_t *h_group_counts, int32_t *h_n_cols) {
+  if (groups < 1 || groups > MFA_PLAN_MAX_GROUPS || (groups > 1 && !h_group_counts)) return -3;
   if (n_states <= 0 || start < 0 || start >= n_states) return -1;
   const int n_arcs = h_arc_off[n_states];
   std::vector<int32_t> bfs(n_states), low(n_states);
@@ -2167,25 +2219,32 @@ MFA_API int mfa_build_score_plan(int32_t n_states, const int32_t *h_arc_off, con
     cols.back().last = std::max(cols.back().last, d);
     col_of_arc[a] = (int32_t)cols.size() - 1;
   }
-  // kernel order: slot class, then ascending first depth (ties: pdf id, then depth — the creation order)
+  // kernel order: slot class, (class 0 only: pdf id mod `groups` — the XCD whose L2 keeps that part of the model), then
+  // ascending first depth (ties: pdf id, then depth — the creation order)
   const int n_cols = (int)cols.size();
   std::vector<int32_t> perm(n_cols), rank(n_cols);
   for (int i = 0; i < n_cols; i++) perm[i] = i;
+  auto group_of = [&](const Col &c) { return c.cls == 0 ? c.pdf % groups : 0; };
   std::stable_sort(perm.begin(), perm.end(), [&](int32_t x, int32_t y) {
     if (cols[x].cls != cols[y].cls) return cols[x].cls < cols[y].cls;
+    const int gx = group_of(cols[x]), gy = group_of(cols[y]);
+    if (gx != gy) return gx < gy;
     return cols[x].first < cols[y].first;
   });
   for (int k = 0; k < 6; k++) h_class_counts[k] = 0;
-  int32_t run_cls = -1, run_max = 0;
+  if (h_group_counts) for (int k = 0; k < groups; k++) h_group_counts[k] = 0;
+  int32_t run_cls = -1, run_grp = -1, run_max = 0;
   for (int i = 0; i < n_cols; i++) {
     const Col &cl = cols[perm[i]];
+    const int grp = group_of(cl);
     rank[perm[i]] = i;
     h_col_pdf[i] = cl.pdf;
     h_col_first[i] = cl.first;
-    if (cl.cls != run_cls) { run_cls = cl.cls; run_max = cl.last; }
+    if (cl.cls != run_cls || grp != run_grp) { run_cls = cl.cls; run_grp = grp; run_max = cl.last; }
     run_max = std::max(run_max, cl.last);
-    h_col_last[i] = run_max;            // running max inside the class: non-decreasing along the list
+    h_col_last[i] = run_max;            // running max inside the class (class 0: inside the group): non-decreasing along it
     h_class_counts[cl.cls]++;
+    if (h_group_counts && cl.cls == 0) h_group_counts[grp]++;
   }
   for (int a = 0; a < n_arcs; a++) h_arc_col[a] = rank[col_of_arc[a]];
   *h_n_cols = n_cols;
@@ -2336,6 +2395,39 @@ MFA_API int mfa_gmm_score_batch(mfa_ctx *c, const float *d_feats, const int64_t 
 
 int mfa_gmm_lazy_supported(mfa_ctx *c) { return c->gmm_ready && (c->kpad == 80 || c->kpad == 96); }
 
+// Pre-split f16 operands of the whole batch (see gmm_presplit_kernel); mfa_gmm_score_window then hands them to the band kernel.
+int mfa_gmm_presplit(mfa_ctx *c, const MfaLazyScoring *lazy, const int64_t *d_frame_off, int n_utt, int64_t total_frames) {
+  c->xsplit_ready = false;
+  const char *bf = getenv("MFA_GMM_BF16");
+  const char *hf = getenv("MFA_GMM_F16");
+  const char *ps = getenv("MFA_GMM_PRESPLIT");
+  if ((bf && bf[0] == '0') || (hf && hf[0] == '0') || (ps && ps[0] == '0') || !c->d_wh || !c->d_wb) return 0;   // no f16 pass: nothing to prepare
+  const int ksteps = c->kpad / 16;
+  if (ksteps != 5 && ksteps != 6) return 0;
+  const int64_t tiles = (total_frames >> 6) + n_utt + 1;
+  if (c->xsplit_tiles < tiles) {
+    MFA_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    if (c->d_xsplit) (void)hipFree(c->d_xsplit);
+    if (c->d_xsplit_bad) (void)hipFree(c->d_xsplit_bad);
+    c->d_xsplit = nullptr; c->d_xsplit_bad = nullptr; c->xsplit_tiles = 0;
+    MFA_HIP_CHECK(c, hipMalloc(&c->d_xsplit, (size_t)tiles * 2 * 6 * 2 * 64 * 16));
+    MFA_HIP_CHECK(c, hipMalloc((void **)&c->d_xsplit_bad, (size_t)tiles * sizeof(int)));
+    c->xsplit_tiles = tiles;
+  }
+  GmmParams p;
+  memset(&p, 0, sizeof(p));
+  p.dim = c->dim; p.kpad = c->kpad; p.feats = lazy->d_feats; p.frame_off = d_frame_off; p.n_utt = n_utt; p.fscale = c->d_fscale;
+  const int tiles_per_utt = (lazy->max_frames + 63) / 64;
+  const int64_t waves = (int64_t)n_utt * tiles_per_utt;
+  const dim3 grid((unsigned)((waves + 3) / 4));
+  KernelTimer kt(c, MFA_K_GMM);
+  if (ksteps == 5) hipLaunchKernelGGL((gmm_presplit_kernel<5>), grid, dim3(256), 0, c->stream, p, (uint4 *)c->d_xsplit, c->d_xsplit_bad, tiles_per_utt);
+  else hipLaunchKernelGGL((gmm_presplit_kernel<6>), grid, dim3(256), 0, c->stream, p, (uint4 *)c->d_xsplit, c->d_xsplit_bad, tiles_per_utt);
+  MFA_HIP_CHECK(c, hipGetLastError());
+  c->xsplit_ready = true;
+  return 0;
+}
+
 int mfa_gmm_score_window(mfa_ctx *c, const MfaLazyScoring *lazy, const MfaWindowScore *ws, const int64_t *d_frame_off,
                          int n_utt, const int64_t *d_ll_off, float *d_loglikes) {
   if (!c->gmm_ready) return c->fail("mfa_load_gmm has not been called");
@@ -2351,17 +2443,19 @@ int mfa_gmm_score_window(mfa_ctx *c, const MfaLazyScoring *lazy, const MfaWindow
   p.first_frame = lazy->plan.d_pdf_first_frame; p.last_depth = lazy->plan.d_pdf_last_depth;
   p.n_utt = n_utt; p.tiles = 0;
   p.acc_scale_inv = 1.0f;
+  p.trace = (unsigned long long *)c->gmm_trace;
   p.b_mode = 1; p.b_t_begin = ws->t_begin; p.b_sub = ws->window / 64; p.b_band = ws->band;
   p.b_utt_list = ws->utt_list; p.b_n_list = ws->n_list;
   p.b_done = ws->done; p.b_done_stride = ws->done_stride; p.b_done_word = ws->done_word;
   const int64_t waves = (int64_t)n_utt * p.b_sub;
   const dim3 grid((unsigned)((waves + 3) / 4));
-  p.b_chunk = ws->cols_per_wave > 0 ? ws->cols_per_wave : 0;
+  p.groups = lazy->plan.groups > 1 && lazy->plan.d_group_counts ? lazy->plan.groups : 0;
+  p.group_counts = p.groups ? lazy->plan.d_group_counts : nullptr;
+  p.b_chunk = (ws->cols_per_wave > 0 && !p.groups) ? ws->cols_per_wave : 0;   // (a grouped plan already spreads the band over `groups` wavefronts)
   p.b_nchunk = p.b_chunk > 0 ? (lazy->plan.max_cols + p.b_chunk - 1) / p.b_chunk : 1;
   const int64_t split_waves = waves * p.b_nchunk;
-  { const char *e = getenv("MFA_GMM_NOSTORE"); p.dbg_nostore = (e && e[0] == '1') ? 1 : 0; }
-  { const char *e = getenv("MFA_GMM_XCD"); p.b_xcd = (p.b_chunk == 0 && e && e[0] == '1') ? 1 : 0; }
-  const dim3 split_grid((unsigned)((split_waves + 3) / 4) * (p.b_xcd ? 8u : 1u));
+  p.b_split = p.groups > 1 ? 1 : 0;
+  const dim3 split_grid((unsigned)((split_waves + 3) / 4) * (unsigned)(p.b_split ? p.groups : 1));
   const int m8 = c->kpad / 8;
   const char *bf = getenv("MFA_GMM_BF16");
   const char *hf = getenv("MFA_GMM_F16");
@@ -2381,6 +2475,7 @@ int mfa_gmm_score_window(mfa_ctx *c, const MfaLazyScoring *lazy, const MfaWindow
       p.wh = (const uint4 *)c->d_wh; p.gch = c->d_gch; p.fscale = c->d_fscale;
       p.acc_scale_inv = 1.0f / c->gmm_acc_scale;
       p.redo_mode = 0;
+      if (c->xsplit_ready) { p.xsplit = (const uint4 *)c->d_xsplit; p.xsplit_bad = c->d_xsplit_bad; }
       if (m8 == 10) hipLaunchKernelGGL((gmm_band_kernel<5, 2>), split_grid, dim3(256), 0, c->stream, p);
       else hipLaunchKernelGGL((gmm_band_kernel<6, 2>), split_grid, dim3(256), 0, c->stream, p);
       p.redo_mode = 2;   // the sub-tiles the f16 pass flagged
@@ -2390,7 +2485,7 @@ int mfa_gmm_score_window(mfa_ctx *c, const MfaLazyScoring *lazy, const MfaWindow
     p.redo_mode = 0;
     p.b_skip0 = 1;
   }
-  p.b_xcd = 0;   // (the f32 band kernel keeps one wavefront per sub-tile)
+  p.b_split = 0;   // (the f32 band kernel keeps one wavefront per sub-tile and walks the runs of class 0 itself)
   const bool f32_classes = c->has_multi_block || c->has_slot_class[4];   // pdfs of more than 32 Gaussians, single Gaussians
   if (!p.b_skip0 || f32_classes) {
     if (m8 <= 10) hipLaunchKernelGGL((gmm_band_f32_kernel<10>), grid, dim3(256), 0, c->stream, p);

@@ -1313,6 +1313,7 @@ int align_impl(mfa_ctx *c, const mfa_graph_batch *g, const float *d_loglikes, co
   // With the normal beam a frame rarely holds more than a few dozen tokens, so every utterance is first decoded with
   // small tables (kSmallTokens); the few that overflow them are marked ST_GROW and decoded again, from scratch and with
   // the same beam, at the caller's full capacity.  Then the retry-beam pass for utterances that did not reach a final state.
+  if (lazy && mfa_gmm_presplit(c, lazy, d_frame_off, n_utt, total_frames) != 0) return -1;
   struct Launch { int pass, N, C, code, grow; int N2 = 0, C2 = 0; };   // N2 > 0: a large tier redoes single windows
   std::vector<Launch> plan;
   // First-tier capacity.  With the hashed state→slot table nothing in the decoder's LDS scales with the graph: 64 tokens
@@ -1419,7 +1420,8 @@ int align_impl(mfa_ctx *c, const mfa_graph_batch *g, const float *d_loglikes, co
       for (int t0 = 0; t0 < lazy->max_frames; t0 += K) {
         MfaWindowScore ws;
         ws.t_begin = t0; ws.window = K; ws.band = p.band; ws.utt_list = p.utt_list; ws.n_list = p.n_list;
-        ws.cols_per_wave = L.code == 0 ? 0 : 32;   // list passes: few utterances, wide bands — spread the columns over wavefronts
+        ws.cols_per_wave = L.code == 0 ? 0 : 32;
+        { const char *e = getenv("MFA_GMM_CHUNK"); if (e && atoi(e) > 0 && L.code == 0) ws.cols_per_wave = atoi(e); }   // experiment   // list passes: few utterances, wide bands — spread the columns over wavefronts
         ws.done = (const int32_t *)(base + w.vstate); ws.done_stride = (int)(sizeof(VitState) / 4); ws.done_word = 2;
         if (mfa_gmm_score_window(c, lazy, &ws, d_frame_off, n_utt, d_ll_off, (float *)d_loglikes) != 0) return -1;
         MFA_DEBUG_POINT(c, "scored window t0=%d K=%d pass=%d code=%d N=%d C=%d", t0, K, ps, L.code, L.N, L.C);
@@ -1451,6 +1453,7 @@ int align_impl(mfa_ctx *c, const mfa_graph_batch *g, const float *d_loglikes, co
     }
     MFA_HIP_CHECK(c, hipGetLastError());
   }
+  c->xsplit_ready = false;
   hipLaunchKernelGGL(finalize_pending_kernel, dim3((n_utt + 255) / 256), dim3(256), 0, c->stream, d_status, n_utt);
   MFA_HIP_CHECK(c, hipGetLastError());
   return 0;

@@ -8,6 +8,7 @@ but operate on ragged batches resident in HBM instead of ark/scp files between p
 """
 from __future__ import annotations
 
+import os
 import ctypes as C
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence
@@ -51,13 +52,17 @@ class PackedGraphs:
     # source states, and {BFS depth, longest-path depth} of every graph state
     pdf_last_depth: Optional[torch.Tensor] = None         # int32 [ΣP_u]
     state_depth: Optional[torch.Tensor] = None            # int32 [ΣS_u, 2]
+    # class-0 columns laid out in `groups` runs (pdf id mod groups), one per XCD of the scoring kernel: columns per run
+    groups: int = 1
+    group_counts: Optional[torch.Tensor] = None           # int32 [n_utt, groups]
 
     def plan(self) -> ScorePlan:
         if self.pdf_last_depth is None or self.state_depth is None or self.pdf_first_frame is None:
             raise _lib.MfaHipError("these graphs were packed without depth keys (lazy scoring needs them)")
         return ScorePlan(self.pdf_list.data_ptr(), self.pdf_off.data_ptr(), self.class_counts.data_ptr(),
                          self.pdf_first_frame.data_ptr(), self.pdf_last_depth.data_ptr(), self.state_depth.data_ptr(),
-                         int(np.diff(self.pdf_off_host).max()) if self.n_utt else 0)
+                         int(np.diff(self.pdf_off_host).max()) if self.n_utt else 0, int(self.groups),
+                         self.group_counts.data_ptr() if self.group_counts is not None else None)
 
     def struct(self) -> GraphBatch:
         t = self.tensors
@@ -315,7 +320,8 @@ class AlignmentEngine:
         """True for graphs the wavefront-parallel decoder does not take: epsilon input arcs, a state with > 64 arcs."""
         return bool(fst.num_arcs and (np.any(fst.arcs["ilabel"] == 0) or int(np.diff(fst.arc_offsets).max()) > 64))
 
-    def pack_graphs(self, fsts: Sequence[Fst], tm: TransitionModel, cluster_gap: Optional[int] = 32) -> PackedGraphs:
+    def pack_graphs(self, fsts: Sequence[Fst], tm: TransitionModel, cluster_gap: Optional[int] = 32,
+                    groups: Optional[int] = None) -> PackedGraphs:
         """Concatenate per-utterance graphs (with transition probabilities already applied) into the device layout.
 
         Score columns: one per (pdf, depth cluster) of the utterance.  A pdf whose arcs leave states far apart in the graph
@@ -323,7 +329,12 @@ class AlignmentEngine:
         more than ``cluster_gap``, or lie in different ``cluster_gap``-wide depth ranges, start a new column — so that the
         lazy-scoring band, which is a range of graph depths, does not have to keep the pdf alive for everything in
         between (optional silence after every word would otherwise chain into one column spanning the utterance).
-        ``cluster_gap=None``: one column per pdf."""
+        ``cluster_gap=None``: one column per pdf.
+
+        ``groups`` (default 8, env MFA_PLAN_GROUPS): the single-block pdfs' columns are laid out in that many runs — pdf id
+        mod groups — so that the lazy scoring kernel can give each run to one XCD (mfa_build_score_plan_grouped)."""
+        if groups is None:
+            groups = int(os.environ.get("MFA_PLAN_GROUPS", "8"))
         n = len(fsts)
         S = np.array([f.num_states for f in fsts], dtype=np.int64)
         A = np.array([f.num_arcs for f in fsts], dtype=np.int64)
@@ -339,7 +350,7 @@ class AlignmentEngine:
             raise _lib.MfaHipError(f"a graph state has {max_deg} arcs; the device decoder supports at most 64")
         pdf_of_arc = tm.id2pdf[arcs["ilabel"]]
         cols = np.empty(arcs.shape[0], dtype=np.int32)
-        pdf_lists, counts, first_frames, last_depths, state_depths = [], [], [], [], []
+        pdf_lists, counts, first_frames, last_depths, state_depths, group_counts = [], [], [], [], [], []
         span = 0 if cluster_gap is None else int(cluster_gap)
         n_cols = C.c_int32(0)
         if self.slot_class is None:
@@ -356,11 +367,13 @@ class AlignmentEngine:
             col = np.empty(na, dtype=np.int32)
             cp, cf, cl = np.empty(na, dtype=np.int32), np.empty(na, dtype=np.int32), np.empty(na, dtype=np.int32)
             cc = np.zeros(6, dtype=np.int32)
+            gc = np.zeros(groups, dtype=np.int32)
             # columns (pdf, depth cluster) in kernel order, their depth keys, and every arc's column: one host call
-            rc = self.lib.mfa_build_score_plan(f.num_states, f_off.ctypes.data, f_nxt.ctypes.data, f_pdf.ctypes.data,
-                                               int(f.start), int(pdf_class.shape[0]), pdf_class.ctypes.data, span,
-                                               sd.ctypes.data, col.ctypes.data, cp.ctypes.data, cf.ctypes.data,
-                                               cl.ctypes.data, cc.ctypes.data, C.byref(n_cols))
+            rc = self.lib.mfa_build_score_plan_grouped(f.num_states, f_off.ctypes.data, f_nxt.ctypes.data, f_pdf.ctypes.data,
+                                                       int(f.start), int(pdf_class.shape[0]), pdf_class.ctypes.data, span,
+                                                       groups, sd.ctypes.data, col.ctypes.data, cp.ctypes.data,
+                                                       cf.ctypes.data, cl.ctypes.data, cc.ctypes.data, gc.ctypes.data,
+                                                       C.byref(n_cols))
             if rc != 0:
                 raise _lib.MfaHipError(f"mfa_build_score_plan: utterance {u}: " +
                                        ("a pdf id outside the loaded model" if rc == -2 else "malformed graph"))
@@ -368,6 +381,7 @@ class AlignmentEngine:
             cols[a0:a1] = col
             pdf_lists.append(cp[:k].copy())
             counts.append(cc)
+            group_counts.append(gc)
             first_frames.append(cf[:k].copy())
             last_depths.append(cl[:k].copy())
             state_depths.append(sd)
@@ -384,7 +398,8 @@ class AlignmentEngine:
                             self._dev(pdf_off), self._dev(np.stack(counts).astype(np.int32)), pdf_off, pdf_lists,
                             self._dev(np.concatenate(first_frames).astype(np.int32)), first_frames,
                             self._dev(np.concatenate(last_depths).astype(np.int32)),
-                            self._dev(np.concatenate(state_depths).astype(np.int32)))
+                            self._dev(np.concatenate(state_depths).astype(np.int32)), groups,
+                            self._dev(np.stack(group_counts).astype(np.int32)) if groups > 1 else None)
 
     def align(self, graphs: PackedGraphs, loglikes: torch.Tensor, ll_off: np.ndarray, ll_cols: torch.Tensor,
               frame_off: np.ndarray, beam: float = 10.0, retry_beam: float = 40.0, acoustic_scale: float = 0.1,

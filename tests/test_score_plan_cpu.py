@@ -10,7 +10,7 @@ from montreal_forced_aligner_amd import _lib
 from tests.test_gpu_parity import _random_graph  # plain numpy graph generator (module import needs no GPU)
 
 
-def _plan(f, pdf_of_arc, pdf_class, span):
+def _plan(f, pdf_of_arc, pdf_class, span, groups=1):
     lib = _lib.lib()
     na = f.num_arcs
     off = np.ascontiguousarray(f.arc_offsets, dtype=np.int32)
@@ -21,26 +21,41 @@ def _plan(f, pdf_of_arc, pdf_class, span):
     col, cp, cf, cl = (np.empty(max(na, 1), np.int32) for _ in range(4))
     cc = np.zeros(6, np.int32)
     n = C.c_int32(0)
-    rc = lib.mfa_build_score_plan(f.num_states, off.ctypes.data, nxt.ctypes.data, pdf.ctypes.data, int(f.start), len(cls),
-                                  cls.ctypes.data, span, sd.ctypes.data, col.ctypes.data, cp.ctypes.data, cf.ctypes.data,
-                                  cl.ctypes.data, cc.ctypes.data, C.byref(n))
+    gc = np.zeros(groups, np.int32)
+    if groups == 1:
+        rc = lib.mfa_build_score_plan(f.num_states, off.ctypes.data, nxt.ctypes.data, pdf.ctypes.data, int(f.start), len(cls),
+                                      cls.ctypes.data, span, sd.ctypes.data, col.ctypes.data, cp.ctypes.data, cf.ctypes.data,
+                                      cl.ctypes.data, cc.ctypes.data, C.byref(n))
+        gc[0] = cc[0]
+    else:
+        rc = lib.mfa_build_score_plan_grouped(f.num_states, off.ctypes.data, nxt.ctypes.data, pdf.ctypes.data, int(f.start),
+                                              len(cls), cls.ctypes.data, span, groups, sd.ctypes.data, col.ctypes.data,
+                                              cp.ctypes.data, cf.ctypes.data, cl.ctypes.data, cc.ctypes.data, gc.ctypes.data,
+                                              C.byref(n))
     assert rc == 0
     k = n.value
-    return sd, col[:na], cp[:k], cf[:k], cl[:k], cc
+    return sd, col[:na], cp[:k], cf[:k], cl[:k], cc, gc
 
 
-def _check_graph(rng, f, pdf_of_arc, pdf_class, span, trials=30):
-    sd, col, cp, cf, cl, cc = _plan(f, pdf_of_arc, pdf_class, span)
+def _check_graph(rng, f, pdf_of_arc, pdf_class, span, trials=30, groups=1):
+    sd, col, cp, cf, cl, cc, gc = _plan(f, pdf_of_arc, pdf_class, span, groups)
+    # runs the band rule is applied to: class 0 split into `groups` runs (pdf id mod groups), the other classes whole
+    assert gc.sum() == cc[0]
+    run_sizes = list(gc) + list(cc[1:])
+    run_class = [0] * groups + [1, 2, 3, 4, 5]
+    run_group = list(range(groups)) + [0] * 5
     S = f.num_states
     src = np.repeat(np.arange(S), np.diff(f.arc_offsets))
     nxt = f.arcs["nextstate"].astype(np.int64)
     # columns: right pdf, class-sorted, keys non-decreasing inside a class, first = min depth of the column's sources
     assert np.array_equal(cp[col], pdf_of_arc)
     assert cc.sum() == len(cp)
-    bounds = np.concatenate([[0], np.cumsum(cc)])
-    for k in range(6):
+    bounds = np.concatenate([[0], np.cumsum(run_sizes)])
+    for k in range(len(run_sizes)):
         seg = slice(bounds[k], bounds[k + 1])
-        assert np.all(pdf_class[cp[seg]] == k)
+        assert np.all(pdf_class[cp[seg]] == run_class[k])
+        if run_class[k] == 0:
+            assert np.all(cp[seg] % groups == run_group[k])
         assert np.all(np.diff(cf[seg]) >= 0) and np.all(np.diff(cl[seg]) >= 0)
     # BFS depth by relaxation; reachable set of the start state
     INF = 1 << 30
@@ -64,8 +79,8 @@ def _check_graph(rng, f, pdf_of_arc, pdf_class, span, trials=30):
     assert np.all(m[nxt[ok]] >= m[src[ok]]) and np.all(m[reach0] <= d[reach0])
     # brute force: random live sets, random K
     adj = [nxt[f.arc_offsets[s]: f.arc_offsets[s + 1]] for s in range(S)]
-    cls_of_col = pdf_class[cp]
-    pos_in_cls = np.arange(len(cp)) - bounds[cls_of_col]
+    run_of_col = np.searchsorted(bounds, np.arange(len(cp)), side="right") - 1
+    pos_in_run = np.arange(len(cp)) - bounds[run_of_col]
     states = np.nonzero(reach0)[0]
     for _ in range(trials):
         K = int(rng.choice([1, 2, 5, 16, 64]))
@@ -82,13 +97,13 @@ def _check_graph(rng, f, pdf_of_arc, pdf_class, span, trials=30):
         need = set()
         for s in seen:
             need.update(int(c) for c in col[f.arc_offsets[s]: f.arc_offsets[s + 1]])
-        for k in range(6):
+        for k in range(len(run_sizes)):
             seg = slice(bounds[k], bounds[k + 1])
             lo_idx = int((cl[seg] < lo).sum())
             hi_idx = int((cf[seg] <= hi).sum())
             for c_ in need:
-                if cls_of_col[c_] == k:
-                    assert lo_idx <= pos_in_cls[c_] < hi_idx, (K, lo, hi, c_, cf[c_], cl[c_])
+                if run_of_col[c_] == k:
+                    assert lo_idx <= pos_in_run[c_] < hi_idx, (K, lo, hi, c_, cf[c_], cl[c_])
 
 
 def test_band_rule_is_a_superset_on_random_graphs(fx):
@@ -98,7 +113,7 @@ def test_band_rule_is_a_superset_on_random_graphs(fx):
     for trial in range(25):
         f = _random_graph(rng, tm, int(rng.choice([3, 8, 40, 150])))
         pdf_of_arc = tm.id2pdf[f.arcs["ilabel"]].astype(np.int32)
-        _check_graph(rng, f, pdf_of_arc, pdf_class, span=int(rng.choice([0, 2, 8, 32])))
+        _check_graph(rng, f, pdf_of_arc, pdf_class, span=int(rng.choice([0, 2, 8, 32])), groups=int(rng.choice([1, 2, 8])))
 
 
 def test_band_rule_on_a_training_graph_and_column_clusters(fx):
@@ -108,10 +123,11 @@ def test_band_rule_on_a_training_graph_and_column_clusters(fx):
     pdf_of_arc = tm.id2pdf[f.arcs["ilabel"]].astype(np.int32)
     pdf_class = np.full(tm.num_pdfs, 5, np.int32)
     _check_graph(rng, f, pdf_of_arc, pdf_class, span=32, trials=60)
+    _check_graph(rng, f, pdf_of_arc, np.zeros(tm.num_pdfs, np.int32), span=32, trials=60, groups=8)   # all single-block pdfs, 8 runs
     # one column per pdf without clustering; more columns, each of bounded depth extent, with it
-    sd, col, cp0, cf0, cl0, cc0 = _plan(f, pdf_of_arc, pdf_class, 0)
+    sd, col, cp0, cf0, cl0, cc0, _g = _plan(f, pdf_of_arc, pdf_class, 0)
     assert len(cp0) == len(np.unique(pdf_of_arc))
-    sd, col, cp, cf, cl, cc = _plan(f, pdf_of_arc, pdf_class, 32)
+    sd, col, cp, cf, cl, cc, _g = _plan(f, pdf_of_arc, pdf_class, 32)
     assert len(cp) > len(cp0)                       # the text repeats its words: repeated pdfs got their own columns
     src = np.repeat(np.arange(f.num_states), np.diff(f.arc_offsets))
     ext_lo = np.full(len(cp), 1 << 30); ext_hi = np.zeros(len(cp), np.int64)
