@@ -1578,7 +1578,19 @@ __global__ __launch_bounds__(256, 2) void gmm_band_kernel(GmmParams p) {
     hi_c[0] = min(hi_c[0], lo_c[0] + p.b_chunk);
     if (chunk != 0) { hi_c[2] = lo_c[2]; hi_c[3] = lo_c[3]; hi_c[4] = lo_c[4]; }
   }
-  if (grp > 0) { hi_c[2] = lo_c[2]; hi_c[3] = lo_c[3]; hi_c[4] = lo_c[4]; }    // the small-slot classes stay with run 0's wavefront
+  if (p.b_split) {
+    // the small-slot classes have no runs: their band is cut into `groups` pieces of whole virtual blocks (32 / slot pdfs),
+    // one per wavefront of the sub-tile — all of them on run 0's wavefront would be all of them on one XCD
+#pragma unroll
+    for (int cls = 2; cls < 5; cls++) {
+      const int kp = cls == 2 ? 2 : (cls == 3 ? 4 : 8);
+      const int jb0 = lo_c[cls] / kp, jb1 = (hi_c[cls] + kp - 1) / kp;
+      const int per = (jb1 - jb0 + p.groups - 1) / p.groups;
+      const int a = jb0 + grp * per, b = min(jb1, a + per);
+      if (a >= b) hi_c[cls] = lo_c[cls];
+      else { lo_c[cls] = max(lo_c[cls], a * kp); hi_c[cls] = min(hi_c[cls], b * kp); }
+    }
+  }
   const int lo = lo_c[0], hi = hi_c[0];
   if (lo >= hi && lo_c[2] >= hi_c[2] && lo_c[3] >= hi_c[3] && lo_c[4] >= hi_c[4]) {
     if (kHalf && lane == 0) *redo_flag = 0;
