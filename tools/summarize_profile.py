@@ -27,7 +27,8 @@ def short(name):
     if "gmm_split_single_kernel" in name:   # <steps, pieces>: 2 = f16×2 pass, 3 = bf16×3 pass (or its redo sweep)
         pieces = name.split("gmm_split_single_kernel<")[-1].split(">")[0].replace(" ", "").split(",")[-1] if "<" in name else "?"
         return {"2": "gmm_split_single_kernel_f16", "3": "gmm_split_single_kernel_bf16"}.get(pieces, "gmm_split_single_kernel")
-    for k in ("gmm_split_single_kernel", "gmm_bf16_single_kernel", "gmm_bf16_kernel", "gmm_kernel", "viterbi_kernel", "mfcc_kernel", "feats_lda_kernel", "feats_kernel", "cmvn_utt_kernel", "cmvn_spk_kernel",
+    for k in ("gmm_split_single_kernel", "gmm_bf16_single_kernel", "gmm_bf16_kernel", "gmm_presplit_kernel", "gmm_kernel",
+              "viterbi_small_kernel", "viterbi_finish_kernel", "viterbi_kernel", "mfcc_kernel", "feats_lda_kernel", "feats_kernel", "cmvn_utt_kernel", "cmvn_spk_kernel",
               "arcnext_kernel", "collect_pending_kernel", "finalize_pending_kernel", "gmm_max_first_frame_kernel"):
         if k in name:
             return k
@@ -85,7 +86,8 @@ for k, e in summary["kernels"].items():
 # WRITE_SIZE is exact for 16-byte-per-lane and dword-per-lane stores.  Infinity-Cache hits are counted (fabric side).
 stage_of = {"gmm_band_kernel_f16": "gmm", "gmm_band_kernel_bf16": "gmm", "gmm_band_f32_kernel": "gmm",
             "gmm_split_single_kernel_f16": "gmm", "gmm_split_single_kernel_bf16": "gmm", "gmm_kernel": "gmm", "gmm_bf16_kernel": "gmm",
-            "viterbi_kernel": "viterbi", "mfcc_kernel": "mfcc", "feats_lda_kernel": "feats", "feats_kernel": "feats"}
+            "gmm_presplit_kernel": "gmm", "viterbi_kernel": "viterbi", "viterbi_small_kernel": "viterbi", "viterbi_finish_kernel": "viterbi",
+            "mfcc_kernel": "mfcc", "feats_lda_kernel": "feats", "feats_kernel": "feats"}
 pmc_steps = 5.0   # 3 warm-up + 1 fill probe + 1 timed step in each PMC run (the model-training set-up launches are tiny)
 traffic = {}
 for k, e in summary["kernels"].items():
