@@ -64,6 +64,10 @@ struct mfa_ctx {
   void *d_xsplit = nullptr;    // lazy scoring: f16 hi/lo operands of every 64-frame tile in register layout (gmm_presplit_kernel)
   int *d_xsplit_bad = nullptr; // … and the tile's "a scaled feature left the f16 range" flag
   int64_t xsplit_tiles = 0;
+  int32_t *d_col_row0 = nullptr;   // lazy scoring: first packed model row of every score column of the batch (row0[pdf_list[j]])
+  int64_t col_row0_cap = 0;
+  int32_t *d_band_ranges = nullptr; // [n_utt][11][2]: per window, the band's index range in each run of class 0 and in classes 2..4
+  int64_t band_ranges_cap = 0;
   bool xsplit_ready = false;   // d_xsplit holds the operands of the batch mfa_align_features_batch is working on
   float *d_gc = nullptr;       // [num_rows]
   int32_t *d_row0 = nullptr;   // [num_pdfs] first packed row

@@ -83,6 +83,8 @@ struct GmmParams {
   int b_chunk, b_nchunk;       // gmm_band_kernel: columns per wavefront (0 = the whole band) and chunks per sub-tile
   const uint4 *xsplit;         // band kernel: pre-split f16 operands [tile][2][kSteps][2][64 lanes] (gmm_presplit_kernel) or NULL
   const int *xsplit_bad;       // [tile]: 1 = a scaled feature of the tile left the f16 range (the bf16×3 pass takes it)
+  const int32_t *col_row0;     // band kernel: row0[pdf_list[j]] of every column of the batch (gmm_col_rows_kernel) or NULL
+  int32_t *ranges;             // [n_utt][kRangeSlots][2] band index ranges of the window (gmm_band_ranges_kernel) or NULL
   // Grouped plans (mfa_build_score_plan_grouped): class 0 of every utterance is laid out in `groups` runs (pdf id mod groups),
   // each ordered by first depth.  gmm_band_kernel then runs `groups` wavefronts per sub-tile, wavefront x — in a workgroup
   // with blockIdx % groups == x, i.e. (groups = 8) always on the same XCD — scoring run x: that XCD's L2 only ever sees
@@ -1464,6 +1466,60 @@ __global__ __launch_bounds__(256, 2) void gmm_split_small_kernel(GmmParams p) {
   }
 }
 
+// Lazy scoring, once per batch: the first packed model row of every score column (saves the pdf id → row lookup, one
+// dependent load per model block and in every wavefront's start-up chain).
+__global__ void gmm_col_rows_kernel(GmmParams p, int32_t *out) {
+  const int utt = blockIdx.x;
+  const int64_t l0 = p.pdf_off[utt], l1 = p.pdf_off[utt + 1];
+  for (int64_t j = l0 + threadIdx.x; j < l1; j += blockDim.x) out[j] = p.row0[p.pdf_list[j]];
+}
+
+// Lazy scoring, once per window: the band's index range [lo, hi) in every run of class 0 (slots 0..groups-1; one run when the
+// plan is not grouped) and in classes 2, 3, 4 (slots 8, 9, 10), relative to the class's first column — what every scoring
+// wavefront of the sub-tile would otherwise search for itself (two dependent memory trips each).  One wavefront per utterance.
+constexpr int kRangeSlots = 11;
+__global__ __launch_bounds__(256) void gmm_band_ranges_kernel(GmmParams p) {
+  const int lane = threadIdx.x & 63;
+  const int utt = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (utt >= p.n_utt) return;
+  if (p.b_t_begin > 0 && p.b_done && p.b_done[(size_t)utt * p.b_done_stride + p.b_done_word] != 0) return;
+  const int64_t l0 = p.pdf_off[utt];
+  const int32_t *cc6 = p.class_counts + (size_t)utt * 6;
+  const Band bd = band_of(p, utt);
+  const int runs = p.groups > 1 ? p.groups : 1;
+  int32_t *out = p.ranges + (size_t)utt * kRangeSlots * 2;
+  int off = 0;
+  for (int slot = 0; slot < kRangeSlots; slot++) {
+    int cnt = 0, base = 0;     // the run searched, its first column relative to the class, the class's first column in `off`
+    if (slot < 8) {
+      if (slot >= runs) continue;
+      if (p.groups > 1) { const int32_t *gc = p.group_counts + (size_t)utt * p.groups; for (int g = 0; g < slot; g++) base += gc[g]; cnt = gc[slot]; }
+      else cnt = cc6[0];
+      off = 0;
+    } else {
+      off = cc6[0] + cc6[1];
+      for (int k = 2; k < slot - 6; k++) off += cc6[k];
+      cnt = cc6[slot - 6];
+    }
+    int nh = 0, nl = 0;
+    for (int i0 = 0; i0 < cnt; i0 += 256) {
+      int ff[4], ld[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int i = min(i0 + 64 * u + lane, cnt - 1);
+        ff[u] = p.first_frame[l0 + off + base + i]; ld[u] = p.last_depth[l0 + off + base + i];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const bool in = i0 + 64 * u + lane < cnt;
+        nh += __popcll(__ballot(in && ff[u] <= bd.hi));
+        nl += __popcll(__ballot(in && ld[u] < bd.lo));
+      }
+    }
+    if (lane == 0) { out[2 * slot] = base + min(nl, nh); out[2 * slot + 1] = base + nh; }
+  }
+}
+
 // Index of the 64-frame tile `tile` of utterance `utt` in the pre-split operand buffer: ⌊frame_off/64⌋ + utt + tile is
 // monotone and leaves every utterance room for ⌈T/64⌉ tiles without a separate offset table.
 __device__ __forceinline__ int64_t xsplit_tile_index(int64_t frame_off_u, int utt, int tile) { return (frame_off_u >> 6) + utt + tile; }
@@ -1537,10 +1593,40 @@ __global__ __launch_bounds__(256, 2) void gmm_band_kernel(GmmParams p) {
   const int32_t *list = p.pdf_list + l0;
   const int32_t *cc6 = p.class_counts + (size_t)utt * 6;
   const Band bd = band_of(p, utt);
+  // The pre-split operands depend on nothing but the sub-tile: requested first, they travel while the band is looked up
+  // (volatile: the loads stay here instead of sinking below the early exit).
+  op8 b[2][kSteps][kPieces];
+  bool bad = false;
+  const bool presplit = kHalf && p.xsplit != nullptr;
+  if (presplit) {
+    const int64_t ti = xsplit_tile_index(f0, utt, t_base >> 6);
+    const volatile uint4 *src = p.xsplit + ti * (2 * kSteps * 2 * 64) + lane;
+#pragma unroll
+    for (int n = 0; n < 2; n++)
+#pragma unroll
+      for (int s_ = 0; s_ < kSteps; s_++)
+#pragma unroll
+        for (int q = 0; q < kPieces; q++) {
+          uint4 v;
+          const volatile uint4 *a4 = src + ((n * kSteps + s_) * 2 + (q & 1)) * 64;
+          v.x = a4->x; v.y = a4->y; v.z = a4->z; v.w = a4->w;
+          b[n][s_][q] = __builtin_bit_cast(op8, v);
+        }
+    bad = p.xsplit_bad[ti] != 0;
+  }
   // band range [lo, hi) of every class this kernel scores: 0 (one 32-row block per pdf) and 2, 3, 4 (16-, 8-, 4-row slots);
   // classes 1 (pdfs of more than 32 Gaussians) and 5 (single Gaussians) are the f32 band kernel's
   int lo_c[5], hi_c[5], base_c[5];
-  {
+  if (p.ranges) {   // looked up once per utterance and window by gmm_band_ranges_kernel
+    const int32_t *rg = p.ranges + (size_t)utt * kRangeSlots * 2;
+    int off = 0;
+#pragma unroll
+    for (int cls = 0; cls < 5; cls++) {
+      const int slot = cls == 0 ? grp : cls + 6;
+      base_c[cls] = off; off += cc6[cls];
+      lo_c[cls] = cls == 1 ? 0 : rg[2 * slot]; hi_c[cls] = cls == 1 ? 0 : rg[2 * slot + 1];
+    }
+  } else {
     int off = 0;
 #pragma unroll
     for (int cls = 0; cls < 5; cls++) {
@@ -1599,21 +1685,7 @@ __global__ __launch_bounds__(256, 2) void gmm_band_kernel(GmmParams p) {
 #ifdef GMM_BAND_STAMPS
   const unsigned long long st1 = wall_clock64();
 #endif
-  op8 b[2][kSteps][kPieces];
-  bool bad = false;
-  if (kHalf && p.xsplit) {                                             // operands split once per utterance by gmm_presplit_kernel
-    const int64_t ti = xsplit_tile_index(f0, utt, t_base >> 6);
-    const uint4 *src = p.xsplit + ti * (2 * kSteps * 2 * 64) + lane;
-#pragma unroll
-    for (int n = 0; n < 2; n++)
-#pragma unroll
-      for (int s_ = 0; s_ < kSteps; s_++)
-#pragma unroll
-        for (int q = 0; q < kPieces; q++) b[n][s_][q] = __builtin_bit_cast(op8, src[((n * kSteps + s_) * 2 + (q & 1)) * 64]);
-    bad = p.xsplit_bad[ti] != 0;
-  } else {
-    bad = split_features<kSteps, kPieces>(p, f0, T, t_base, col, h, b);
-  }
+  if (!presplit) bad = split_features<kSteps, kPieces>(p, f0, T, t_base, col, h, b);
 #ifdef GMM_BAND_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const unsigned long long st2 = wall_clock64();
@@ -1647,7 +1719,9 @@ __global__ __launch_bounds__(256, 2) void gmm_band_kernel(GmmParams p) {
     const uint4 *wsrc = (kHalf ? p.wh : p.wb) + lane;
     const float *gsrc = (kHalf ? p.gch : p.gc) + 4 * h;
     const int last = hi - 1;
-    auto block_at = [&](int jj) { return __builtin_amdgcn_readfirstlane(p.row0[list[min(jj, last)]]) >> 5; };
+    const int32_t *crow = p.col_row0 ? p.col_row0 + l0 : nullptr;     // first model row per column (one load instead of two dependent ones)
+    auto row0_at = [&](int jj) { return crow ? crow[min(jj, last)] : p.row0[list[min(jj, last)]]; };
+    auto block_at = [&](int jj) { return __builtin_amdgcn_readfirstlane(row0_at(jj)) >> 5; };
     op8 a[kSteps][kPieces];
     f32x4 g[4];
     {
@@ -1662,7 +1736,7 @@ __global__ __launch_bounds__(256, 2) void gmm_band_kernel(GmmParams p) {
     }
     int blk_next = block_at(lo + 1);
     for (int j = lo; j < hi; j++) {
-      const int x_next2 = p.row0[list[min(j + 2, last)]];      // lookup two blocks ahead (oldest entry of the vmcnt queue)
+      const int x_next2 = row0_at(j + 2);                      // lookup two blocks ahead (oldest entry of the vmcnt queue)
       f32x16 init, acc[2];
 #pragma unroll
       for (int rr = 0; rr < 16; rr++) init[rr] = g[rr >> 2][rr & 3];
@@ -1720,7 +1794,7 @@ __global__ __launch_bounds__(256, 2) void gmm_band_kernel(GmmParams p) {
     const int jb0 = lo_s / kPdfs, jb1 = (hi_s + kPdfs - 1) / kPdfs;
     auto row_of = [&](int jb) -> int {                 // this lane's packed row in virtual block jb (two dependent loads)
       const int idx = min(jb, jb1 - 1) * kPdfs + my_k;
-      return idx < hi_s ? p.row0[list[base + idx]] + my_r : p.num_rows;
+      return idx < hi_s ? (p.col_row0 ? p.col_row0[l0 + base + idx] : p.row0[list[base + idx]]) + my_r : p.num_rows;
     };
     auto src_of = [&](int row) { return wsrc + (size_t)(row >> 5) * kUnits + (row & 31) + 32 * h; };
     op8 a[kSteps][kPieces];
@@ -2437,6 +2511,18 @@ int mfa_gmm_presplit(mfa_ctx *c, const MfaLazyScoring *lazy, const int64_t *d_fr
   else hipLaunchKernelGGL((gmm_presplit_kernel<6>), grid, dim3(256), 0, c->stream, p, (uint4 *)c->d_xsplit, c->d_xsplit_bad, tiles_per_utt);
   MFA_HIP_CHECK(c, hipGetLastError());
   c->xsplit_ready = true;
+  // first model row of every score column of the batch
+  const int64_t cols_cap = (int64_t)n_utt * std::max(1, lazy->plan.max_cols);
+  if (c->col_row0_cap < cols_cap) {
+    MFA_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    if (c->d_col_row0) (void)hipFree(c->d_col_row0);
+    c->d_col_row0 = nullptr; c->col_row0_cap = 0;
+    MFA_HIP_CHECK(c, hipMalloc((void **)&c->d_col_row0, (size_t)cols_cap * sizeof(int32_t)));
+    c->col_row0_cap = cols_cap;
+  }
+  p.row0 = c->d_row0; p.pdf_list = lazy->plan.d_pdf_list; p.pdf_off = lazy->plan.d_pdf_off;
+  hipLaunchKernelGGL(gmm_col_rows_kernel, dim3(n_utt), dim3(256), 0, c->stream, p, c->d_col_row0);
+  MFA_HIP_CHECK(c, hipGetLastError());
   return 0;
 }
 
@@ -2483,11 +2569,23 @@ int mfa_gmm_score_window(mfa_ctx *c, const MfaLazyScoring *lazy, const MfaWindow
     }
     p.redo = c->d_gmm_redo;
     p.wb = (const uint4 *)c->d_wb;
+    {   // the band's index ranges, once per utterance (instead of once per scoring wavefront)
+      const int64_t need = (int64_t)n_utt * kRangeSlots * 2;
+      if (c->band_ranges_cap < need) {
+        MFA_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+        if (c->d_band_ranges) (void)hipFree(c->d_band_ranges);
+        c->d_band_ranges = nullptr; c->band_ranges_cap = 0;
+        MFA_HIP_CHECK(c, hipMalloc((void **)&c->d_band_ranges, (size_t)need * sizeof(int32_t)));
+        c->band_ranges_cap = need;
+      }
+      p.ranges = c->d_band_ranges;
+      hipLaunchKernelGGL(gmm_band_ranges_kernel, dim3((unsigned)((n_utt + 3) / 4)), dim3(256), 0, c->stream, p);
+    }
     if (f16_ok) {
       p.wh = (const uint4 *)c->d_wh; p.gch = c->d_gch; p.fscale = c->d_fscale;
       p.acc_scale_inv = 1.0f / c->gmm_acc_scale;
       p.redo_mode = 0;
-      if (c->xsplit_ready) { p.xsplit = (const uint4 *)c->d_xsplit; p.xsplit_bad = c->d_xsplit_bad; }
+      if (c->xsplit_ready) { p.xsplit = (const uint4 *)c->d_xsplit; p.xsplit_bad = c->d_xsplit_bad; p.col_row0 = c->d_col_row0; }
       if (m8 == 10) hipLaunchKernelGGL((gmm_band_kernel<5, 2>), split_grid, dim3(256), 0, c->stream, p);
       else hipLaunchKernelGGL((gmm_band_kernel<6, 2>), split_grid, dim3(256), 0, c->stream, p);
       p.redo_mode = 2;   // the sub-tiles the f16 pass flagged
