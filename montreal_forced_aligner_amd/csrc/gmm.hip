@@ -1719,9 +1719,19 @@ __global__ __launch_bounds__(256, 2) void gmm_band_kernel(GmmParams p) {
     const uint4 *wsrc = (kHalf ? p.wh : p.wb) + lane;
     const float *gsrc = (kHalf ? p.gch : p.gc) + 4 * h;
     const int last = hi - 1;
-    const int32_t *crow = p.col_row0 ? p.col_row0 + l0 : nullptr;     // first model row per column (one load instead of two dependent ones)
-    auto row0_at = [&](int jj) { return crow ? crow[min(jj, last)] : p.row0[list[min(jj, last)]]; };
-    auto block_at = [&](int jj) { return __builtin_amdgcn_readfirstlane(row0_at(jj)) >> 5; };
+    // First model row per column, precomputed per batch: ONE load.  The pdf id → row chain it replaces (row0[list[j]]) made
+    // the second load wait for the first — the youngest entry of the in-order vmcnt queue — i.e. drained every outstanding
+    // operand load of the next block at the top of each block.
+    const int32_t *crow = p.col_row0 + l0;
+    auto row0_at = [&](int jj) { return crow[min(jj, last)]; };
+    auto block_at = [&](int jj) {
+      const int blk = __builtin_amdgcn_readfirstlane(row0_at(jj)) >> 5;
+#ifdef BAND_DIAG_BLKMOD   // timing-only builds (-DBAND_DIAG_BLKMOD=8): every block from a cache-resident handful (wrong scores)
+      return blk % BAND_DIAG_BLKMOD;
+#else
+      return blk;
+#endif
+    };
     op8 a[kSteps][kPieces];
     f32x4 g[4];
     {
@@ -1749,6 +1759,9 @@ __global__ __launch_bounds__(256, 2) void gmm_band_kernel(GmmParams p) {
 #pragma unroll
           for (int n = 0; n < 2; n++) {
             const f32x16 &cin = (s_ == 0 && t6 == 0) ? init : acc[n];
+#ifdef BAND_DIAG_NO_MFMA   // timing-only builds: one product per step instead of six (results wrong by construction)
+            if (t6 > 0) { if (s_ == 0 && t6 == 1) acc[n] = cin; continue; }
+#endif
             if constexpr (kHalf) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s_][pa[t6]], b[n][s_][pb[t6]], cin, 0, 0, 0);
             else acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s_][pa[t6]], b[n][s_][pb[t6]], cin, 0, 0, 0);
           }
@@ -1764,14 +1777,21 @@ __global__ __launch_bounds__(256, 2) void gmm_band_kernel(GmmParams p) {
         __builtin_amdgcn_sched_barrier(0);
       }
       blk_next = __builtin_amdgcn_readfirstlane(x_next2) >> 5;
+#ifdef BAND_DIAG_BLKMOD
+      blk_next %= BAND_DIAG_BLKMOD;
+#endif
       float mx[2], sum[2];
 #pragma unroll
       for (int n = 0; n < 2; n++) {
+#ifdef BAND_DIAG_NO_EPI   // timing-only builds: results are wrong by construction
+        mx[n] = acc[n][0] + acc[n][15]; sum[n] = 1.0f;
+#else
         float m = reg_max<0, 16>(acc[n]);
         m = fmaxf(m, swap32(m, h));
         float sv = reg_expsum_fast(acc[n], m, l2e_s);
         sv += swap32(sv, h);
         mx[n] = m; sum[n] = sv;
+#endif
       }
       const int jj = (j - lo) & 31;
       stage[(32 * h + col) * 33 + jj] = finish((h ? mx[1] : mx[0]) * inv_s, h ? sum[1] : sum[0]);
@@ -1794,7 +1814,7 @@ __global__ __launch_bounds__(256, 2) void gmm_band_kernel(GmmParams p) {
     const int jb0 = lo_s / kPdfs, jb1 = (hi_s + kPdfs - 1) / kPdfs;
     auto row_of = [&](int jb) -> int {                 // this lane's packed row in virtual block jb (two dependent loads)
       const int idx = min(jb, jb1 - 1) * kPdfs + my_k;
-      return idx < hi_s ? (p.col_row0 ? p.col_row0[l0 + base + idx] : p.row0[list[base + idx]]) + my_r : p.num_rows;
+      return idx < hi_s ? p.col_row0[l0 + base + idx] + my_r : p.num_rows;
     };
     auto src_of = [&](int row) { return wsrc + (size_t)(row >> 5) * kUnits + (row & 31) + 32 * h; };
     op8 a[kSteps][kPieces];
@@ -2484,6 +2504,21 @@ int mfa_gmm_lazy_supported(mfa_ctx *c) { return c->gmm_ready && (c->kpad == 80 |
 // Pre-split f16 operands of the whole batch (see gmm_presplit_kernel); mfa_gmm_score_window then hands them to the band kernel.
 int mfa_gmm_presplit(mfa_ctx *c, const MfaLazyScoring *lazy, const int64_t *d_frame_off, int n_utt, int64_t total_frames) {
   c->xsplit_ready = false;
+  {   // first model row of every score column of the batch (the band kernels read nothing else to find a block)
+    const int64_t cols_cap = (int64_t)n_utt * std::max(1, lazy->plan.max_cols);
+    if (c->col_row0_cap < cols_cap) {
+      MFA_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+      if (c->d_col_row0) (void)hipFree(c->d_col_row0);
+      c->d_col_row0 = nullptr; c->col_row0_cap = 0;
+      MFA_HIP_CHECK(c, hipMalloc((void **)&c->d_col_row0, (size_t)cols_cap * sizeof(int32_t)));
+      c->col_row0_cap = cols_cap;
+    }
+    GmmParams q;
+    memset(&q, 0, sizeof(q));
+    q.row0 = c->d_row0; q.pdf_list = lazy->plan.d_pdf_list; q.pdf_off = lazy->plan.d_pdf_off; q.n_utt = n_utt;
+    hipLaunchKernelGGL(gmm_col_rows_kernel, dim3(n_utt), dim3(256), 0, c->stream, q, c->d_col_row0);
+    MFA_HIP_CHECK(c, hipGetLastError());
+  }
   const char *bf = getenv("MFA_GMM_BF16");
   const char *hf = getenv("MFA_GMM_F16");
   const char *ps = getenv("MFA_GMM_PRESPLIT");
@@ -2511,18 +2546,6 @@ int mfa_gmm_presplit(mfa_ctx *c, const MfaLazyScoring *lazy, const int64_t *d_fr
   else hipLaunchKernelGGL((gmm_presplit_kernel<6>), grid, dim3(256), 0, c->stream, p, (uint4 *)c->d_xsplit, c->d_xsplit_bad, tiles_per_utt);
   MFA_HIP_CHECK(c, hipGetLastError());
   c->xsplit_ready = true;
-  // first model row of every score column of the batch
-  const int64_t cols_cap = (int64_t)n_utt * std::max(1, lazy->plan.max_cols);
-  if (c->col_row0_cap < cols_cap) {
-    MFA_HIP_CHECK(c, hipStreamSynchronize(c->stream));
-    if (c->d_col_row0) (void)hipFree(c->d_col_row0);
-    c->d_col_row0 = nullptr; c->col_row0_cap = 0;
-    MFA_HIP_CHECK(c, hipMalloc((void **)&c->d_col_row0, (size_t)cols_cap * sizeof(int32_t)));
-    c->col_row0_cap = cols_cap;
-  }
-  p.row0 = c->d_row0; p.pdf_list = lazy->plan.d_pdf_list; p.pdf_off = lazy->plan.d_pdf_off;
-  hipLaunchKernelGGL(gmm_col_rows_kernel, dim3(n_utt), dim3(256), 0, c->stream, p, c->d_col_row0);
-  MFA_HIP_CHECK(c, hipGetLastError());
   return 0;
 }
 
@@ -2569,6 +2592,7 @@ int mfa_gmm_score_window(mfa_ctx *c, const MfaLazyScoring *lazy, const MfaWindow
     }
     p.redo = c->d_gmm_redo;
     p.wb = (const uint4 *)c->d_wb;
+    p.col_row0 = c->d_col_row0;
     {   // the band's index ranges, once per utterance (instead of once per scoring wavefront)
       const int64_t need = (int64_t)n_utt * kRangeSlots * 2;
       if (c->band_ranges_cap < need) {
@@ -2585,7 +2609,7 @@ int mfa_gmm_score_window(mfa_ctx *c, const MfaLazyScoring *lazy, const MfaWindow
       p.wh = (const uint4 *)c->d_wh; p.gch = c->d_gch; p.fscale = c->d_fscale;
       p.acc_scale_inv = 1.0f / c->gmm_acc_scale;
       p.redo_mode = 0;
-      if (c->xsplit_ready) { p.xsplit = (const uint4 *)c->d_xsplit; p.xsplit_bad = c->d_xsplit_bad; p.col_row0 = c->d_col_row0; }
+      if (c->xsplit_ready) { p.xsplit = (const uint4 *)c->d_xsplit; p.xsplit_bad = c->d_xsplit_bad; }
       if (m8 == 10) hipLaunchKernelGGL((gmm_band_kernel<5, 2>), split_grid, dim3(256), 0, c->stream, p);
       else hipLaunchKernelGGL((gmm_band_kernel<6, 2>), split_grid, dim3(256), 0, c->stream, p);
       p.redo_mode = 2;   // the sub-tiles the f16 pass flagged
