@@ -79,7 +79,7 @@ struct GmmParams {
   const int32_t *b_utt_list; const int32_t *b_n_list;
   const int32_t *b_done; int b_done_stride, b_done_word;
   const int32_t *last_depth;   // parallel to pdf_list: running max (inside a class) of the longest-path depth of the pdf's sources
-  int b_skip0;                 // f32 band kernel: classes 0, 2, 3, 4 were scored by gmm_band_kernel (it keeps 1 and 5)
+  int b_skip0;                 // f32 band kernel: classes 0..4 were scored by gmm_band_kernel (it keeps 5: single Gaussians, f32-exact)
   int b_chunk, b_nchunk;       // gmm_band_kernel: columns per wavefront (0 = the whole band) and chunks per sub-tile
   const uint4 *xsplit;         // band kernel: pre-split f16 operands [tile][2][kSteps][2][64 lanes] (gmm_presplit_kernel) or NULL
   const int *xsplit_bad;       // [tile]: 1 = a scaled feature of the tile left the f16 range (the bf16×3 pass takes it)
@@ -314,9 +314,9 @@ __device__ __forceinline__ void score_tile(const GmmParams &p, int utt, int t_ba
   // left for this launch
   if (p.skip_single >= 2) { need[2] = 0; need[3] = 0; need[4] = 0; }   // slots 16 / 8 / 4 went to gmm_split_small_kernel
   if (p.skip_single && need[2] + need[3] + need[4] + need[5] == 0) return;
-  if (p.b_skip0) {   // band mode after gmm_band_kernel: pdfs of more than 32 Gaussians and single Gaussians are left
-    need[2] = 0; need[3] = 0; need[4] = 0; lo_[2] = 0; lo_[3] = 0; lo_[4] = 0;
-    if ((need[1] - lo_[1]) + (need[5] - lo_[5]) == 0) return;
+  if (p.b_skip0) {   // band mode after gmm_band_kernel: single Gaussians are left
+    need[1] = 0; need[2] = 0; need[3] = 0; need[4] = 0; lo_[1] = 0; lo_[2] = 0; lo_[3] = 0; lo_[4] = 0;
+    if (need[5] - lo_[5] == 0) return;
   }
 
   Tile<M8, kNT> tile;
@@ -1475,9 +1475,9 @@ __global__ void gmm_col_rows_kernel(GmmParams p, int32_t *out) {
 }
 
 // Lazy scoring, once per window: the band's index range [lo, hi) in every run of class 0 (slots 0..groups-1; one run when the
-// plan is not grouped) and in classes 2, 3, 4 (slots 8, 9, 10), relative to the class's first column — what every scoring
+// plan is not grouped), in classes 2, 3, 4 (slots 8, 9, 10) and in class 1 (slot 11), relative to the class's first column — what every scoring
 // wavefront of the sub-tile would otherwise search for itself (two dependent memory trips each).  One wavefront per utterance.
-constexpr int kRangeSlots = 11;
+constexpr int kRangeSlots = 12;
 __global__ __launch_bounds__(256) void gmm_band_ranges_kernel(GmmParams p) {
   const int lane = threadIdx.x & 63;
   const int utt = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1496,6 +1496,9 @@ __global__ __launch_bounds__(256) void gmm_band_ranges_kernel(GmmParams p) {
       if (p.groups > 1) { const int32_t *gc = p.group_counts + (size_t)utt * p.groups; for (int g = 0; g < slot; g++) base += gc[g]; cnt = gc[slot]; }
       else cnt = cc6[0];
       off = 0;
+    } else if (slot == 11) {
+      off = cc6[0];
+      cnt = cc6[1];
     } else {
       off = cc6[0] + cc6[1];
       for (int k = 2; k < slot - 6; k++) off += cc6[k];
@@ -1622,9 +1625,9 @@ __global__ __launch_bounds__(256, 2) void gmm_band_kernel(GmmParams p) {
     int off = 0;
 #pragma unroll
     for (int cls = 0; cls < 5; cls++) {
-      const int slot = cls == 0 ? grp : cls + 6;
+      const int slot = cls == 0 ? grp : (cls == 1 ? 11 : cls + 6);
       base_c[cls] = off; off += cc6[cls];
-      lo_c[cls] = cls == 1 ? 0 : rg[2 * slot]; hi_c[cls] = cls == 1 ? 0 : rg[2 * slot + 1];
+      lo_c[cls] = rg[2 * slot]; hi_c[cls] = rg[2 * slot + 1];
     }
   } else {
     int off = 0;
@@ -1638,7 +1641,7 @@ __global__ __launch_bounds__(256, 2) void gmm_band_kernel(GmmParams p) {
         cnt = gc[grp];
       }
       int nh = 0, nl = 0;
-      if (cls != 1) {
+      {
         // four chunks per trip, every load issued before the first ballot waits (one memory round trip per 256 pdfs, not four)
         for (int i0 = 0; i0 < cnt; i0 += 256) {
           int ff[4], ld[4];
@@ -1677,8 +1680,11 @@ __global__ __launch_bounds__(256, 2) void gmm_band_kernel(GmmParams p) {
       else { lo_c[cls] = max(lo_c[cls], a * kp); hi_c[cls] = min(hi_c[cls], b * kp); }
     }
   }
+  // class 1 (pdfs of more than 32 Gaussians, few): its band's columns go round the sub-tile's wavefronts one by one
+  const int step1 = p.b_split ? p.groups : (p.b_chunk > 0 ? p.b_nchunk : 1);
+  const int first1 = lo_c[1] + (p.b_split ? grp : (p.b_chunk > 0 ? chunk : 0));
   const int lo = lo_c[0], hi = hi_c[0];
-  if (lo >= hi && lo_c[2] >= hi_c[2] && lo_c[3] >= hi_c[3] && lo_c[4] >= hi_c[4]) {
+  if (lo >= hi && first1 >= hi_c[1] && lo_c[2] >= hi_c[2] && lo_c[3] >= hi_c[3] && lo_c[4] >= hi_c[4]) {
     if (kHalf && lane == 0) *redo_flag = 0;
     return;
   }
@@ -1797,6 +1803,59 @@ __global__ __launch_bounds__(256, 2) void gmm_band_kernel(GmmParams p) {
       stage[(32 * h + col) * 33 + jj] = finish((h ? mx[1] : mx[0]) * inv_s, h ? sum[1] : sum[0]);
       if (jj == 31 || j == last) flush_cols(j - jj, jj + 1);
     }
+  }
+
+  // ---------------------------------------------------------------- class 1: several 32-row blocks per pdf
+  // Online log-sum-exp over the pdf's blocks (running max M and sum S against it, per frame): (M, S) ← (max(M, m_b),
+  // S·2^((M − M')·l2e) + s_b·2^((m_b − M')·l2e)).  Products and per-block reductions are class 0's; pad rows carry gconst
+  // −1e30 and vanish in the sum.  No software pipeline: a trained model has a few such pdfs per band, if any.
+  for (int j1 = first1; j1 < hi_c[1]; j1 += step1) {
+    const int cidx = base_c[1] + j1;
+    const int r0 = __builtin_amdgcn_readfirstlane(p.col_row0[l0 + cidx]);
+    const int nb = __builtin_amdgcn_readfirstlane(p.nblk[list[cidx]]);
+    const uint4 *wsrc = (kHalf ? p.wh : p.wb) + lane;
+    const float *gsrc = (kHalf ? p.gch : p.gc) + 4 * h;
+    float M[2] = {0.0f, 0.0f}, S[2] = {0.0f, 0.0f};
+    for (int bk = 0; bk < nb; bk++) {
+      const int blk = (r0 >> 5) + bk;
+      const uint4 *src = wsrc + (size_t)blk * kUnits;
+      f32x16 acc[2];
+      {
+        f32x4 g[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) g[q] = *reinterpret_cast<const f32x4 *>(gsrc + (size_t)blk * 32 + 8 * q);
+#pragma unroll
+        for (int rr = 0; rr < 16; rr++) { acc[0][rr] = g[rr >> 2][rr & 3]; acc[1][rr] = acc[0][rr]; }
+      }
+#pragma unroll
+      for (int s_ = 0; s_ < kSteps; s_++) {
+        op8 a[kPieces];
+#pragma unroll
+        for (int q = 0; q < kPieces; q++) a[q] = __builtin_bit_cast(op8, src[(s_ * kPieces + q) * 64]);
+#pragma unroll
+        for (int t6 = 0; t6 < kProd; t6++)
+#pragma unroll
+          for (int n = 0; n < 2; n++) {
+            if constexpr (kHalf) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[pa[t6]], b[n][s_][pb[t6]], acc[n], 0, 0, 0);
+            else acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa[t6]], b[n][s_][pb[t6]], acc[n], 0, 0, 0);
+          }
+      }
+#pragma unroll
+      for (int n = 0; n < 2; n++) {
+        float m = reg_max<0, 16>(acc[n]);
+        m = fmaxf(m, swap32(m, h));
+        float sv = reg_expsum_fast(acc[n], m, l2e_s);
+        sv += swap32(sv, h);
+        if (bk == 0) { M[n] = m; S[n] = sv; }
+        else {
+          const float mn = fmaxf(M[n], m);
+          S[n] = S[n] * __builtin_amdgcn_exp2f((M[n] - mn) * l2e_s) + sv * __builtin_amdgcn_exp2f((m - mn) * l2e_s);
+          M[n] = mn;
+        }
+      }
+    }
+    const int t = t_base + 32 * h + col;
+    if (t < T) __builtin_nontemporal_store(finish((h ? M[1] : M[0]) * inv_s, h ? S[1] : S[0]), &out[(size_t)t * P + cidx]);
   }
 
   // ---------------------------------------------------------------- classes 2, 3, 4: 32 / slot pdfs per virtual block
@@ -2581,7 +2640,7 @@ int mfa_gmm_score_window(mfa_ctx *c, const MfaLazyScoring *lazy, const MfaWindow
   const char *bf = getenv("MFA_GMM_BF16");
   const char *hf = getenv("MFA_GMM_F16");
   KernelTimer kt(c, MFA_K_GMM);
-  const bool split_classes = c->has_single32 || c->has_slot_class[1] || c->has_slot_class[2] || c->has_slot_class[3];
+  const bool split_classes = c->has_single32 || c->has_multi_block || c->has_slot_class[1] || c->has_slot_class[2] || c->has_slot_class[3];
   if (!(bf && bf[0] == '0') && c->d_wb && split_classes) {
     const bool f16_ok = !(hf && hf[0] == '0') && c->d_wh;
     if (c->gmm_redo_cap < split_waves) {
@@ -2620,7 +2679,7 @@ int mfa_gmm_score_window(mfa_ctx *c, const MfaLazyScoring *lazy, const MfaWindow
     p.b_skip0 = 1;
   }
   p.b_split = 0;   // (the f32 band kernel keeps one wavefront per sub-tile and walks the runs of class 0 itself)
-  const bool f32_classes = c->has_multi_block || c->has_slot_class[4];   // pdfs of more than 32 Gaussians, single Gaussians
+  const bool f32_classes = c->has_slot_class[4];   // single Gaussians stay on the f32 pipe (bit-exact); everything else was scored above
   if (!p.b_skip0 || f32_classes) {
     if (m8 <= 10) hipLaunchKernelGGL((gmm_band_f32_kernel<10>), grid, dim3(256), 0, c->stream, p);
     else hipLaunchKernelGGL((gmm_band_f32_kernel<12>), grid, dim3(256), 0, c->stream, p);
