@@ -171,53 +171,71 @@ __global__ __launch_bounds__(256) void feats_kernel(FeatParams p) {
 // the contiguous floats x[r·dim .. r·dim + sdim).  Same fmaf chains, same order, as feats_kernel and the oracle.
 // Round-1 measurement: 2.05 ms → 0.6 ms per 2M frames (13 → 40 dims, ±3 splice).
 constexpr int kTileLda = 128;   // frames per block of the register-row kernel
-template <int kSdim, int kR>   // exact spliced dimension and output rows: no bounds tests inside the unrolled chains
+// Round 2: one LDS read per multiply-add made the kernel LDS-issue-bound (91 ds_read_b32 per output and frame, the LDS pipe
+// shared by the CU's four SIMDs).  The base rows are now padded to 16 floats and the LDA outputs to 16-byte alignment, so a
+// spliced vector is read as 7 × (3 × 16 bytes + 4) and the fMLLR input as 10 × 16 bytes: 28 + 10 reads instead of 91 + 40,
+// the multiply-add chains in the same order (results unchanged).
+template <int kDim, int kCtx, int kR>   // exact base dimension, splice context and output rows: no bounds tests inside the unrolled chains
 __global__ __launch_bounds__(256) void feats_lda_kernel(FeatParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int kSdim = (2 * kCtx + 1) * kDim;
+  constexpr int kXS = (kDim + 3) & ~3;               // row stride of the base-feature tile (16-byte aligned rows)
+  static_assert(kR % 4 == 0, "LDA output rows are read 16 bytes at a time");
   const int utt = blockIdx.y;
   const int64_t f0 = p.frame_off[utt];
   const int T = (int)(p.frame_off[utt + 1] - f0);
   const int t0 = blockIdx.x * kTileLda;
   if (t0 >= T) return;
-  const int halo = p.ctx, rows = kTileLda + 2 * halo;
+  constexpr int halo = kCtx, rows = kTileLda + 2 * halo;
   constexpr int R = kR;
-  // X: [rows][dim] CMVN-applied base features (frame t0-halo+r, clamped); later the staging area of the fMLLR matrix
+  // X: [rows][kXS] CMVN-applied base features (frame t0-halo+r, clamped); later the staging area of the fMLLR matrix
   // Y: staging area of the LDA matrix, then [kTileLda][R] LDA outputs (with fMLLR)
   float *X = smem;
-  const int x_floats = max(rows * p.dim, R * (R + 1));
+  constexpr int x_floats = rows * kXS > R * (R + 1) ? rows * kXS : R * (R + 1);
   float *Y = X + x_floats;
   const int spk = p.utt2spk ? p.utt2spk[utt] : 0;
-  for (int i = threadIdx.x; i < rows * p.dim; i += blockDim.x) {
-    int r = i / p.dim, d = i % p.dim;
+  for (int i = threadIdx.x; i < rows * kDim; i += blockDim.x) {
+    int r = i / kDim, d = i % kDim;
     int t = t0 - halo + r;
     t = t < 0 ? 0 : (t >= T ? T - 1 : t);
-    float v = p.mfcc[(f0 + t) * p.dim + d];
+    float v = p.mfcc[(f0 + t) * kDim + d];
     if (p.cmvn) {
-      const double *st = p.cmvn + (size_t)spk * 2 * (p.dim + 1);
-      v += (float)(-(st[d] / st[p.dim]));
+      const double *st = p.cmvn + (size_t)spk * 2 * (kDim + 1);
+      v += (float)(-(st[d] / st[kDim]));
     }
-    X[i] = v;
+    X[r * kXS + d] = v;
   }
   for (int i = threadIdx.x; i < R * p.lda_cols; i += blockDim.x) Y[i] = p.lda[i];   // coalesced; rows go to registers below
   __syncthreads();
   constexpr int G = 256 / R;                         // frame groups
   const int o = threadIdx.x % R, g = threadIdx.x / R;
   const bool active = g < G;
-  constexpr int sdim = kSdim;
-  const bool lda_offset = (p.lda_cols == sdim + 1);
+  const bool lda_offset = (p.lda_cols == kSdim + 1);
   float m[kSdim];
 #pragma unroll
   for (int k = 0; k < kSdim; k++) m[k] = Y[o * p.lda_cols + k];   // spare threads (g == G) read a valid row too
-  const float m_off = lda_offset ? Y[o * p.lda_cols + sdim] : 0.0f;
+  const float m_off = lda_offset ? Y[o * p.lda_cols + kSdim] : 0.0f;
   __syncthreads();                                   // Y is free for the outputs
   if (active) {
     for (int r = g; r < kTileLda; r += G) {
       const int t = t0 + r;
       if (t >= T) break;
-      const float *xs = X + r * p.dim;               // frames t-ctx .. t+ctx, contiguous
+      const float *xs = X + r * kXS;                 // frames t-ctx .. t+ctx: rows r .. r+2·ctx of the tile
       float acc = 0.0f;
 #pragma unroll
-      for (int k = 0; k < kSdim; k++) acc = fmaf(m[k], xs[k], acc);
+      for (int j = 0; j < 2 * kCtx + 1; j++) {
+        const float *xr = xs + j * kXS;
+#pragma unroll
+        for (int d4 = 0; d4 + 4 <= kDim; d4 += 4) {
+          const float4 x4 = *reinterpret_cast<const float4 *>(xr + d4);
+          acc = fmaf(m[j * kDim + d4], x4.x, acc);
+          acc = fmaf(m[j * kDim + d4 + 1], x4.y, acc);
+          acc = fmaf(m[j * kDim + d4 + 2], x4.z, acc);
+          acc = fmaf(m[j * kDim + d4 + 3], x4.w, acc);
+        }
+#pragma unroll
+        for (int d = kDim & ~3; d < kDim; d++) acc = fmaf(m[j * kDim + d], xr[d], acc);
+      }
       if (lda_offset) acc += m_off;
       if (p.fmllr) Y[r * R + o] = acc;
       else p.out[(f0 + t) * R + o] = acc;
@@ -239,7 +257,10 @@ __global__ __launch_bounds__(256) void feats_lda_kernel(FeatParams p) {
     const float *ys = Y + r * R;
     float acc = 0.0f;
 #pragma unroll
-    for (int k = 0; k < kR; k++) acc = fmaf(f[k], ys[k], acc);
+    for (int k = 0; k < kR; k += 4) {
+      const float4 y4 = *reinterpret_cast<const float4 *>(ys + k);
+      acc = fmaf(f[k], y4.x, acc); acc = fmaf(f[k + 1], y4.y, acc); acc = fmaf(f[k + 2], y4.z, acc); acc = fmaf(f[k + 3], y4.w, acc);
+    }
     acc += f_off;
     p.out[(f0 + t) * R + o] = acc;
   }
@@ -319,14 +340,14 @@ MFA_API int mfa_feats_batch(mfa_ctx *c, const float *d_mfcc, const int64_t *d_fr
   dim3 grid((max_frames + kTile - 1) / kTile, n_utt);
   KernelTimer kt(c, MFA_K_FEATS);
   // register-row kernel for MFA's standard shape (13 MFCCs spliced ±3 → 91, LDA to 40); other shapes take the generic kernel
-  constexpr int kSdim = 91, kR = 40;
+  constexpr int kDim = 13, kCtx = 3, kR = 40;
   const char *generic = getenv("MFA_FEATS_GENERIC");
-  if (mode == 1 && (2 * splice_ctx + 1) * dim == kSdim && lda_rows == kR && !(generic && generic[0] == '1')) {
+  if (mode == 1 && dim == kDim && splice_ctx == kCtx && lda_rows == kR && !(generic && generic[0] == '1')) {
     const int rows = kTileLda + 2 * splice_ctx;
-    size_t x_floats = std::max((size_t)rows * dim, (size_t)lda_rows * (lda_rows + 1));
+    size_t x_floats = std::max((size_t)rows * ((kDim + 3) & ~3), (size_t)lda_rows * (lda_rows + 1));
     size_t y_floats = std::max((size_t)kTileLda * lda_rows, (size_t)lda_rows * lda_cols);
     dim3 grid2((max_frames + kTileLda - 1) / kTileLda, n_utt);
-    hipLaunchKernelGGL((feats_lda_kernel<kSdim, kR>), grid2, dim3(256), (x_floats + y_floats) * 4, c->stream, p);
+    hipLaunchKernelGGL((feats_lda_kernel<kDim, kCtx, kR>), grid2, dim3(256), (x_floats + y_floats) * 4, c->stream, p);
   } else {
     hipLaunchKernelGGL(feats_kernel, grid, dim3(256), lds, c->stream, p);
   }
