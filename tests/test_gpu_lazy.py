@@ -245,3 +245,45 @@ def test_beam_10_40_result_is_the_unpruned_best_path(engine, tri, fx):
     assert set(b_["status"].cpu().tolist()) == {0}
     for u in range(len(segs)):
         assert torch.equal(a_["ali"][fo2[u]: fo2[u + 1]], b_["ali"][fo2[u]: fo2[u + 1]]), u
+
+
+def test_plan_grouping_and_decoder_tier_do_not_change_results(engine, tri, monkeypatch):
+    """Two layout / launch choices that must be invisible in the outputs: the score plan's grouping of the single-block
+    pdfs (one run per XCD vs one run) and the first decoder tier (dedicated 64-token kernel vs the general kernel,
+    MFA_VIT_LEAN=0).  Alignments, words, likelihoods and statuses are compared bit for bit; so are the scores of every
+    column both layouts wrote (columns are matched through the arcs' column maps)."""
+    world, model, lda, fm, feats_of = tri
+    engine.load_gmm(model.am)
+    utts = [world.utterance(7300 + i, n_words=nw, samples=ns) for i, (nw, ns) in enumerate([(30, 160000), (12, 70000), (40, 200000)])]
+    gc = G.TrainingGraphCompiler(model.tm, model.tree, world.lexicon)
+    scaled = model.tm.scaled_log_probs(1.0, 0.1)
+    fsts = [G.add_transition_probs(gc.compile_fst(u[1]), scaled) for u in utts]
+    feats, fo = feats_of([u[0] for u in utts], [u[3] for u in utts])
+    kw = dict(beam=10.0, retry_beam=40.0, max_tokens=1024, bp_tokens_per_frame=256, want_frame_likes=True)
+    g8 = engine.pack_graphs(fsts, model.tm, groups=8)
+    g1 = engine.pack_graphs(fsts, model.tm, groups=1)
+    assert g8.groups == 8 and g8.group_counts is not None and g1.group_counts is None
+    assert int(g8.group_counts.sum()) == int(g8.class_counts[:, 0].sum())
+    ref = engine.align_features(g8, feats, fo, **kw)
+    one = engine.align_features(g1, feats, fo, **kw)
+    monkeypatch.setenv("MFA_VIT_LEAN", "0")
+    general = engine.align_features(g8, feats, fo, **kw)
+    monkeypatch.delenv("MFA_VIT_LEAN")
+    torch.cuda.synchronize()
+    assert set(ref["status"].cpu().tolist()) <= {0, 1}
+    for other, what in ((one, "ungrouped plan"), (general, "general kernel as first tier")):
+        for k in ("status", "ali", "words", "n_words", "like", "frame_like"):
+            assert torch.equal(ref[k], other[k]), f"{k} differs with the {what}"
+    # same cells, same values: column c of the grouped layout is the ungrouped layout's column of the same arcs
+    a8, a1 = g8.tensors["arc_col"].cpu().numpy(), g1.tensors["arc_col"].cpu().numpy()
+    ab = g8.tensors["arc_base"].cpu().numpy()
+    l8, l1 = ref["loglikes"].cpu().numpy(), one["loglikes"].cpu().numpy()
+    off8 = off1 = 0
+    for u in range(len(fsts)):
+        T, P = int(fo[u + 1] - fo[u]), int(g8.pdf_off_host[u + 1] - g8.pdf_off_host[u])
+        m8, m1 = l8[off8: off8 + T * P].reshape(T, P), l1[off1: off1 + T * P].reshape(T, P)
+        perm = np.zeros(P, dtype=np.int64)
+        perm[a8[ab[u]: ab[u + 1]]] = a1[ab[u]: ab[u + 1]]
+        both = (m8 != 0.0) & (m1[:, perm] != 0.0)
+        assert both.any() and np.array_equal(m8[both], m1[:, perm][both])
+        off8 += T * P; off1 += T * P
