@@ -120,10 +120,18 @@ __device__ __forceinline__ u32 incl_scan_max(u32 v) {
   v = max(v, dpp_u32<0x118>(0, v)); v = max(v, dpp_u32<0x142, 0xA>(0, v)); v = max(v, dpp_u32<0x143, 0xC>(0, v));
   return v;
 }
+// min of two costs as ONE instruction.  fmin() is llvm.minnum: with IEEE mode on it first canonicalises both operands
+// (v_max_f64 x, x, x) in case one is a signalling NaN — the decoder's costs are finite or +inf, never NaN, and every DPP scan
+// step paid two extra double-rate instructions for it (62 canonicalisations against 50 minima in the first-tier kernel).
+__device__ __forceinline__ double min_f64(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 __device__ __forceinline__ double incl_scan_min(double v) {
   const double inf = INFINITY;
-  v = fmin(v, dpp_f64<0x111>(inf, v)); v = fmin(v, dpp_f64<0x112>(inf, v)); v = fmin(v, dpp_f64<0x114>(inf, v));
-  v = fmin(v, dpp_f64<0x118>(inf, v)); v = fmin(v, dpp_f64<0x142, 0xA>(inf, v)); v = fmin(v, dpp_f64<0x143, 0xC>(inf, v));
+  v = min_f64(v, dpp_f64<0x111>(inf, v)); v = min_f64(v, dpp_f64<0x112>(inf, v)); v = min_f64(v, dpp_f64<0x114>(inf, v));
+  v = min_f64(v, dpp_f64<0x118>(inf, v)); v = min_f64(v, dpp_f64<0x142, 0xA>(inf, v)); v = min_f64(v, dpp_f64<0x143, 0xC>(inf, v));
   return v;
 }
 __device__ __forceinline__ double wave_min_f64(double v) { return readlane_f64(incl_scan_min(v), 63); }
@@ -459,7 +467,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             double cst = i < n ? c_cost[i] : INFINITY;
             u32 le = 0;
             for (int j = 0; j < n; j++) le += (c_cost[j] <= cst) ? 1u : 0u;  // LDS broadcast reads
-            if (i < n && le > (u32)kMinActive) v = fmin(v, cst);
+            if (i < n && le > (u32)kMinActive) v = min_f64(v, cst);
           }
         }
         v = wave_min_f64(v);
@@ -554,7 +562,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         STAMP(3);   // arc gather + score + cost
         const double seed = wave_min_f64((valid && tok == best_i) ? nw : INFINITY);  // the best token's candidates
         const double m_incl = incl_scan_min(nw);
-        const double local = fmin(seed, shift_in_min(m_incl));
+        const double local = min_f64(seed, shift_in_min(m_incl));
         const bool created = valid && nw < local + (double)abeam;
         const u32 cidx = (tok << kArcBits) | k;
         STAMP(4);   // running cutoff (seed, prefix-min)
@@ -583,7 +591,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         const u32 ban = c_an[best_i];
         const int a0 = (int)(ban >> 7), a1 = a0 + (int)(ban & 127u);
         double m = INFINITY;
-        for (int a = a0 + lane; a < a1; a += 64) m = fmin(m, cand_cost(a_w[a], best, score(a_col[a]), p.scale));
+        for (int a = a0 + lane; a < a1; a += 64) m = min_f64(m, cand_cost(a_w[a], best, score(a_col[a]), p.scale));
         run = wave_min_f64(m);
       }
 
@@ -613,15 +621,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   #pragma unroll
         for (int k = 0; k < kArcCache; k++) {
           nw[k] = (k < narc) ? cand_cost(w[k], cst, score(col[k]), p.scale) : INFINITY;
-          m = fmin(m, nw[k]);
+          m = min_f64(m, nw[k]);
           sl[k] = kEmpty;
         }
         for (int k = kArcCache; k < maxarc; k++)
-          if (k < narc) m = fmin(m, cand_cost(a_w[a0 + k], cst, score(a_col[a0 + k]), p.scale));
+          if (k < narc) m = min_f64(m, cand_cost(a_w[a0 + k], cst, score(a_col[a0 + k]), p.scale));
         if (single) run = best_i != kEmpty ? readlane_f64(m, __builtin_amdgcn_readfirstlane((int)best_i)) : INFINITY;  // best token is always expanded
         const double m_incl = incl_scan_min(m);
-        double local = fmin(run, shift_in_min(m_incl));
-        run = fmin(run, readlane_f64(m_incl, 63));
+        double local = min_f64(run, shift_in_min(m_incl));
+        run = min_f64(run, readlane_f64(m_incl, 63));
 
         // Candidate creation in three wavefront phases (each phase's LDS operations are issued back to back):
         //   look up the destination's slot → claim missing slots (CAS; the winner allocates, initialises, publishes)
@@ -631,7 +639,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   #pragma unroll
         for (int k = 0; k < kArcCache; k++) {
           cr[k] = (k < narc) && (nw[k] < local + (double)abeam);
-          if (k < narc) local = fmin(local, nw[k]);
+          if (k < narc) local = min_f64(local, nw[k]);
           hk[k] = hash_of(nx[k]);
           any_pend |= cr[k];
         }
@@ -665,7 +673,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
           if (k < narc) {
             cnw = cand_cost(a_w[a0 + k], cst, score(a_col[a0 + k]), p.scale);
             created = cnw < local + (double)abeam;
-            local = fmin(local, cnw);
+            local = min_f64(local, cnw);
             d = a_rec[a0 + k].x;
             dan = a_rec[a0 + k].y;
           }
@@ -990,18 +998,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     for (int r = 0; r < kRounds; r++)
       nw[r] = ((u32)lane + 64u * r < ctot) ? cand_cost(wv[r], tcost[r], llt[colv[r]], p.scale) : INFINITY;
     // ---------------- running cutoff: seed from the best token's candidates, then an exclusive prefix-min in ordinal order
+    // (the best token's candidates sit at ordinals cb[best] .. + narc[best]: a few broadcast reads instead of a masked
+    //  wavefront reduction per round)
     double run = INFINITY;
+    {
+      const u32 ob = (u32)__builtin_amdgcn_readlane((int)cb, (int)best_i), nb_ = (u32)__builtin_amdgcn_readlane((int)narc, (int)best_i);
+      for (u32 k = 0; k < nb_; k++) {
+        const u32 ord = ob + k;
+        const int ln = (int)(ord & 63u);
+        double v = readlane_f64(nw[0], ln);
 #pragma unroll
-    for (int r = 0; r < kRounds; r++)
-      if (r < rounds) run = fmin(run, wave_min_f64(((u32)lane + 64u * r < ctot && tokv[r] == best_i) ? nw[r] : INFINITY));
+        for (int r = 1; r < kRounds; r++) if ((ord >> 6) == (u32)r) v = readlane_f64(nw[r], ln);
+        run = min_f64(run, v);
+      }
+    }
     bool created[kRounds];
 #pragma unroll
     for (int r = 0; r < kRounds; r++) {
       created[r] = false;
       if (r < rounds) {
         const double m_incl = incl_scan_min(nw[r]);
-        const double local = fmin(run, shift_in_min(m_incl));
-        run = fmin(run, readlane_f64(m_incl, 63));
+        const double local = min_f64(run, shift_in_min(m_incl));
+        run = min_f64(run, readlane_f64(m_incl, 63));
         created[r] = ((u32)lane + 64u * r < ctot) && nw[r] < local + (double)abeam;
       }
     }
