@@ -118,22 +118,22 @@ def test_lazy_single_gaussian_model_and_real_audio(engine, fx):
     assert 1 in seen                                        # the retry-beam pass really ran (windowed, on its own list)
 
 
-@pytest.mark.parametrize("seed", [0, 1])
-def test_lazy_random_graphs_all_slot_classes(engine, fx, seed, monkeypatch):
+@pytest.mark.parametrize("seed,dim", [(0, 39), (1, 39), (0, 48), (1, 45)])
+def test_lazy_random_graphs_all_slot_classes(engine, fx, seed, dim, monkeypatch):
     """Graphs with cycles, skips, dead ends and unreachable states over a model with every slot class (1, 4, 8, 16, 32 rows,
-    multi-block) — both band kernels at once.  (The band rule itself is brute-forced on such graphs on the CPU:
-    tests/test_score_plan_cpu.py.)"""
+    multi-block) — both band kernels at once, for operand widths of 80 (dim 39) and 96 (dim 45, 48) columns.  (The band rule
+    itself is brute-forced on such graphs on the CPU: tests/test_score_plan_cpu.py.)"""
     rng = np.random.default_rng(4000 + seed)
     tm = fx.mono_tm
     sizes = [int(x) for x in rng.choice([1, 2, 3, 4, 5, 8, 9, 12, 16, 17, 26, 32, 40, 70], size=tm.num_pdfs)]
-    am = helpers.random_gmm(rng, 39, sizes)
+    am = helpers.random_gmm(rng, dim, sizes)
     engine.load_gmm(am)
     fsts, feats = [], []
     for u in range(12):
         S = int(rng.choice([3, 8, 40, 150, 400, 1100]))
         fsts.append(_random_graph(rng, tm, S))
         T = int(rng.integers(2, 300))
-        feats.append(rng.normal(0, 3.0, size=(T, 39)).astype(np.float32))
+        feats.append(rng.normal(0, 3.0, size=(T, dim)).astype(np.float32))
     fo = np.concatenate([[0], np.cumsum([f.shape[0] for f in feats])]).astype(np.int64)
     graphs = engine.pack_graphs(fsts, tm)
     beam, retry = [(8.0, 32.0), (30.0, 0.0)][seed]
@@ -146,8 +146,8 @@ def test_lazy_random_graphs_all_slot_classes(engine, fx, seed, monkeypatch):
     monkeypatch.delenv("MFA_GMM_BF16")
     # Default arithmetic: the band kernel scores the 32-row single-block class and the 16/8/4-row classes with the dense
     # split-operand kernels' own expressions (bit-identical cells), single Gaussians go to the f32 band kernel (bit-identical
-    # to the dense f32 kernel); only pdfs of more than 32 Gaussians differ — the dense path merges their blocks online on
-    # the f16 pipe, the lazy path scores them on the f32 pipe: same scores to ≤ 1e-4·scale, not the same bits.
+    # to the dense f32 kernel); only pdfs of more than 32 Gaussians may differ — both paths merge their blocks on the f16
+    # pipe, but the dense kernel with its own block schedule: same scores to ≤ 1e-4·scale, not necessarily the same bits.
     ll, ll_off, ll_cols = engine.score(d_feats, fo, graphs.pdf_list, graphs.pdf_off_host, graphs.class_counts)
     dense = engine.align(graphs, ll, ll_off, ll_cols, fo, **kw)
     lazy = engine.align_features(graphs, d_feats, fo, **kw)
