@@ -1438,8 +1438,7 @@ int align_impl(mfa_ctx *c, const mfa_graph_batch *g, const float *d_loglikes, co
       for (int t0 = 0; t0 < lazy->max_frames; t0 += K) {
         MfaWindowScore ws;
         ws.t_begin = t0; ws.window = K; ws.band = p.band; ws.utt_list = p.utt_list; ws.n_list = p.n_list;
-        ws.cols_per_wave = L.code == 0 ? 0 : 32;
-        { const char *e = getenv("MFA_GMM_CHUNK"); if (e && atoi(e) > 0 && L.code == 0) ws.cols_per_wave = atoi(e); }   // experiment   // list passes: few utterances, wide bands — spread the columns over wavefronts
+        ws.cols_per_wave = L.code == 0 ? 0 : 32;   // list passes: few utterances, wide bands — spread the columns over wavefronts
         ws.done = (const int32_t *)(base + w.vstate); ws.done_stride = (int)(sizeof(VitState) / 4); ws.done_word = 2;
         if (mfa_gmm_score_window(c, lazy, &ws, d_frame_off, n_utt, d_ll_off, (float *)d_loglikes) != 0) return -1;
         MFA_DEBUG_POINT(c, "scored window t0=%d K=%d pass=%d code=%d N=%d C=%d", t0, K, ps, L.code, L.N, L.C);
