@@ -208,15 +208,23 @@ __device__ __forceinline__ void finalize_utterance(const VitParams &p, int utt, 
     return;
   }
 
-  // ---------------- traceback (one lane chases the pointers), arc index per frame parked in ali[]
+  // ---------------- traceback, arc index per frame parked in ali[].  The chain is pos → record → pos; the per-frame offsets
+  // do not depend on it, so 64 of them are fetched at once and handed out by v_readlane: one dependent load per frame
+  // instead of two (every lane walks the same chain on broadcast addresses; lane 0 stores).
   int32_t *ali = p.ali + f0;
   const u32 fstate = c_state[bpos];
-  if (lane == 0) {
+  {
     u32 pos = bpos;
-    for (int tt = T - 1; tt >= 0; tt--) {
-      u64 rec = bp[(u64)tokoff[tt] + pos];
-      ali[tt] = (int32_t)(rec >> 32);
-      pos = (u32)(rec & 0xFFFFFFFFu);
+    for (int c0 = T - 1; c0 >= 0; c0 -= 64) {
+      const int tl = c0 - lane;
+      const u32 tokv = tl >= 0 ? tokoff[tl] : 0u;
+      const int cnt = min(64, c0 + 1);
+      for (int k = 0; k < cnt; k++) {
+        const u32 to = (u32)__builtin_amdgcn_readlane((int)tokv, k);
+        const u64 rec = bp[(u64)to + pos];
+        if (lane == 0) ali[c0 - k] = (int32_t)(rec >> 32);
+        pos = (u32)(rec & 0xFFFFFFFFu);
+      }
     }
   }
   __threadfence_block();
@@ -1033,6 +1041,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
       any_pend = false;
 #pragma unroll
       for (int r = 0; r < kRounds; r++) {
+        if (r >= rounds) continue;      // (uniform: a frame of one round does not walk the other rounds' masks)
         if (pend[r]) {
           const u32 v = hmap[hk[r]];
           if (v == kEmpty) {
@@ -1063,12 +1072,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 #pragma unroll
     for (int r = 0; r < kRounds; r++) {
       cidx[r] = (tokv[r] << kArcBits) | kv[r];
-      if (sl[r] != kEmpty) { atomicMin(&s_cost[sl[r]], dkey(nw[r])); atomicMin(&s_F[sl[r]], cidx[r]); }
+      if (r < rounds && sl[r] != kEmpty) { atomicMin(&s_cost[sl[r]], dkey(nw[r])); atomicMin(&s_F[sl[r]], cidx[r]); }
     }
     WSYNC();
 #pragma unroll
     for (int r = 0; r < kRounds; r++)
-      if (sl[r] != kEmpty && dkey(nw[r]) == s_cost[sl[r]]) atomicMin(&s_W[sl[r]], cidx[r]);
+      if (r < rounds && sl[r] != kEmpty && dkey(nw[r]) == s_cost[sl[r]]) atomicMin(&s_W[sl[r]], cidx[r]);
     WSYNC();
     const u32 nslots = ctr[0];
     if (nslots > (u32)N || bp_used + nslots > bp_cap) { overflow = true; break; }
