@@ -308,6 +308,9 @@ def main():
         w = max(a[3], 1.0)
         log(rank, f"band kernel per wavefront: search {a[0] / w / 100:.2f} us, feature split {a[1] / w / 100:.2f} us, block loop "
                   f"{a[2] / w / 100:.2f} us over {a[4] / w:.1f} blocks ({a[2] / max(a[4], 1) / 100:.3f} us per block); {int(a[3])} wavefronts")
+        nb = max(a[4], 1.0)
+        log(rank, "band kernel block loop, shader-clock cycles per block: MFMA phase (issue + operand waits) %.0f, lookup wait %.0f, "
+                  "log-sum-exp + stage %.0f, flush %.0f" % tuple(a[8 + k] / nb for k in range(4)))
     if os.environ.get("MFA_VIT_STAMPS"):  # diagnostic (library built with -DVIT_STAMPS): decoder phase cycles → .npy
         import ctypes as C
         stamps = torch.zeros(pipe.n_utt * 12, dtype=torch.int64, device=dev)

@@ -1751,7 +1751,13 @@ __global__ __launch_bounds__(256, 2) void gmm_band_kernel(GmmParams p) {
         for (int q = 0; q < kPieces; q++) a[s_][q] = __builtin_bit_cast(op8, src[(s_ * kPieces + q) * 64]);
     }
     int blk_next = block_at(lo + 1);
+#ifdef GMM_BAND_STAMPS
+    unsigned long long ph[4] = {0, 0, 0, 0};   // shader-clock cycles: MFMA phase (issue + operand waits), lookup wait, log-sum-exp + stage, flush
+#endif
     for (int j = lo; j < hi; j++) {
+#ifdef GMM_BAND_STAMPS
+      const unsigned long long c0_ = clock64();
+#endif
       const int x_next2 = row0_at(j + 2);                      // lookup two blocks ahead (oldest entry of the vmcnt queue)
       f32x16 init, acc[2];
 #pragma unroll
@@ -1782,9 +1788,15 @@ __global__ __launch_bounds__(256, 2) void gmm_band_kernel(GmmParams p) {
         for (int q = 0; q < kPieces; q++) a[s_][q] = __builtin_bit_cast(op8, src[(s_ * kPieces + q) * 64]);
         __builtin_amdgcn_sched_barrier(0);
       }
+#ifdef GMM_BAND_STAMPS
+      const unsigned long long c1_ = clock64();
+#endif
       blk_next = __builtin_amdgcn_readfirstlane(x_next2) >> 5;
 #ifdef BAND_DIAG_BLKMOD
       blk_next %= BAND_DIAG_BLKMOD;
+#endif
+#ifdef GMM_BAND_STAMPS
+      const unsigned long long c2_ = clock64();
 #endif
       float mx[2], sum[2];
 #pragma unroll
@@ -1801,8 +1813,19 @@ __global__ __launch_bounds__(256, 2) void gmm_band_kernel(GmmParams p) {
       }
       const int jj = (j - lo) & 31;
       stage[(32 * h + col) * 33 + jj] = finish((h ? mx[1] : mx[0]) * inv_s, h ? sum[1] : sum[0]);
+#ifdef GMM_BAND_STAMPS
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const unsigned long long c3_ = clock64();
+#endif
       if (jj == 31 || j == last) flush_cols(j - jj, jj + 1);
+#ifdef GMM_BAND_STAMPS
+      const unsigned long long c4_ = clock64();
+      ph[0] += c1_ - c0_; ph[1] += c2_ - c1_; ph[2] += c3_ - c2_; ph[3] += c4_ - c3_;
+#endif
     }
+#ifdef GMM_BAND_STAMPS
+    if (p.trace && lane == 0 && kHalf) { atomicAdd(&p.trace[8], ph[0]); atomicAdd(&p.trace[9], ph[1]); atomicAdd(&p.trace[10], ph[2]); atomicAdd(&p.trace[11], ph[3]); }
+#endif
   }
 
   // ---------------------------------------------------------------- class 1: several 32-row blocks per pdf
