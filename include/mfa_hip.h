@@ -266,9 +266,10 @@ MFA_API int mfa_build_score_plan(int32_t n_states, const int32_t *h_arc_off, con
  * `groups` runs, run g holding the pdfs with id mod groups == g, each run in ascending first depth with its own running
  * max in h_col_last; h_group_counts[groups] = columns per run.  With groups = 8 the lazy scoring kernel gives run g of every
  * utterance to workgroups of one XCD, whose 4 MiB L2 then only ever sees an eighth of the model (MI355X: 8 XCDs; a
- * 5k-pdf model is 51 MB of operands, re-read from the Infinity Cache otherwise).  The band rule holds per run.
+ * 5k-pdf model is 51 MB of operands, re-read from the Infinity Cache otherwise); with groups = 16 an XCD serves runs x and
+ * x + 8 one after the other (first and second half of the launch).  The band rule holds per run.
  * groups = 1 is mfa_build_score_plan.  Returns -3 for groups outside 1..MFA_PLAN_MAX_GROUPS. */
-#define MFA_PLAN_MAX_GROUPS 8
+#define MFA_PLAN_MAX_GROUPS 16
 MFA_API int mfa_build_score_plan_grouped(int32_t n_states, const int32_t *h_arc_off, const int32_t *h_arc_next,
                                          const int32_t *h_arc_pdf, int32_t start, int32_t num_pdfs, const int32_t *h_pdf_class,
                                          int32_t cluster_span, int32_t groups, int32_t *h_state_depth, int32_t *h_arc_col,

@@ -103,9 +103,19 @@ __device__ __forceinline__ Band band_of(const GmmParams &p, int utt) {
   else { b.lo = p.b_band[2 * utt]; b.hi = p.b_band[2 * utt + 1]; }
   return b;
 }
+// gmm_band_kernel launches over a grouped plan: workgroup → (index of its four sub-tiles, run of class 0).  Consecutive
+// workgroups go to consecutive XCDs, so the run's XCD is blockIdx % 8.  With 16 runs an XCD serves two of them — x and
+// x + 8 — one after the other: the first half of the grid is runs 0..7, the second half runs 8..15, so that at any time an
+// XCD's L2 is asked for one sixteenth of the model.  (Measured on the 51 MB model of BASELINE configs[2]: 12.8 ms per step
+// against 11.2 with eight runs — sixteen wavefronts per sub-tile pay sixteen start-up chains; eight is the default.)
+__device__ __forceinline__ int2 band_split_block(const GmmParams &p) {
+  if (p.groups <= 8) return make_int2((int)(blockIdx.x / (unsigned)p.groups), (int)(blockIdx.x % (unsigned)p.groups));
+  const unsigned half = gridDim.x >> 1, phase = blockIdx.x >= half ? 1u : 0u, rem = blockIdx.x - phase * half;
+  return make_int2((int)(rem >> 3), (int)(phase * 8u + (rem & 7u)));
+}
 // wavefront → (utterance, 64-frame sub-tile) of a band-mode launch; false: nothing to do
 __device__ __forceinline__ bool band_item(const GmmParams &p, int wave, int &utt, int &r, int *chunk = nullptr) {
-  int witem = (p.b_split ? (int)(blockIdx.x / (unsigned)p.groups) : (int)blockIdx.x) * 4 + wave;
+  int witem = (p.b_split ? band_split_block(p).x : (int)blockIdx.x) * 4 + wave;
   if (chunk) { const int q = witem / p.b_nchunk; *chunk = witem - q * p.b_nchunk; witem = q; }
   const int item = witem / p.b_sub;
   r = witem - item * p.b_sub;
@@ -1475,9 +1485,10 @@ __global__ void gmm_col_rows_kernel(GmmParams p, int32_t *out) {
 }
 
 // Lazy scoring, once per window: the band's index range [lo, hi) in every run of class 0 (slots 0..groups-1; one run when the
-// plan is not grouped), in classes 2, 3, 4 (slots 8, 9, 10) and in class 1 (slot 11), relative to the class's first column — what every scoring
+// plan is not grouped), in classes 2, 3, 4 and in class 1 (the slots after the runs'), relative to the class's first column — what every scoring
 // wavefront of the sub-tile would otherwise search for itself (two dependent memory trips each).  One wavefront per utterance.
-constexpr int kRangeSlots = 12;
+constexpr int kRunSlots = MFA_PLAN_MAX_GROUPS;   // slots 0..kRunSlots-1: runs of class 0; then classes 2, 3, 4; then class 1
+constexpr int kRangeSlots = kRunSlots + 4;
 __global__ __launch_bounds__(256) void gmm_band_ranges_kernel(GmmParams p) {
   const int lane = threadIdx.x & 63;
   const int utt = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1491,18 +1502,19 @@ __global__ __launch_bounds__(256) void gmm_band_ranges_kernel(GmmParams p) {
   int off = 0;
   for (int slot = 0; slot < kRangeSlots; slot++) {
     int cnt = 0, base = 0;     // the run searched, its first column relative to the class, the class's first column in `off`
-    if (slot < 8) {
+    if (slot < kRunSlots) {
       if (slot >= runs) continue;
       if (p.groups > 1) { const int32_t *gc = p.group_counts + (size_t)utt * p.groups; for (int g = 0; g < slot; g++) base += gc[g]; cnt = gc[slot]; }
       else cnt = cc6[0];
       off = 0;
-    } else if (slot == 11) {
+    } else if (slot == kRunSlots + 3) {
       off = cc6[0];
       cnt = cc6[1];
     } else {
+      const int cls = slot - kRunSlots + 2;
       off = cc6[0] + cc6[1];
-      for (int k = 2; k < slot - 6; k++) off += cc6[k];
-      cnt = cc6[slot - 6];
+      for (int k = 2; k < cls; k++) off += cc6[k];
+      cnt = cc6[cls];
     }
     int nh = 0, nl = 0;
     for (int i0 = 0; i0 < cnt; i0 += 256) {
@@ -1576,7 +1588,7 @@ __global__ __launch_bounds__(256, 2) void gmm_band_kernel(GmmParams p) {
   __shared__ float stage_all[4][64 * 33];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float *stage = stage_all[wave];
-  const int grp = p.b_split ? (int)(blockIdx.x % (unsigned)p.groups) : 0;      // the run of class 0 this wavefront scores
+  const int grp = p.b_split ? band_split_block(p).y : 0;                          // the run of class 0 this wavefront scores
 #ifdef GMM_BAND_STAMPS
   // phase accounting (-DGMM_BAND_STAMPS, buffer from mfa_debug_gmm_trace): Σ 100 MHz ticks of {item + band search, feature
   // split, block loop}, wavefronts with work, blocks
@@ -1625,7 +1637,7 @@ __global__ __launch_bounds__(256, 2) void gmm_band_kernel(GmmParams p) {
     int off = 0;
 #pragma unroll
     for (int cls = 0; cls < 5; cls++) {
-      const int slot = cls == 0 ? grp : (cls == 1 ? 11 : cls + 6);
+      const int slot = cls == 0 ? grp : (cls == 1 ? kRunSlots + 3 : kRunSlots + cls - 2);
       base_c[cls] = off; off += cc6[cls];
       lo_c[cls] = rg[2 * slot]; hi_c[cls] = rg[2 * slot + 1];
     }

@@ -113,7 +113,7 @@ def test_band_rule_is_a_superset_on_random_graphs(fx):
     for trial in range(25):
         f = _random_graph(rng, tm, int(rng.choice([3, 8, 40, 150])))
         pdf_of_arc = tm.id2pdf[f.arcs["ilabel"]].astype(np.int32)
-        _check_graph(rng, f, pdf_of_arc, pdf_class, span=int(rng.choice([0, 2, 8, 32])), groups=int(rng.choice([1, 2, 8])))
+        _check_graph(rng, f, pdf_of_arc, pdf_class, span=int(rng.choice([0, 2, 8, 32])), groups=int(rng.choice([1, 2, 8, 16])))
 
 
 def test_band_rule_on_a_training_graph_and_column_clusters(fx):
