@@ -932,6 +932,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
   WSYNC();
 
   bool overflow = false;
+  bool have_best = false;
+  double best_carry = 0.0;
   for (; t < t_stop; t++) {
     const float *llt = ll + (size_t)t * P;
     u32 *n_state = l_state0 + (cur ^ 1) * N;
@@ -940,7 +942,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     // ---------------- GetCutoff
     const double cst = lane < n ? c_cost[lane] : INFINITY;
     const u32 an = lane < n ? c_an[lane] : 0u;
-    const double best = wave_min_f64(cst);
+    // The cheapest token's cost is the cheapest candidate of the previous frame (the global minimum is always created and
+    // wins its slot, and a slot's cost is its candidate's, bit for bit): carried over instead of a wavefront reduction.
+    const double best = have_best ? best_carry : wave_min_f64(cst);
     const u32 best_i = (u32)__ffsll((long long)__ballot(lane < n && cst == best)) - 1u;
     double wcut = INFINITY; float abeam = INFINITY;
     if (n > kMinActive) {
@@ -1146,6 +1150,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     bp_used += nslots;
     n = (int)nslots;
     cur ^= 1;
+    best_carry = run; have_best = true;
     WSYNC();
   }
   if (overflow) { hand_over(); return; }
