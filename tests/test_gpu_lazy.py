@@ -287,3 +287,30 @@ def test_plan_grouping_and_decoder_tier_do_not_change_results(engine, tri, monke
         both = (m8 != 0.0) & (m1[:, perm] != 0.0)
         assert both.any() and np.array_equal(m8[both], m1[:, perm][both])
         off8 += T * P; off1 += T * P
+
+
+def test_lazy_window_edges_and_empty_transcript(engine, tri):
+    """Utterance lengths around the window size (1, 63, 64, 65, 128, 129 frames), an empty transcript (a graph of optional
+    silence only) and a transcript far too long for its audio (no path reaches a final state: failure status, no crash) —
+    lazy and dense agree on everything, whatever the status."""
+    world, model, lda, fm, feats_of = tri
+    engine.load_gmm(model.am)
+    gc = G.TrainingGraphCompiler(model.tm, model.tree, world.lexicon)
+    scaled = model.tm.scaled_log_probs(1.0, 0.1)
+    frames = [1, 63, 64, 65, 128, 129, 40, 30]
+    texts = []
+    pcm = []
+    for i, T in enumerate(frames):
+        u = world.utterance(7400 + i, n_words=2 if T < 100 else 4, samples=160 * T)
+        pcm.append(u[0]); texts.append(u[1])
+    texts[6] = ""                                                   # optional silence only
+    texts[7] = " ".join(world.words[:40])                           # 40 words in 0.3 s
+    fsts = [G.add_transition_probs(gc.compile_fst(t), scaled) for t in texts]
+    feats, fo = feats_of(pcm, [0] * len(pcm))
+    assert [int(fo[i + 1] - fo[i]) for i in range(len(frames))] == frames
+    graphs = engine.pack_graphs(fsts, model.tm)
+    dense, lazy, _ = _both(engine, graphs, feats, fo, beam=10.0, retry_beam=40.0, max_tokens=1024, bp_tokens_per_frame=256)
+    st = dense["status"].cpu().tolist()
+    assert st[6] in (0, 1)                                           # silence-only graph aligns
+    assert st[7] == 2                                                # too much text for the audio: failed, reported as such
+    assert all(s in (0, 1, 2) for s in st)
