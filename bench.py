@@ -47,7 +47,7 @@ HBM_PEAK_GBS = 8000.0
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=4096, help="utterances per step per GPU")
     ap.add_argument("--pool", type=int, default=0,
@@ -70,10 +70,12 @@ def parse_args(argv=None):
                     help="1: windowed scoring of the cells live decoder tokens can ask for (mfa_align_features_batch); "
                          "0: score the whole (reachability-bounded) matrix, then decode")
     ap.add_argument("--window", type=int, default=64, help="frames per scoring/decoding window of the lazy path")
-    ap.add_argument("--inflight", type=int, default=3,
+    ap.add_argument("--inflight", type=int, default=6,
                     help="batches in flight per GPU: steps alternate between this many pipelines (own HIP stream, engine "
                          "context and buffers each), so that the short latency-bound tails of a step — retry-beam and "
-                         "table-growth passes over a handful of utterances — run under the next step's kernels")
+                         "table-growth passes over a handful of utterances — run under the next steps' kernels, and "
+                         "latency-bound kernels of different steps share the chip (GPU_MAX_HW_QUEUES is raised to 8: with the "
+                         "runtime's default of 4 hardware queues more than three streams queue up behind each other)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo to rehearse "
                                                            "several ranks on one GPU)")
     ap.add_argument("--verbose", action="store_true")
@@ -153,6 +155,10 @@ def _cpu_one(task):
 
 def main():
     args = parse_args()
+    # One hardware queue per pipeline stream: read by the HIP runtime when it initialises (nothing has touched it yet, in
+    # this process or — the environment is inherited — in the ranks self_launch starts).  Measured: 3 pipelines 185 k
+    # utterances/s with 4 or 8 queues; 6 pipelines 184 k with 4 queues, 203 k with 8.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
@@ -453,6 +459,7 @@ def main():
 
     # ---- the same stages with ONE batch in flight (no other stream's kernels sharing the chip): clean per-kernel times
     single = None
+    kt_ss, n_ss = None, 0
     if n_inflight > 1 and not args.no_extra_loops:
         n_ss = 2
         engines[0].kernel_timing(True)
@@ -476,7 +483,17 @@ def main():
     # batches in flight these are measured while other streams' kernels share the chip — what rocprofv3 sees too)
     stage_ms = {k: v["ms"] / args.steps for k, v in ktimes.items()}
     dominant = max(stage_ms, key=stage_ms.get)
-    roofline = pipe.roofline(dominant, ktimes, args.steps, mono, args.gauss_per_pdf)
+    roofline_concurrent = pipe.roofline(dominant, ktimes, args.steps, mono, args.gauss_per_pdf)
+    roofline_concurrent["measured"] = (f"timed region, {n_inflight} batches in flight: launch durations include the time other "
+                                       "streams' kernels share the chip")
+    if kt_ss is not None:
+        # the kernel's own roofline: its launch durations with the chip to itself (the one-batch-in-flight loop of this
+        # very run, HIP events on the launch stream) — what tools/profile_round.sh's --inflight 1 stats pass and the PMC
+        # passes see too.  The figure taken inside the timed region stays in the line as roofline_batches_in_flight.
+        roofline = pipe.roofline(dominant, kt_ss, n_ss, mono, args.gauss_per_pdf)   # (dominant: by the timed region's stage times)
+        roofline["measured"] = "one batch in flight (same run, after the timed region): the kernel has the chip to itself"
+    else:
+        roofline = roofline_concurrent
     # fabric-side bytes of that kernel's launches: PMC counters cannot be collected from inside this process, so the
     # figure is the one tools/profile_round.sh measured (separate rocprofv3 --pmc passes of this very command), committed
     # under profiles/; it applies to the default workload at the batch size in the file's name
@@ -509,7 +526,7 @@ def main():
             "batch_per_gpu": B, "utterances_total": total_utts, "distinct_utterances_per_gpu": n_pool,
             "frames_per_utt": int(pipe.max_frames), "parallelism": f"utterance-sharded x{world}, no collective",
             "inputs": "PCM + graphs resident in HBM; alignments copied to pinned host memory inside every step",
-            "batches_in_flight": n_inflight,
+            "batches_in_flight": n_inflight, "hip_hardware_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
             "scores": pipe.scores_string(),
         },
         "real_time_factor": dt / (pipe.audio_seconds * args.steps * world),
@@ -517,6 +534,7 @@ def main():
         "stage_ms_per_step": {k: round(v, 3) for k, v in stage_ms.items()},
         **extra,
         "roofline": roofline,
+        "roofline_batches_in_flight": roofline_concurrent,
         **({"single_batch_in_flight": single} if single is not None else {}),
     }
 
