@@ -161,7 +161,15 @@ struct MfaWindowScore {
   const int32_t *done;          // per-utterance "finished" word: done[utt * done_stride + done_word] != 0 → skip
   int done_stride, done_word;
   int cols_per_wave;            // 0: one wavefront walks a sub-tile's whole band; n: one wavefront per n columns of it
+  int hi_slack;                 // speculative look-ahead: the band's upper depth bound is lowered by this many arcs (0: the
+                                // proven bound); the decoder then checks every score it reads against mfa_band_ranges
 };
+// Index ranges of the columns mfa_gmm_score_window scored last, per utterance: [n_utt][kMfaRangeSlots][2], relative to the
+// first column of the slot's class — slots 0..15: runs of class 0 (only the first `groups` are written), 16..18: classes 2,
+// 3, 4, 19: class 1, 20: class 5.  Device memory owned by the context; valid until the next mfa_gmm_score_window call.
+constexpr int kMfaRunSlots = MFA_PLAN_MAX_GROUPS;
+constexpr int kMfaRangeSlots = kMfaRunSlots + 5;
+const int32_t *mfa_band_ranges(mfa_ctx *ctx);
 int mfa_gmm_presplit(mfa_ctx *c, const MfaLazyScoring *lazy, const int64_t *d_frame_off, int n_utt, int64_t total_frames);
 int mfa_gmm_lazy_supported(mfa_ctx *ctx);   // the loaded model fits the MFMA kernels (dim <= 48)
 // Score, for every listed utterance, the (frame, pdf) cells of the window that lie inside the band.  Enqueues on ctx->stream.

@@ -92,6 +92,7 @@ struct GmmParams {
   int groups;                  // 0/1: ungrouped
   const int32_t *group_counts; // [n_utt][groups]
   int b_split;                 // 1: this launch's grid holds `groups` workgroups per four sub-tiles (gmm_band_kernel)
+  int b_hi_slack;              // band mode: arcs taken off the band's upper depth bound (speculative look-ahead), 0 = none
 };
 
 // Band of one (utterance, window): pdf j of a class is needed iff first_frame[j] <= hi and last_depth[j] >= lo; both keys
@@ -101,6 +102,7 @@ __device__ __forceinline__ Band band_of(const GmmParams &p, int utt) {
   Band b;
   if (p.b_t_begin == 0) { b.lo = 0; b.hi = 64 * p.b_sub - 1; }   // only the start state is live: BFS depth 0
   else { b.lo = p.b_band[2 * utt]; b.hi = p.b_band[2 * utt + 1]; }
+  if (p.b_hi_slack > 0 && b.hi != INT32_MAX) b.hi -= p.b_hi_slack;   // speculative look-ahead (the decoder checks what it reads)
   return b;
 }
 // gmm_band_kernel launches over a grouped plan: workgroup → (index of its four sub-tiles, run of class 0).  Consecutive
@@ -1487,8 +1489,8 @@ __global__ void gmm_col_rows_kernel(GmmParams p, int32_t *out) {
 // Lazy scoring, once per window: the band's index range [lo, hi) in every run of class 0 (slots 0..groups-1; one run when the
 // plan is not grouped), in classes 2, 3, 4 and in class 1 (the slots after the runs'), relative to the class's first column — what every scoring
 // wavefront of the sub-tile would otherwise search for itself (two dependent memory trips each).  One wavefront per utterance.
-constexpr int kRunSlots = MFA_PLAN_MAX_GROUPS;   // slots 0..kRunSlots-1: runs of class 0; then classes 2, 3, 4; then class 1
-constexpr int kRangeSlots = kRunSlots + 4;
+constexpr int kRunSlots = kMfaRunSlots;   // slots 0..kRunSlots-1: runs of class 0; then classes 2, 3, 4; then class 1; then class 5
+constexpr int kRangeSlots = kMfaRangeSlots;
 __global__ __launch_bounds__(256) void gmm_band_ranges_kernel(GmmParams p) {
   const int lane = threadIdx.x & 63;
   const int utt = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1510,6 +1512,9 @@ __global__ __launch_bounds__(256) void gmm_band_ranges_kernel(GmmParams p) {
     } else if (slot == kRunSlots + 3) {
       off = cc6[0];
       cnt = cc6[1];
+    } else if (slot == kRunSlots + 4) {
+      off = cc6[0] + cc6[1] + cc6[2] + cc6[3] + cc6[4];
+      cnt = cc6[5];
     } else {
       const int cls = slot - kRunSlots + 2;
       off = cc6[0] + cc6[1];
@@ -2643,6 +2648,8 @@ int mfa_gmm_presplit(mfa_ctx *c, const MfaLazyScoring *lazy, const int64_t *d_fr
   return 0;
 }
 
+const int32_t *mfa_band_ranges(mfa_ctx *c) { return c->d_band_ranges; }
+
 int mfa_gmm_score_window(mfa_ctx *c, const MfaLazyScoring *lazy, const MfaWindowScore *ws, const int64_t *d_frame_off,
                          int n_utt, const int64_t *d_ll_off, float *d_loglikes) {
   if (!c->gmm_ready) return c->fail("mfa_load_gmm has not been called");
@@ -2659,6 +2666,7 @@ int mfa_gmm_score_window(mfa_ctx *c, const MfaLazyScoring *lazy, const MfaWindow
   p.n_utt = n_utt; p.tiles = 0;
   p.acc_scale_inv = 1.0f;
   p.trace = (unsigned long long *)c->gmm_trace;
+  p.b_hi_slack = ws->hi_slack > 0 ? ws->hi_slack : 0;
   p.b_mode = 1; p.b_t_begin = ws->t_begin; p.b_sub = ws->window / 64; p.b_band = ws->band;
   p.b_utt_list = ws->utt_list; p.b_n_list = ws->n_list;
   p.b_done = ws->done; p.b_done_stride = ws->done_stride; p.b_done_word = ws->done_word;
@@ -2675,6 +2683,18 @@ int mfa_gmm_score_window(mfa_ctx *c, const MfaLazyScoring *lazy, const MfaWindow
   const char *bf = getenv("MFA_GMM_BF16");
   const char *hf = getenv("MFA_GMM_F16");
   KernelTimer kt(c, MFA_K_GMM);
+  {   // the band's index ranges, once per utterance (instead of once per scoring wavefront)
+    const int64_t need = (int64_t)n_utt * kRangeSlots * 2;
+    if (c->band_ranges_cap < need) {
+      MFA_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+      if (c->d_band_ranges) (void)hipFree(c->d_band_ranges);
+      c->d_band_ranges = nullptr; c->band_ranges_cap = 0;
+      MFA_HIP_CHECK(c, hipMalloc((void **)&c->d_band_ranges, (size_t)need * sizeof(int32_t)));
+      c->band_ranges_cap = need;
+    }
+    p.ranges = c->d_band_ranges;
+    hipLaunchKernelGGL(gmm_band_ranges_kernel, dim3((unsigned)((n_utt + 3) / 4)), dim3(256), 0, c->stream, p);
+  }
   const bool split_classes = c->has_single32 || c->has_multi_block || c->has_slot_class[1] || c->has_slot_class[2] || c->has_slot_class[3];
   if (!(bf && bf[0] == '0') && c->d_wb && split_classes) {
     const bool f16_ok = !(hf && hf[0] == '0') && c->d_wh;
@@ -2687,18 +2707,6 @@ int mfa_gmm_score_window(mfa_ctx *c, const MfaLazyScoring *lazy, const MfaWindow
     p.redo = c->d_gmm_redo;
     p.wb = (const uint4 *)c->d_wb;
     p.col_row0 = c->d_col_row0;
-    {   // the band's index ranges, once per utterance (instead of once per scoring wavefront)
-      const int64_t need = (int64_t)n_utt * kRangeSlots * 2;
-      if (c->band_ranges_cap < need) {
-        MFA_HIP_CHECK(c, hipStreamSynchronize(c->stream));
-        if (c->d_band_ranges) (void)hipFree(c->d_band_ranges);
-        c->d_band_ranges = nullptr; c->band_ranges_cap = 0;
-        MFA_HIP_CHECK(c, hipMalloc((void **)&c->d_band_ranges, (size_t)need * sizeof(int32_t)));
-        c->band_ranges_cap = need;
-      }
-      p.ranges = c->d_band_ranges;
-      hipLaunchKernelGGL(gmm_band_ranges_kernel, dim3((unsigned)((n_utt + 3) / 4)), dim3(256), 0, c->stream, p);
-    }
     if (f16_ok) {
       p.wh = (const uint4 *)c->d_wh; p.gch = c->d_gch; p.fscale = c->d_fscale;
       p.acc_scale_inv = 1.0f / c->gmm_acc_scale;

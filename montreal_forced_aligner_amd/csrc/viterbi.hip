@@ -78,6 +78,13 @@ struct VitParams {
   u32 *w_redo;                         // [n_utt]
   int npark;                           // stride (tokens) of the parked lists: the large tier's capacity, whatever tier runs
   VitState *w_vstate;                  // [n_utt]
+  // Speculative look-ahead (first-beam windowed pass): the window was scored for a band narrower than the proven one; the
+  // decoder checks every score it reads against the column ranges that were scored (spec_ranges, see mfa_band_ranges) and
+  // gives the utterance up (ST_GROW: decoded again from frame 0 by the list pass, proven bands) the moment one lies outside.
+  int spec;                            // 1: check
+  const int32_t *spec_ranges;          // [n_utt][kMfaRangeSlots][2]
+  const int32_t *spec_class_counts;    // [n_utt][6]
+  int spec_groups;                     // runs of class 0 in the plan (0/1: one)
   const int32_t *state_depth;          // [total_states][2] {fewest arcs from start, most arcs from start} (mfa_score_plan)
   int32_t *band;                       // [n_utt][2] out: {min longest-path depth of a live token, max BFS depth + next_window - 1}
   // outputs
@@ -166,6 +173,30 @@ __device__ __forceinline__ double cand_cost(float w, double cost, float ll, floa
     __builtin_amdgcn_wave_barrier();                       \
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
   } while (0)
+
+// Columns scored for the current window as a bitmap in LDS (one wavefront; kBmWords × 32 columns).
+constexpr int kBmWords = 64;
+__device__ __forceinline__ void build_scored_bitmap(const VitParams &p, int utt, int lane, u32 *bm) {
+  for (int i = lane; i < kBmWords; i += 64) bm[i] = 0u;
+  WSYNC();
+  const int32_t *rg = p.spec_ranges + (size_t)utt * kMfaRangeSlots * 2;
+  const int32_t *cc6 = p.spec_class_counts + (size_t)utt * 6;
+  const int runs = p.spec_groups > 1 ? p.spec_groups : 1;
+  for (int slot = 0; slot < kMfaRangeSlots; slot++) {
+    if (slot < kMfaRunSlots && slot >= runs) continue;
+    int base = 0;                                                            // first column of the slot's class
+    if (slot == kMfaRunSlots + 3) base = cc6[0];                             // class 1
+    else if (slot == kMfaRunSlots + 4) base = cc6[0] + cc6[1] + cc6[2] + cc6[3] + cc6[4];   // class 5
+    else if (slot >= kMfaRunSlots) { base = cc6[0] + cc6[1]; for (int k = 2; k < slot - kMfaRunSlots + 2; k++) base += cc6[k]; }
+    const int a = base + rg[2 * slot], b = base + rg[2 * slot + 1];
+    for (int c = a + lane; c < b; c += 64)
+      if (c >= 0 && c < 32 * kBmWords) atomicOr(&bm[c >> 5], 1u << (c & 31));
+  }
+  WSYNC();
+}
+__device__ __forceinline__ bool column_scored(const u32 *bm, int col) {
+  return (u32)col < (u32)(32 * kBmWords) && ((bm[col >> 5] >> (col & 31)) & 1u) != 0u;
+}
 
 // ReachedFinal / best final token, traceback, outputs (transition-ids, words, likelihood) of one utterance whose frame
 // loop has ended with `n` tokens in (c_state, c_cost) after `t` frames.  One wavefront; shared by the frame-loop kernels
@@ -327,6 +358,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   u32 *cntord = s_bucket + N + (kListsInLds ? 4 * N : 0);  // [C] bucket sizes at leader ordinals → exclusive sums
   float *ll_row = (float *)(cntord + C);      // [llcap] this frame's score row
   u32 *ctr = (u32 *)(ll_row + p.llcap);       // [2]: nslots, nstash
+  u32 *bm = ctr + 4;                          // [kBmWords] columns scored for this window (speculative look-ahead only)
 
   u32 *st_a = p.w_stash_a + (size_t)utt * C;
   u32 *st_b = p.w_stash_b + (size_t)utt * C;
@@ -383,6 +415,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 #pragma unroll
   for (int r = 0; r < kPre; r++) pre[r] = (row_cached && t < T && lane + 64 * r < P) ? ll[(size_t)t * P + lane + 64 * r] : 0.0f;
   WSYNC();
+  const bool spec = p.spec != 0 && p.windowed;
+  if (spec) build_scored_bitmap(p, utt, lane, bm);
+  bool viol = false;   // a score outside the scored columns was read this window
 
 #ifdef VIT_STAMPS
   unsigned long long stamp_acc[12] = {0}, stamp_last;
@@ -421,6 +456,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
       float v = ll_row[row_cached ? col : 0];   // LDS read, always (column 0 when the row is not staged)
       if (!row_cached) v = *(const volatile float *)&llt[col];  // rows wider than the LDS cache: straight from HBM/L2
       // (volatile: otherwise the two loads are merged back into one FLAT load of a selected address)
+      if (spec) viol |= !column_scored(bm, col);
       return v;
     };
     // Next frame's score row: requested after this frame's last dependent global load (vmcnt retires in order, so a
@@ -712,6 +748,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     WSYNC();
     const u32 nslots = ctr[0], nstash = ctr[1];
     if (__any(bad_degree)) { status = ST_UNSUPPORTED; break; }
+    if (spec && __any(viol)) { status = ST_TOKEN_OVERFLOW; break; }   // reported as ST_GROW (p.grow): the list pass decodes it again
     if (nslots > (u32)N || nstash > (u32)C || cand_base > (u32)C) { status = ST_TOKEN_OVERFLOW; break; }
     if (nslots == 0) { n = 0; t++; break; }  // everything pruned: no surviving token
 
@@ -912,6 +949,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
   u32 *l_an0 = l_state0 + 2 * N;             // [2][N]
   u32 *cntord = l_an0 + 2 * N;               // [C]: owner map of the candidate ordinals, then bucket sizes → exclusive sums
   u32 *ctr = cntord + C;                     // [2]
+  u32 *bm = ctr + 4;                         // [kBmWords] columns scored for this window (speculative look-ahead only)
   // (no staged score row: a candidate reads its score straight from L2 — measured faster than the general kernel's LDS
   //  row cache here, and 2 KB less LDS per wavefront leaves room for a scoring workgroup next to sixteen of these)
 
@@ -930,8 +968,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
   }
   const int t_stop = min(T, p.t_end);
   WSYNC();
+  const bool spec = p.spec != 0;
+  if (spec) build_scored_bitmap(p, utt, lane, bm);
 
-  bool overflow = false;
+  bool overflow = false, spec_fail = false;
   bool have_best = false;
   double best_carry = 0.0;
   for (; t < t_stop; t++) {
@@ -1004,6 +1044,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
       }
     }
     WSYNC();
+    if (spec) {   // every score read below must be one that was computed for this window
+      bool viol = false;
+#pragma unroll
+      for (int r = 0; r < kRounds; r++) viol |= (u32)lane + 64u * r < ctot && !column_scored(bm, colv[r]);
+      if (__any(viol)) { spec_fail = true; break; }
+    }
     if (narc > 0u) cntord[cb] = 0u;                   // owner map read by every round: back to zero for the ordering pass
     double nw[kRounds];
 #pragma unroll
@@ -1154,6 +1200,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     WSYNC();
   }
   if (overflow) { hand_over(); return; }
+  if (spec_fail) {   // the narrow band did not hold: the list pass decodes the utterance again from frame 0 with proven bands
+    if (lane == 0) {
+      VitState vs; vs.n = 0; vs.cur = 0; vs.done = 1; vs.pad0 = 0; vs.H = H; vs.pad1 = 0; vs.bp_used = bp_used;
+      p.w_vstate[utt] = vs;
+      p.w_hash[utt] = H;
+      p.status[utt] = ST_GROW; p.n_words[utt] = 0; p.like[utt] = 0.0f;
+    }
+    return;
+  }
   __threadfence_block();
   u32 *c_state = l_state0 + cur * N;
   double *c_costp = l_cost0 + cur * N;
@@ -1248,7 +1303,7 @@ int hash_bits(int S, int N) {
 size_t lds_bytes(int S, int N, int C, bool lists_in_lds) {
   const int hb = hash_bits(S, N);
   const size_t table = hb ? ((size_t)4 << hb) : (size_t)((S + 1) & ~1) * 4;
-  return (size_t)N * 8 + table + (size_t)N * 7 * 4 + (size_t)C * 4 + (size_t)kLlCap * 4 + 16 +
+  return (size_t)N * 8 + table + (size_t)N * 7 * 4 + (size_t)C * 4 + (size_t)kLlCap * 4 + 16 + (size_t)kBmWords * 4 +
          (lists_in_lds ? (size_t)N * 32 : 0);
 }
 constexpr size_t kLdsLimit = 160 * 1024;
@@ -1353,16 +1408,31 @@ int align_impl(mfa_ctx *c, const mfa_graph_batch *g, const float *d_loglikes, co
   // MFA_VIT_TIER overrides (diagnostics).
   int kSmallTokens = lazy ? 64 : 128;
   { const char *e = getenv("MFA_VIT_TIER"); if (e && atoi(e) >= 64) kSmallTokens = (atoi(e) + 63) & ~63; }
+  // Speculative look-ahead of the windowed first-beam pass.  The proven band lets a token advance one arc per frame, K − 1
+  // arcs by the window's last frame; speech advances a third of that (synthetic 10 s utterances: 21 states per 64 frames on
+  // average, 34 at the 99th percentile, 38 at most).  The window is scored for a look-ahead of 3/4 K arcs instead (48 for
+  // K = 64: 16 % fewer cells, no utterance of the bench workload exceeds it; 40: 25 % fewer cells, 2 % of the utterances
+  // fail somewhere), the decoder checks every score it reads against what was scored, and an utterance that asks for more
+  // is decoded again from frame 0 by the list pass below with the proven bands — results cannot differ.
+  // MFA_LAZY_LOOKAHEAD=n overrides (n >= K − 1: off).
+  int spec_slack = 0;
+  if (lazy) {
+    int look = lazy->window * 3 / 4;
+    { const char *e = getenv("MFA_LAZY_LOOKAHEAD"); if (e && atoi(e) > 0) look = atoi(e); }
+    spec_slack = std::max(0, lazy->window - 1 - look);
+    if (lazy->plan.max_cols > 32 * kBmWords) spec_slack = 0;   // (the decoder's bitmap of scored columns holds 2 048)
+  }
   if (lazy && N[0] > kSmallTokens) {
     // windowed first-beam pass: the small tier decodes every window; the few utterances it cannot hold in a window are
     // decoded again — that window only, from the state parked at its start — by the large tier (LDS-resident lists,
     // so at most 1 024 tokens; beyond that a from-scratch pass with HBM-resident lists follows, as in the dense path)
     const int nb = std::min(N[0], 1024);
     const int cb = std::min(C[0], 4 * nb);
-    Launch a{0, kSmallTokens, std::min(C[0], 4 * kSmallTokens), 0, nb < N[0] ? 1 : 0};
+    const bool second = nb < N[0] || spec_slack > 0;   // a from-scratch list pass: table growth, failed speculation
+    Launch a{0, kSmallTokens, std::min(C[0], 4 * kSmallTokens), 0, second ? 1 : 0};
     a.N2 = nb; a.C2 = cb;
     plan.push_back(a);
-    if (nb < N[0]) plan.push_back({0, N[0], C[0], ST_GROW, 0});
+    if (second) plan.push_back({0, N[0], C[0], ST_GROW, 0});
   } else if (N[0] > kSmallTokens) {
     int cs = std::min(C[0], 4 * kSmallTokens);
     plan.push_back({0, kSmallTokens, cs, 0, 1});
@@ -1437,7 +1507,7 @@ int align_impl(mfa_ctx *c, const mfa_graph_batch *g, const float *d_loglikes, co
     };
     // first tier of the windowed pass: the dedicated 64-token kernel (MFA_VIT_LEAN=0: the general kernel as first tier)
     constexpr int kSmallRounds = 3;
-    const size_t lds_small = (size_t)kSmallN * (8 + 16 + 6 * 4 + 8 + 8) + 256 * 4 + (size_t)64 * kSmallRounds * 4 + 16;
+    const size_t lds_small = (size_t)kSmallN * (8 + 16 + 6 * 4 + 8 + 8) + 256 * 4 + (size_t)64 * kSmallRounds * 4 + 16 + (size_t)kBmWords * 4;
     bool lean = lazy && L.N2 > 0 && lists_in_lds && L.code == 0 && L.N == kSmallN;
     { const char *e = getenv("MFA_VIT_LEAN"); if (e && e[0] == '0') lean = false; }
     if (!lazy) {
@@ -1453,10 +1523,15 @@ int align_impl(mfa_ctx *c, const mfa_graph_batch *g, const float *d_loglikes, co
         MfaWindowScore ws;
         ws.t_begin = t0; ws.window = K; ws.band = p.band; ws.utt_list = p.utt_list; ws.n_list = p.n_list;
         ws.cols_per_wave = L.code == 0 ? 0 : 32;   // list passes: few utterances, wide bands — spread the columns over wavefronts
+        const bool spec = L.code == 0 && L.N2 > 0 && lists_in_lds && spec_slack > 0;   // (only the tiered first-beam pass speculates)
+        ws.hi_slack = spec ? spec_slack : 0;
         ws.done = (const int32_t *)(base + w.vstate); ws.done_stride = (int)(sizeof(VitState) / 4); ws.done_word = 2;
         if (mfa_gmm_score_window(c, lazy, &ws, d_frame_off, n_utt, d_ll_off, (float *)d_loglikes) != 0) return -1;
         MFA_DEBUG_POINT(c, "scored window t0=%d K=%d pass=%d code=%d N=%d C=%d", t0, K, ps, L.code, L.N, L.C);
         p.t_begin = t0; p.t_end = t0 + K;
+        p.spec = spec ? 1 : 0; p.spec_ranges = mfa_band_ranges(c); p.spec_class_counts = lazy->plan.d_class_counts;
+        p.spec_groups = lazy->plan.groups;
+        p2.spec = p.spec; p2.spec_ranges = p.spec_ranges; p2.spec_class_counts = p.spec_class_counts; p2.spec_groups = p.spec_groups;
         if (L.N2 > 0 && lists_in_lds) {
           p.redo_mode = 1;
           if (lean) {

@@ -314,3 +314,27 @@ def test_lazy_window_edges_and_empty_transcript(engine, tri):
     assert st[6] in (0, 1)                                           # silence-only graph aligns
     assert st[7] == 2                                                # too much text for the audio: failed, reported as such
     assert all(s in (0, 1, 2) for s in st)
+
+
+@pytest.mark.parametrize("lookahead", [6, 24])
+def test_speculative_lookahead_failures_fall_back_to_the_proven_band(engine, tri, lookahead, monkeypatch):
+    """The first-beam windows are scored for a look-ahead of 40 arcs instead of the proven 63; a decoder that reads a score
+    outside what was scored gives the utterance up and the list pass decodes it again with proven bands.  Forced here with
+    look-aheads far too short (almost every utterance fails its first windows): every output still equals the dense path's."""
+    world, model, lda, fm, feats_of = tri
+    engine.load_gmm(model.am)
+    utts = [world.utterance(7500 + i, n_words=nw, samples=ns) for i, (nw, ns) in enumerate([(30, 160000), (10, 60000), (2, 9000), (35, 200000)])]
+    gc = G.TrainingGraphCompiler(model.tm, model.tree, world.lexicon)
+    scaled = model.tm.scaled_log_probs(1.0, 0.1)
+    fsts = [G.add_transition_probs(gc.compile_fst(u[1]), scaled) for u in utts]
+    feats, fo = feats_of([u[0] for u in utts], [u[3] for u in utts])
+    graphs = engine.pack_graphs(fsts, model.tm)
+    kw = dict(beam=10.0, retry_beam=40.0, max_tokens=1024, bp_tokens_per_frame=256)
+    _, _, fill_default = _both(engine, graphs, feats, fo, **kw)
+    monkeypatch.setenv("MFA_LAZY_LOOKAHEAD", str(lookahead))
+    dense, lazy, fill_forced = _both(engine, graphs, feats, fo, **kw)
+    monkeypatch.setenv("MFA_LAZY_LOOKAHEAD", "63")           # speculation off: the proven band
+    _, _, fill_proven = _both(engine, graphs, feats, fo, **kw)
+    assert set(dense["status"].cpu().tolist()) <= {0, 1}
+    assert fill_default < fill_proven                         # the default look-ahead scores fewer cells than the proven band
+    assert fill_forced > fill_default                         # and the forced failures really went through the list pass
