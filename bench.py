@@ -76,6 +76,9 @@ def parse_args(argv=None):
                          "table-growth passes over a handful of utterances — run under the next steps' kernels, and "
                          "latency-bound kernels of different steps share the chip (GPU_MAX_HW_QUEUES is raised to 8: with the "
                          "runtime's default of 4 hardware queues more than three streams queue up behind each other)")
+    ap.add_argument("--hf-buffers", type=int, default=2,
+                    help="device PCM buffers per pipeline in the host-fed loop (2: the H2D of a pipeline's next step "
+                         "travels under its current step)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo to rehearse "
                                                            "several ranks on one GPU)")
     ap.add_argument("--verbose", action="store_true")
@@ -384,7 +387,7 @@ def main():
         # stream, so the H2D of one step travels under the kernels of the other pipeline's step (and, with one pipeline,
         # two buffers alternate: the copy of step i+1 under the kernels of step i)
         n_hf = max(3, min(args.steps, 10))
-        n_buf = 2 if n_inflight == 1 else 1
+        n_buf = args.hf_buffers
         bufs = [[torch.empty_like(pcm_all) for _ in range(n_buf)] for _ in pipes]
         copy_streams = [torch.cuda.Stream(dev) for _ in pipes]
         ev_copied = [[torch.cuda.Event() for _ in range(n_buf)] for _ in pipes]
@@ -416,7 +419,7 @@ def main():
                 ev_free[k][b_].record(streams[k])
                 pipes[k].outputs_to_host(host_outs[k])
 
-        for _ in range(n_inflight):
+        for _ in range(2 * n_inflight):
             step_host_fed()                                  # warm-up (first copies not overlapped)
         torch.cuda.synchronize()
         dt_hf = timed_loop(step_host_fed, n_hf)
