@@ -77,6 +77,7 @@ struct mfa_ctx {
   float *d_w_stats = nullptr;  // packed rows of the fMLLR statistics model (two-model form; mfa_fmllr_stats_model) or NULL
   bool has_slot_class[5] = {false, false, false, false, false};   // model has pdfs of slot 32 / 16 / 8 / 4 / 1 rows
   bool has_single32 = false;       // some pdf is one 32-row block (17–32 Gaussians): gmm_split_single_kernel has work
+  int max_nblk = 1;                // most 32-row blocks of any pdf
   bool has_multi_block = false;    // some pdf has more than 32 Gaussians (several blocks, merged by gmm_bf16_kernel<…, true>)
   bool all_single_block = false;   // every pdf occupies exactly one 32-row block (no work for the f32 kernel in bf16 mode)
   int32_t *d_nrows = nullptr;  // [num_pdfs] packed rows per pdf (fmllr.hip)

@@ -93,6 +93,8 @@ struct GmmParams {
   const int32_t *group_counts; // [n_utt][groups]
   int b_split;                 // 1: this launch's grid holds `groups` workgroups per four sub-tiles (gmm_band_kernel)
   int b_hi_slack;              // band mode: arcs taken off the band's upper depth bound (speculative look-ahead), 0 = none
+  int col_nb_packed;           // 1: col_row0 of a pdf of several blocks carries (blocks − 1) in its five low bits (rows of
+                               //    the 32-row classes are multiples of 32; models whose largest pdf has ≤ 1 024 Gaussians)
 };
 
 // Band of one (utterance, window): pdf j of a class is needed iff first_frame[j] <= hi and last_depth[j] >= lo; both keys
@@ -1483,7 +1485,12 @@ __global__ __launch_bounds__(256, 2) void gmm_split_small_kernel(GmmParams p) {
 __global__ void gmm_col_rows_kernel(GmmParams p, int32_t *out) {
   const int utt = blockIdx.x;
   const int64_t l0 = p.pdf_off[utt], l1 = p.pdf_off[utt + 1];
-  for (int64_t j = l0 + threadIdx.x; j < l1; j += blockDim.x) out[j] = p.row0[p.pdf_list[j]];
+  for (int64_t j = l0 + threadIdx.x; j < l1; j += blockDim.x) {
+    const int pdf = p.pdf_list[j];
+    int r = p.row0[pdf];
+    if (p.col_nb_packed) { const int nb = p.nblk[pdf]; if (nb > 1) r |= nb - 1; }
+    out[j] = r;
+  }
 }
 
 // Lazy scoring, once per window: the band's index range [lo, hi) in every run of class 0 (slots 0..groups-1; one run when the
@@ -1685,14 +1692,27 @@ __global__ __launch_bounds__(256, 2) void gmm_band_kernel(GmmParams p) {
     if (chunk != 0) { hi_c[2] = lo_c[2]; hi_c[3] = lo_c[3]; hi_c[4] = lo_c[4]; }
   }
   if (p.b_split) {
-    // the small-slot classes have no runs: their band is cut into `groups` pieces of whole virtual blocks (32 / slot pdfs),
-    // one per wavefront of the sub-tile — all of them on run 0's wavefront would be all of them on one XCD
+    // the small-slot classes have no runs: the virtual blocks (32 / slot pdfs each) of their three bands, laid end to end,
+    // are cut into `groups` pieces, one per wavefront of the sub-tile — all of them on run 0's wavefront would be all of
+    // them on one XCD, and a piece of every class on every wavefront (the first version) was three pipelines to fill and
+    // drain per wavefront, three or four blocks each: a piece now lies inside one class, rarely two
+    int nb_c[5], tot = 0;
 #pragma unroll
     for (int cls = 2; cls < 5; cls++) {
       const int kp = cls == 2 ? 2 : (cls == 3 ? 4 : 8);
-      const int jb0 = lo_c[cls] / kp, jb1 = (hi_c[cls] + kp - 1) / kp;
-      const int per = (jb1 - jb0 + p.groups - 1) / p.groups;
-      const int a = jb0 + grp * per, b = min(jb1, a + per);
+      nb_c[cls] = (hi_c[cls] + kp - 1) / kp - lo_c[cls] / kp;
+      if (lo_c[cls] >= hi_c[cls]) nb_c[cls] = 0;
+      tot += nb_c[cls];
+    }
+    const int per = (tot + p.groups - 1) / p.groups;
+    const int w0 = grp * per, w1 = min(tot, w0 + per);
+    int pos = 0;
+#pragma unroll
+    for (int cls = 2; cls < 5; cls++) {
+      const int kp = cls == 2 ? 2 : (cls == 3 ? 4 : 8);
+      const int jb0 = lo_c[cls] / kp;
+      const int a = jb0 + max(w0 - pos, 0), b = jb0 + min(w1 - pos, nb_c[cls]);
+      pos += nb_c[cls];
       if (a >= b) hi_c[cls] = lo_c[cls];
       else { lo_c[cls] = max(lo_c[cls], a * kp); hi_c[cls] = min(hi_c[cls], b * kp); }
     }
@@ -1849,36 +1869,61 @@ __global__ __launch_bounds__(256, 2) void gmm_band_kernel(GmmParams p) {
   // Online log-sum-exp over the pdf's blocks (running max M and sum S against it, per frame): (M, S) ← (max(M, m_b),
   // S·2^((M − M')·l2e) + s_b·2^((m_b − M')·l2e)).  Products and per-block reductions are class 0's; pad rows carry gconst
   // −1e30 and vanish in the sum.  No software pipeline: a trained model has a few such pdfs per band, if any.
-  for (int j1 = first1; j1 < hi_c[1]; j1 += step1) {
-    const int cidx = base_c[1] + j1;
-    const int r0 = __builtin_amdgcn_readfirstlane(p.col_row0[l0 + cidx]);
-    const int nb = __builtin_amdgcn_readfirstlane(p.nblk[list[cidx]]);
+  // Software pipeline as class 0's: the operands of the next block — the pdf's next one, or the first block of this
+  // wavefront's next column — are requested as soon as a step's MFMAs have been issued; the column's (row, blocks) word is
+  // looked up one column ahead.
+  if (first1 < hi_c[1]) {
     const uint4 *wsrc = (kHalf ? p.wh : p.wb) + lane;
     const float *gsrc = (kHalf ? p.gch : p.gc) + 4 * h;
-    float M[2] = {0.0f, 0.0f}, S[2] = {0.0f, 0.0f};
-    for (int bk = 0; bk < nb; bk++) {
-      const int blk = (r0 >> 5) + bk;
+    const int32_t *crow1 = p.col_row0 + l0 + base_c[1];
+    const int last1 = hi_c[1] - 1;
+    auto col_word = [&](int jj) { return crow1[min(jj, last1)]; };     // row | (blocks − 1) when packed
+    auto blocks_of = [&](int word, int jj) {
+      return p.col_nb_packed ? (word & 31) + 1 : __builtin_amdgcn_readfirstlane(p.nblk[list[base_c[1] + min(jj, last1)]]);
+    };
+    int j1 = first1;
+    int word = __builtin_amdgcn_readfirstlane(col_word(j1));
+    int nb = blocks_of(word, j1), blk = word >> 5, bk = 0;
+    int word_n = col_word(j1 + step1);                                 // stays a vector register until its column opens
+    op8 a[kSteps][kPieces];
+    f32x4 g[4];
+    {
       const uint4 *src = wsrc + (size_t)blk * kUnits;
-      f32x16 acc[2];
-      {
-        f32x4 g[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) g[q] = *reinterpret_cast<const f32x4 *>(gsrc + (size_t)blk * 32 + 8 * q);
+      for (int q = 0; q < 4; q++) g[q] = *reinterpret_cast<const f32x4 *>(gsrc + (size_t)blk * 32 + 8 * q);
 #pragma unroll
-        for (int rr = 0; rr < 16; rr++) { acc[0][rr] = g[rr >> 2][rr & 3]; acc[1][rr] = acc[0][rr]; }
-      }
+      for (int s_ = 0; s_ < kSteps; s_++)
+#pragma unroll
+        for (int q = 0; q < kPieces; q++) a[s_][q] = __builtin_bit_cast(op8, src[(s_ * kPieces + q) * 64]);
+    }
+    float M[2] = {0.0f, 0.0f}, S[2] = {0.0f, 0.0f};
+    for (;;) {
+      const bool last_blk = bk + 1 == nb;
+      const bool more_cols = j1 + step1 < hi_c[1];
+      int blk_n = blk + 1;                                             // (past the pdf's last block only when nothing follows:
+      if (last_blk) blk_n = more_cols ? __builtin_amdgcn_readfirstlane(word_n) >> 5 : blk;   //  then the same block again, unused)
+      f32x16 init, acc[2];
+#pragma unroll
+      for (int rr = 0; rr < 16; rr++) init[rr] = g[rr >> 2][rr & 3];
+      const uint4 *src = wsrc + (size_t)blk_n * kUnits;
+      const float *gn = gsrc + (size_t)blk_n * 32;
 #pragma unroll
       for (int s_ = 0; s_ < kSteps; s_++) {
-        op8 a[kPieces];
-#pragma unroll
-        for (int q = 0; q < kPieces; q++) a[q] = __builtin_bit_cast(op8, src[(s_ * kPieces + q) * 64]);
 #pragma unroll
         for (int t6 = 0; t6 < kProd; t6++)
 #pragma unroll
           for (int n = 0; n < 2; n++) {
-            if constexpr (kHalf) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[pa[t6]], b[n][s_][pb[t6]], acc[n], 0, 0, 0);
-            else acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa[t6]], b[n][s_][pb[t6]], acc[n], 0, 0, 0);
+            const f32x16 &cin = (s_ == 0 && t6 == 0) ? init : acc[n];
+            if constexpr (kHalf) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s_][pa[t6]], b[n][s_][pb[t6]], cin, 0, 0, 0);
+            else acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s_][pa[t6]], b[n][s_][pb[t6]], cin, 0, 0, 0);
           }
+        if (s_ == 0) {
+#pragma unroll
+          for (int q = 0; q < 4; q++) g[q] = *reinterpret_cast<const f32x4 *>(gn + 8 * q);
+        }
+#pragma unroll
+        for (int q = 0; q < kPieces; q++) a[s_][q] = __builtin_bit_cast(op8, src[(s_ * kPieces + q) * 64]);
+        __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
       for (int n = 0; n < 2; n++) {
@@ -1893,9 +1938,16 @@ __global__ __launch_bounds__(256, 2) void gmm_band_kernel(GmmParams p) {
           M[n] = mn;
         }
       }
+      blk = blk_n;
+      if (!last_blk) { bk++; continue; }
+      const int t = t_base + 32 * h + col;
+      if (t < T) __builtin_nontemporal_store(finish((h ? M[1] : M[0]) * inv_s, h ? S[1] : S[0]), &out[(size_t)t * P + base_c[1] + j1]);
+      if (!more_cols) break;
+      j1 += step1;
+      word = __builtin_amdgcn_readfirstlane(word_n);
+      nb = blocks_of(word, j1); bk = 0;
+      word_n = col_word(j1 + step1);
     }
-    const int t = t_base + 32 * h + col;
-    if (t < T) __builtin_nontemporal_store(finish((h ? M[1] : M[0]) * inv_s, h ? S[1] : S[0]), &out[(size_t)t * P + cidx]);
   }
 
   // ---------------------------------------------------------------- classes 2, 3, 4: 32 / slot pdfs per virtual block
@@ -2235,11 +2287,13 @@ MFA_API int mfa_load_gmm(mfa_ctx *c, int32_t dim, int32_t num_pdfs, const int32_
   if (c->d_nrows) { (void)hipFree(c->d_nrows); c->d_nrows = nullptr; }
   c->all_single_block = true;   // (name kept: "all pdfs are 32-row pdfs", single- or multi-block)
   c->has_multi_block = false;
+  c->max_nblk = 1;
   for (int q = 0; q < 5; q++) c->has_slot_class[q] = false;
   c->has_single32 = false;
   for (int p = 0; p < num_pdfs; p++) {
     if (slot[p] != 32) c->all_single_block = false;
     if (nblk[p] > 1) c->has_multi_block = true;
+    c->max_nblk = std::max(c->max_nblk, nblk[p]);
     if (slot[p] == 32 && nblk[p] == 1) c->has_single32 = true;
     c->has_slot_class[class_index(slot[p])] = true;
   }
@@ -2615,6 +2669,7 @@ int mfa_gmm_presplit(mfa_ctx *c, const MfaLazyScoring *lazy, const int64_t *d_fr
     GmmParams q;
     memset(&q, 0, sizeof(q));
     q.row0 = c->d_row0; q.pdf_list = lazy->plan.d_pdf_list; q.pdf_off = lazy->plan.d_pdf_off; q.n_utt = n_utt;
+    q.nblk = c->d_nblk; q.col_nb_packed = c->max_nblk <= 32 ? 1 : 0;
     hipLaunchKernelGGL(gmm_col_rows_kernel, dim3(n_utt), dim3(256), 0, c->stream, q, c->d_col_row0);
     MFA_HIP_CHECK(c, hipGetLastError());
   }
@@ -2707,6 +2762,7 @@ int mfa_gmm_score_window(mfa_ctx *c, const MfaLazyScoring *lazy, const MfaWindow
     p.redo = c->d_gmm_redo;
     p.wb = (const uint4 *)c->d_wb;
     p.col_row0 = c->d_col_row0;
+    p.col_nb_packed = c->max_nblk <= 32 ? 1 : 0;
     if (f16_ok) {
       p.wh = (const uint4 *)c->d_wh; p.gch = c->d_gch; p.fscale = c->d_fscale;
       p.acc_scale_inv = 1.0f / c->gmm_acc_scale;
