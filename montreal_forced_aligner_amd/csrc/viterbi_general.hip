@@ -44,7 +44,8 @@ struct GenParams {
   int32_t *rev;                                           // [n_utt][rev_cap] reversed best path (arc indices)
   int rev_cap;
   int32_t *ali; int32_t *words; int32_t *n_words; float *like; float *frame_like; int32_t *status;
-  int n_utt;
+  int n_utt;                                              // end of the launch's utterance range
+  int utt_base;                                           // its first utterance (the batch is decoded in chunks that fit the workspace cap)
 };
 
 // One utterance, one thread: the oracle's FasterDecoder (oracle/mfa_oracle.cpp) with arrays in place of std::vector.
@@ -74,12 +75,13 @@ struct Decoder {
     const int64_t f0 = p.frame_off[u];
     T = (int)(p.frame_off[u + 1] - f0);
     ll = p.ll + p.ll_off[u]; P = p.ll_cols[u];
-    const int64_t po = p.pool_off[u];
-    pool_cap = p.pool_off[u + 1] - po;
+    const int w = u - p.utt_base;                  // workspace slot: the launch covers utterances [utt_base, n_utt)
+    const int64_t po = p.pool_off[w];
+    pool_cap = p.pool_off[w + 1] - po;
     tok_cost = p.tok_cost + po; tok_arc = p.tok_arc + po; tok_prev = p.tok_prev + po;
-    el_key = p.el_key + (size_t)u * 2 * p.ncap; el_val = p.el_val + (size_t)u * 2 * p.ncap; el_tail = p.el_tail + (size_t)u * 2 * p.ncap;
-    bk_prev = p.bk_prev + (size_t)u * p.hcap; bk_last = p.bk_last + (size_t)u * p.hcap;
-    queue = p.queue + (size_t)u * p.qcap; tmp = p.tmp + (size_t)u * p.ncap;
+    el_key = p.el_key + (size_t)w * 2 * p.ncap; el_val = p.el_val + (size_t)w * 2 * p.ncap; el_tail = p.el_tail + (size_t)w * 2 * p.ncap;
+    bk_prev = p.bk_prev + (size_t)w * p.hcap; bk_last = p.bk_last + (size_t)w * p.hcap;
+    queue = p.queue + (size_t)w * p.qcap; tmp = p.tmp + (size_t)w * p.ncap;
     hash_size = 1000 < p.hcap ? 1000 : p.hcap;
     status = G_OK;
   }
@@ -283,7 +285,7 @@ struct Decoder {
 };
 
 __global__ __launch_bounds__(64) void viterbi_general_kernel(GenParams p) {
-  const int utt = blockIdx.x * blockDim.x + threadIdx.x;
+  const int utt = p.utt_base + blockIdx.x * blockDim.x + threadIdx.x;
   if (utt >= p.n_utt) return;
   Decoder d(p, utt);
   const int64_t f0 = p.frame_off[utt];
@@ -308,7 +310,7 @@ __global__ __launch_bounds__(64) void viterbi_general_kernel(GenParams p) {
     if (c < best_cost && c != INFINITY) { best_cost = c; best_tok = d.el_val[e]; }
   }
   if (best_tok < 0) { fail(G_FAILED); return; }
-  int32_t *rev = p.rev + (size_t)utt * p.rev_cap;
+  int32_t *rev = p.rev + (size_t)(utt - p.utt_base) * p.rev_cap;
   int n_rev = 0;
   for (int tok = best_tok; tok != -1; tok = d.tok_prev[tok]) {
     if (n_rev >= p.rev_cap) { fail(G_INTERNAL); return; }
@@ -361,42 +363,61 @@ MFA_API int mfa_align_general_batch(mfa_ctx *c, const mfa_graph_batch *g, const 
   p.ncap = (max_states + 63) & ~63;
   p.hcap = 2 * p.ncap > 1000 ? 2 * p.ncap : 1000;
   p.qcap = 8 * p.ncap;
-  int64_t max_frames = 0, total_frames = h_frame_off[n_utt];
+  int64_t max_frames = 0;
   for (int u = 0; u < n_utt; u++) max_frames = std::max<int64_t>(max_frames, h_frame_off[u + 1] - h_frame_off[u]);
   const int ppf = std::min<int64_t>(max_arcs, std::max(4 * (o->bp_tokens_per_frame > 0 ? o->bp_tokens_per_frame : 512), 256));
   p.ppf = ppf;
   p.rev_cap = (int)(4 * max_frames + 64);
-  std::vector<int64_t> pool_off(n_utt + 1, 0);
-  for (int u = 0; u < n_utt; u++) pool_off[u + 1] = pool_off[u] + 2 + (h_frame_off[u + 1] - h_frame_off[u]) * (int64_t)ppf;
-  (void)total_frames;
-  size_t off = 0;
-  auto take = [&](size_t bytes) { size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
-  const size_t o_cost = take((size_t)pool_off[n_utt] * 8), o_arc = take((size_t)pool_off[n_utt] * 4), o_prev = take((size_t)pool_off[n_utt] * 4);
-  const size_t o_poff = take((size_t)(n_utt + 1) * 8);
-  const size_t o_ek = take((size_t)n_utt * 2 * p.ncap * 4), o_ev = take((size_t)n_utt * 2 * p.ncap * 4), o_et = take((size_t)n_utt * 2 * p.ncap * 4);
-  const size_t o_bp = take((size_t)n_utt * p.hcap * 4), o_bl = take((size_t)n_utt * p.hcap * 4);
-  const size_t o_q = take((size_t)n_utt * p.qcap * 4), o_tmp = take((size_t)n_utt * p.ncap * 8);
-  const size_t o_rev = take((size_t)n_utt * p.rev_cap * 4);
-  if (c->gen_ws_bytes < off) {
-    if (c->d_gen_ws) { MFA_HIP_CHECK(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->d_gen_ws); c->d_gen_ws = nullptr; c->gen_ws_bytes = 0; }
-    MFA_HIP_CHECK(c, hipMalloc(&c->d_gen_ws, off));
-    c->gen_ws_bytes = off;
-  }
-  unsigned char *base = (unsigned char *)c->d_gen_ws;
-  p.tok_cost = (double *)(base + o_cost); p.tok_arc = (int32_t *)(base + o_arc); p.tok_prev = (int32_t *)(base + o_prev);
-  p.pool_off = (const int64_t *)(base + o_poff);
-  p.el_key = (int32_t *)(base + o_ek); p.el_val = (int32_t *)(base + o_ev); p.el_tail = (int32_t *)(base + o_et);
-  p.bk_prev = (int32_t *)(base + o_bp); p.bk_last = (int32_t *)(base + o_bl);
-  p.queue = (int32_t *)(base + o_q); p.tmp = (double *)(base + o_tmp); p.rev = (int32_t *)(base + o_rev);
-  MFA_HIP_CHECK(c, hipMemcpyAsync(base + o_poff, pool_off.data(), (size_t)(n_utt + 1) * 8, hipMemcpyHostToDevice, c->stream));
-  MFA_HIP_CHECK(c, hipStreamSynchronize(c->stream));   // pool_off is a host vector about to go out of scope
+  // Workspace per utterance: the token pool (frames × ppf × 16 bytes: 33 MB for 10 s at the default ppf) dominates.  The
+  // batch is decoded in chunks whose workspace stays under a cap (MFA_GENERAL_WS_GIB, default 64), one launch each.
+  const size_t per_utt_fixed = (size_t)3 * 2 * p.ncap * 4 + (size_t)2 * p.hcap * 4 + (size_t)p.qcap * 4 + (size_t)p.ncap * 8 +
+                               (size_t)p.rev_cap * 4 + 8 + 12 * 256;
+  size_t cap_bytes = (size_t)64 << 30;
+  { const char *e = getenv("MFA_GENERAL_WS_GIB"); if (e && atof(e) > 0.0) cap_bytes = (size_t)(atof(e) * (double)((size_t)1 << 30)); }
   p.ali = d_ali; p.words = d_words; p.n_words = d_n_words; p.like = d_like; p.frame_like = d_frame_like; p.status = d_status;
-  {
-    KernelTimer kt(c, MFA_K_VITERBI);
-    hipLaunchKernelGGL(viterbi_general_kernel, dim3((n_utt + 63) / 64), dim3(64), 0, c->stream, p);
+  int n_chunks = 0;
+  for (int u0 = 0; u0 < n_utt;) {
+    // the chunk [u0, u1): at least one utterance, then as many as fit
+    int u1 = u0;
+    size_t need = 0;
+    while (u1 < n_utt) {
+      const size_t add = per_utt_fixed + (size_t)(2 + (h_frame_off[u1 + 1] - h_frame_off[u1]) * (int64_t)ppf) * 16;
+      if (u1 > u0 && need + add > cap_bytes) break;
+      need += add; u1++;
+    }
+    const int nc = u1 - u0;
+    std::vector<int64_t> pool_off(nc + 1, 0);
+    for (int u = 0; u < nc; u++) pool_off[u + 1] = pool_off[u] + 2 + (h_frame_off[u0 + u + 1] - h_frame_off[u0 + u]) * (int64_t)ppf;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
+    const size_t o_cost = take((size_t)pool_off[nc] * 8), o_arc = take((size_t)pool_off[nc] * 4), o_prev = take((size_t)pool_off[nc] * 4);
+    const size_t o_poff = take((size_t)(nc + 1) * 8);
+    const size_t o_ek = take((size_t)nc * 2 * p.ncap * 4), o_ev = take((size_t)nc * 2 * p.ncap * 4), o_et = take((size_t)nc * 2 * p.ncap * 4);
+    const size_t o_bp = take((size_t)nc * p.hcap * 4), o_bl = take((size_t)nc * p.hcap * 4);
+    const size_t o_q = take((size_t)nc * p.qcap * 4), o_tmp = take((size_t)nc * p.ncap * 8);
+    const size_t o_rev = take((size_t)nc * p.rev_cap * 4);
+    if (c->gen_ws_bytes < off) {
+      if (c->d_gen_ws) { MFA_HIP_CHECK(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->d_gen_ws); c->d_gen_ws = nullptr; c->gen_ws_bytes = 0; }
+      MFA_HIP_CHECK(c, hipMalloc(&c->d_gen_ws, off));
+      c->gen_ws_bytes = off;
+    }
+    unsigned char *base = (unsigned char *)c->d_gen_ws;
+    p.tok_cost = (double *)(base + o_cost); p.tok_arc = (int32_t *)(base + o_arc); p.tok_prev = (int32_t *)(base + o_prev);
+    p.pool_off = (const int64_t *)(base + o_poff);
+    p.el_key = (int32_t *)(base + o_ek); p.el_val = (int32_t *)(base + o_ev); p.el_tail = (int32_t *)(base + o_et);
+    p.bk_prev = (int32_t *)(base + o_bp); p.bk_last = (int32_t *)(base + o_bl);
+    p.queue = (int32_t *)(base + o_q); p.tmp = (double *)(base + o_tmp); p.rev = (int32_t *)(base + o_rev);
+    MFA_HIP_CHECK(c, hipMemcpyAsync(base + o_poff, pool_off.data(), (size_t)(nc + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    MFA_HIP_CHECK(c, hipStreamSynchronize(c->stream));   // pool_off is a host vector about to go out of scope
+    p.utt_base = u0; p.n_utt = u1;
+    {
+      KernelTimer kt(c, MFA_K_VITERBI);
+      hipLaunchKernelGGL(viterbi_general_kernel, dim3((nc + 63) / 64), dim3(64), 0, c->stream, p);
+    }
+    MFA_HIP_CHECK(c, hipGetLastError());
+    u0 = u1; n_chunks++;
   }
-  MFA_HIP_CHECK(c, hipGetLastError());
-  MFA_DEBUG_POINT(c, "general decoder: %d utterances, ncap %d hcap %d ppf %d", n_utt, p.ncap, p.hcap, ppf);
+  MFA_DEBUG_POINT(c, "general decoder: %d utterances in %d launches, ncap %d hcap %d ppf %d", n_utt, n_chunks, p.ncap, p.hcap, ppf);
   return 0;
 }
 

@@ -80,7 +80,7 @@ def _check(engine, tm, am, fsts, feats, beam, retry):
     return seen
 
 
-def test_training_graphs_with_epsilon_arcs_match_the_oracle(engine, fx):
+def test_training_graphs_with_epsilon_arcs_match_the_oracle(engine, fx, monkeypatch):
     """The reference's recording and plumbing model; training graphs rewritten with epsilon arcs on a third of their
     arcs: same alignment as the oracle on the same graph, and — the rewriting being an equivalence — the same transition-ids
     as the epsilon-free graph gives on the fast path when nothing is pruned."""
@@ -96,6 +96,10 @@ def test_training_graphs_with_epsilon_arcs_match_the_oracle(engine, fx):
     assert all((f.arcs["ilabel"] == 0).any() for f in fsts)
     for beam, retry in ((100.0, 400.0), (10.0, 40.0), (1.0e4, 0.0)):
         _check(engine, tm, am, fsts, feats, beam, retry)
+    # a workspace cap that holds one utterance at a time: the batch is decoded in three launches, same results
+    monkeypatch.setenv("MFA_GENERAL_WS_GIB", "0.001")
+    _check(engine, tm, am, fsts, feats, 10.0, 40.0)
+    monkeypatch.delenv("MFA_GENERAL_WS_GIB")
     # equivalence with the epsilon-free graphs on the fast path (no pruning: beam 1e4)
     engine.load_gmm(am)
     fo = np.concatenate([[0], np.cumsum([x.shape[0] for x in feats])]).astype(np.int64)

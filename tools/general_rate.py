@@ -1,0 +1,73 @@
+"""Rate of the general-graph decoder (mfa_align_general_batch: ε input arcs, one thread per utterance) on configs[2]-shaped
+utterances whose training graphs were rewritten with ε arcs on a third of their arcs — next to the fast path on the
+equivalent ε-free graphs.  GPU box only:  python tools/general_rate.py [n_utt]
+"""
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+from montreal_forced_aligner_amd import graph as G                      # noqa: E402
+from montreal_forced_aligner_amd.engine import AlignmentEngine          # noqa: E402
+from tests import synth                                                 # noqa: E402
+from tests.test_gpu_general import _with_eps                            # noqa: E402
+
+
+def main():
+    n_utt = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+    engine = AlignmentEngine(0)
+    world = synth.SynthWorld.build()
+    engine.configure_mfcc()
+    lda = synth.seeded_lda()
+    fm = synth.seeded_fmllr(16)
+    d_lda = torch.from_numpy(lda).to(engine.device)
+
+    def feats_of(pcm_list, spks):
+        so = np.concatenate([[0], np.cumsum([len(p) for p in pcm_list])]).astype(np.int64)
+        mfcc, fo = engine.mfcc(torch.from_numpy(np.concatenate(pcm_list)).to(engine.device), so)
+        own = np.arange(len(pcm_list), dtype=np.int32)
+        stats = engine.cmvn_stats(mfcc, fo, own, len(pcm_list))
+        per_utt = torch.from_numpy(fm[np.asarray(spks) % 16]).to(engine.device)
+        return engine.features(mfcc, fo, own, stats, lda=d_lda, fmllr=per_utt), fo
+
+    model = synth.train_triphone(world, lambda pcm, spk: feats_of([pcm], [spk])[0].cpu().numpy(), n_train=40, n_gauss=32,
+                                 n_classes=2)
+    engine.load_gmm(model.am)
+    pool = 64                                                           # distinct utterances, repeated to n_utt
+    utts = [world.utterance(9000 + i, n_words=30, samples=160000) for i in range(pool)]
+    gc = G.TrainingGraphCompiler(model.tm, model.tree, world.lexicon)
+    scaled = model.tm.scaled_log_probs(1.0, 0.1)
+    plain = [G.add_transition_probs(gc.compile_fst(u[1]), scaled) for u in utts]
+    rng = np.random.default_rng(5)
+    eps = [_with_eps(rng, f) for f in plain]
+    rep = (n_utt + pool - 1) // pool
+    pcm = [u[0] for u in utts] * rep
+    spk = [u[3] for u in utts] * rep
+    feats, fo = feats_of(pcm[:n_utt], spk[:n_utt])
+    g_fast = engine.pack_graphs((plain * rep)[:n_utt], model.tm)
+    g_gen = engine.pack_graphs_general((eps * rep)[:n_utt], model.tm)
+    kw = dict(beam=10.0, retry_beam=40.0)
+    out = {}
+    for name, fn in (("fast path, ε-free graphs", lambda: engine.align_features(g_fast, feats, fo, max_tokens=1024,
+                                                                                 bp_tokens_per_frame=256, **kw)),
+                     ("general decoder, ε graphs", lambda: engine.align_general(g_gen, feats, fo, **kw))):
+        r = fn()
+        torch.cuda.synchronize()
+        t0 = time.time()
+        n = 3
+        for _ in range(n):
+            r = fn()
+        torch.cuda.synchronize()
+        dt = (time.time() - t0) / n
+        st = r["status"].cpu().numpy()
+        out[name] = r
+        print(f"{name}: {n_utt} utterances in {dt * 1e3:.1f} ms = {n_utt / dt:.0f} utterances/s; "
+              f"aligned {(st <= 1).mean():.3f}", flush=True)
+    a, b = out["fast path, ε-free graphs"], out["general decoder, ε graphs"]
+    print("same likelihoods (|Δ| per frame):", float((a["like"] - b["like"]).abs().max()))
+
+
+if __name__ == "__main__":
+    main()
