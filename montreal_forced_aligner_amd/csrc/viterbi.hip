@@ -1023,23 +1023,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     WSYNC();
     const int rounds = (int)((ctot + 63u) >> 6);
     // ---------------- arc gather (all rounds' loads in flight together)
-    u32 tokv[kRounds], kv[kRounds], nx[kRounds], nan_[kRounds]; int colv[kRounds]; float wv[kRounds]; double tcost[kRounds];
+    u32 cidx[kRounds], nx[kRounds], nan_[kRounds]; int colv[kRounds]; float wv[kRounds]; double tcost[kRounds];
     {
       u32 carry = 0;
 #pragma unroll
       for (int r = 0; r < kRounds; r++) {
-        tokv[r] = 0; kv[r] = 0; nx[r] = 0; nan_[r] = 0; colv[r] = 0; wv[r] = 0.0f; tcost[r] = INFINITY;
+        cidx[r] = 0; nx[r] = 0; nan_[r] = 0; colv[r] = 0; wv[r] = 0.0f; tcost[r] = INFINITY;
         if (r < rounds) {   // uniform
           const u32 c = (u32)lane + 64u * r;
           const u32 own = max(incl_scan_max(cntord[c]), carry);
           carry = (u32)__builtin_amdgcn_readlane((int)own, 63);
           const bool valid = c < ctot;
           const u32 tok = valid ? own - 1u : 0u;
-          tokv[r] = tok;
           tcost[r] = valid ? c_cost[tok] : INFINITY;
           const u32 tan = c_an[tok];
-          kv[r] = valid ? c - t_cbase[tok] : 0u;
-          if (valid) { const uint4 rec = a_rec[(tan >> 7) + kv[r]]; nx[r] = rec.x; nan_[r] = rec.y; colv[r] = (int)rec.z; wv[r] = __uint_as_float(rec.w); }
+          const u32 k_ = valid ? c - t_cbase[tok] : 0u;
+          cidx[r] = (tok << kArcBits) | k_;            // (token, arc) of the candidate: what the winner records
+          if (valid) { const uint4 rec = a_rec[(tan >> 7) + k_]; nx[r] = rec.x; nan_[r] = rec.y; colv[r] = (int)rec.z; wv[r] = __uint_as_float(rec.w); }
         }
       }
     }
@@ -1050,7 +1050,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
       for (int r = 0; r < kRounds; r++) viol |= (u32)lane + 64u * r < ctot && !column_scored(bm, colv[r]);
       if (__any(viol)) { spec_fail = true; break; }
     }
-    if (narc > 0u) cntord[cb] = 0u;                   // owner map read by every round: back to zero for the ordering pass
+    const u32 cb2 = t_cbase[min(lane, N - 1)];        // (= cb for the lanes that hold a token; re-read: one register less across the gather)
+    if (narc > 0u) cntord[cb2] = 0u;                  // owner map read by every round: back to zero for the ordering pass
     double nw[kRounds];
 #pragma unroll
     for (int r = 0; r < kRounds; r++)
@@ -1060,7 +1061,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     //  wavefront reduction per round)
     double run = INFINITY;
     {
-      const u32 ob = (u32)__builtin_amdgcn_readlane((int)cb, (int)best_i), nb_ = (u32)__builtin_amdgcn_readlane((int)narc, (int)best_i);
+      const u32 ob = (u32)__builtin_amdgcn_readlane((int)cb2, (int)best_i), nb_ = (u32)__builtin_amdgcn_readlane((int)narc, (int)best_i);
       for (u32 k = 0; k < nb_; k++) {
         const u32 ord = ob + k;
         const int ln = (int)(ord & 63u);
@@ -1118,10 +1119,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
       WSYNC();
       if (ctr[0] > (u32)N) break;
     }
-    u32 cidx[kRounds];
 #pragma unroll
     for (int r = 0; r < kRounds; r++) {
-      cidx[r] = (tokv[r] << kArcBits) | kv[r];
       if (r < rounds && sl[r] != kEmpty) { atomicMin(&s_cost[sl[r]], dkey(nw[r])); atomicMin(&s_F[sl[r]], cidx[r]); }
     }
     WSYNC();
