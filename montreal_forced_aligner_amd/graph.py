@@ -447,9 +447,13 @@ class TrainingGraphCompiler:
 
     def __init__(self, transition_model: TransitionModel, tree: ContextDependency, lexicon_compiler: LexiconCompiler,
                  use_g2p: bool = False, batch_size: int = 500):
+        if use_g2p:
+            raise NotImplementedError("use_g2p (character transcripts through a G2P lexicon) is outside the alignment path built here")
         self.tm = transition_model
         self.tree = tree
         self.lexicon = lexicon_compiler
+        self.use_g2p = False
+        self.batch_size = batch_size
         if lexicon_compiler.phone_table is None:
             lexicon_compiler.build_phone_table()
         if tree.context_width not in (1, 3) or tree.central_position != tree.context_width // 2:

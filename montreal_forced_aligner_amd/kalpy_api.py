@@ -353,12 +353,40 @@ class TrainingGraphCompiler(_graph.TrainingGraphCompiler):
 
     def export_graphs(self, file_name, records: Iterable[Tuple[str, str]], write_scp: bool = False, callback=None,
                       interjection_words=None) -> None:
-        """Writes ``fsts.*.ark`` (key + OpenFst VectorFst<StdArc> binary per utterance)."""
+        """Writes ``fsts.*.ark`` (key + OpenFst VectorFst<StdArc> binary per utterance).  ``records``:
+        ``(key, text)`` pairs, or the utterance dicts CompileTrainGraphsFunction passes (``kaldi_id`` plus
+        ``normalized_text`` / ``normalized_character_text`` with ``use_g2p``; MFA/alignment/multiprocessing.py:547-571).
+        ``interjection_words`` belong to the transcript-verification workflow (``:512-536``; empty for alignment) and are
+        refused when non-empty rather than ignored."""
+        if interjection_words:
+            raise NotImplementedError("interjection words (transcript verification) are not part of the alignment path")
+        text_column = "normalized_character_text" if self.use_g2p else "normalized_text"
         with open(file_name, "wb") as f:
-            for key, text in records:
+            for rec in records:
+                key, text = (rec["kaldi_id"], rec[text_column]) if isinstance(rec, dict) else rec
                 kaldi_io.write_ark_entry(f, key, self.compile_fst(text), "fst")
                 if callback:
                     callback(key)
+
+
+class FstArchive:
+    """``FstArchive(path)`` — the training-graph table ``fsts.*.ark`` AlignFunction opens (MFA/alignment/multiprocessing.py:
+    828): iterable of ``(key, Fst)`` in file order, ``archive[key]`` for random access (KeyError when absent)."""
+
+    def __init__(self, file_name):
+        self.file_name = str(file_name)
+        self._index: Optional[Dict[str, kaldi_io.Fst]] = None
+
+    def __iter__(self):
+        return kaldi_io.read_ark(Path(self.file_name).read_bytes(), "fst")
+
+    def __getitem__(self, key: str) -> kaldi_io.Fst:
+        if self._index is None:
+            self._index = dict(iter(self))
+        return self._index[key]
+
+    def close(self) -> None:
+        self._index = None
 
 
 # ------------------------------------------------------------------------------------------------ alignment
@@ -383,7 +411,8 @@ class GmmAligner:
                  careful: bool = False):
         if careful:
             raise NotImplementedError("careful alignment is not implemented")
-        self.acoustic_model_path = acoustic_model_path
+        # (AlignFunction._run tests `.endswith(".alimdl")` on it, MFA/alignment/multiprocessing.py:842)
+        self.acoustic_model_path = acoustic_model_path if isinstance(acoustic_model_path, (bytes, bytearray)) else str(acoustic_model_path)
         self.transition_model, self.acoustic_model = _read_model(acoustic_model_path)
         self.beam, self.retry_beam = float(beam), float(retry_beam)
         if self.retry_beam != 0 and self.retry_beam <= self.beam:

@@ -110,7 +110,8 @@ def test_archives_follow_the_corpus_file_flow(fx, tmp_path):
     graphs = list(K.read_ark((tmp_path / "fsts.ark").read_bytes(), "fst"))
     aligner = KA.GmmAligner(tmp_path / "final.mdl", beam=100, retry_beam=400)
     seen = []
-    aligner.export_alignments(tmp_path / "ali.ark", graphs, feats, word_file_name=tmp_path / "words.ark",
+    assert aligner.acoustic_model_path.endswith("final.mdl")    # AlignFunction tests the suffix (multiprocessing.py:842)
+    aligner.export_alignments(tmp_path / "ali.ark", KA.FstArchive(tmp_path / "fsts.ark"), feats, word_file_name=tmp_path / "words.ark",
                               likelihood_file_name=tmp_path / "likes.ark", callback=seen.append)
     assert [k for k, _ in seen] == list(cuts) and all(like is not None for _, like in seen)
     aa = KA.AlignmentArchive(tmp_path / "ali.ark", words_file_name=tmp_path / "words.ark", likelihood_file_name=tmp_path / "likes.ark")

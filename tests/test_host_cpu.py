@@ -256,3 +256,33 @@ def test_suffix_sharing_keeps_every_path_of_the_phone_graph(fx):
     assert r_a["status"] == 0 and r_b["status"] == 0
     assert np.array_equal(r_a["words"], r_b["words"]) and np.array_equal(r_a["ali"], r_b["ali"])
     assert abs(r_a["like"] - r_b["like"]) < 1e-2
+
+
+def test_export_graphs_takes_the_references_utterance_records(fx, tmp_path):
+    """CompileTrainGraphsFunction hands export_graphs the utterance table's dicts (kaldi_id + normalized_text,
+    MFA/alignment/multiprocessing.py:547-571) and an empty interjection-cost dict for alignment workflows; the table written is
+    the one (key, text) pairs give, graph for graph.  Non-empty interjection costs (transcript verification) and use_g2p are
+    refused, not ignored."""
+    import pytest
+
+    from montreal_forced_aligner_amd import kaldi_io as K
+    from montreal_forced_aligner_amd import kalpy_api as KA
+
+    gc = KA.TrainingGraphCompiler(fx.mono_tm, fx.mono_tree, fx.mono_lex)
+    recs = [{"kaldi_id": "1-1", "normalized_text": "this is the acoustic corpus", "text": "ignored"},
+            {"kaldi_id": "1-2", "normalized_text": "um and that should be all thanks", "text": "ignored"}]
+    gc.export_graphs(tmp_path / "a.ark", recs, interjection_words={})
+    gc.export_graphs(tmp_path / "b.ark", [(r["kaldi_id"], r["normalized_text"]) for r in recs])
+    assert (tmp_path / "a.ark").read_bytes() == (tmp_path / "b.ark").read_bytes()
+    got = list(K.read_ark((tmp_path / "a.ark").read_bytes(), "fst"))
+    assert [k for k, _ in got] == ["1-1", "1-2"]
+    arch = KA.FstArchive(tmp_path / "a.ark")                   # what AlignFunction opens on the table (multiprocessing.py:828)
+    assert [k for k, _ in arch] == ["1-1", "1-2"] and arch["1-2"].num_arcs == got[1][1].num_arcs
+    with pytest.raises(KeyError):
+        arch["1-3"]
+    ref = fx.mono_gc.compile_fst(recs[1]["normalized_text"])
+    assert got[1][1].num_states == ref.num_states and np.array_equal(got[1][1].arcs, ref.arcs)
+    with pytest.raises(NotImplementedError):
+        gc.export_graphs(tmp_path / "c.ark", recs, interjection_words={"uh": 1.0})
+    with pytest.raises(NotImplementedError):
+        KA.TrainingGraphCompiler(fx.mono_tm, fx.mono_tree, fx.mono_lex, use_g2p=True)
