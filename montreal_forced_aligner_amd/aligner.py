@@ -214,7 +214,7 @@ class CorpusAligner:
         results: List[Optional[dict]] = [None] * len(utts)
         kept = []
         for idx_all in self._batches(utts):
-            fsts_all = [_graph.add_transition_probs(self.compiler.compile_fst(utts[i].text), self.scaled) for i in idx_all]
+            fsts_all = self.compiler.compile_fsts([utts[i].text for i in idx_all], self.scaled)   # native, batched
             idx, fsts, gidx, gfsts = [], [], [], []
             for i, f in zip(idx_all, fsts_all):
                 if f.num_arcs == 0 or f.num_states == 0 or np.any(f.arcs["ilabel"] < 0):

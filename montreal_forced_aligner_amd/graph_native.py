@@ -1,0 +1,239 @@
+"""Batched native training-graph compiler (libmfa_graph.so, include/mfa_graph.h) behind ``TrainingGraphCompiler``.
+
+``graph.py`` is the specification — one utterance at a time, in Python, ≈11 ms per 10 s transcript and core.  The reference
+compiles its graphs in kalpy's C++ (``TrainingGraphCompiler.compile_fst`` / ``export_graphs``,
+MFA/alignment/multiprocessing.py:537-571), and a device that aligns 200 k utterances per second needs its graphs at that
+rate: this module hands whole batches to ``csrc/graph_compile.cpp`` (one utterance per worker thread) and gets back the
+very graphs ``graph.py`` builds — same state numbers, arc order and float32 weights (tests/test_graph_native_cpu.py).
+
+The lexicon goes over as flat tables, once; the tree and the topology stay here and are consulted only for context windows
+the native side has not seen yet."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import graph as _graph
+from .kaldi_io import ARC_DTYPE, Fst
+
+_PKG = Path(__file__).resolve().parent
+_SO = _PKG / "libmfa_graph.so"
+_SRC = _PKG / "csrc" / "graph_compile.cpp"
+_HDR = _PKG.parent / "include" / "mfa_graph.h"
+
+
+def build_native(force: bool = False, verbose: bool = False) -> Path:
+    """g++ -O2 -shared of csrc/graph_compile.cpp next to this file (host code only: no hipcc, no GPU)."""
+    if not force and _SO.exists() and all(_SO.stat().st_mtime >= d.stat().st_mtime for d in (_SRC, _HDR) if d.exists()):
+        return _SO
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-ffp-contract=off",
+           "-fvisibility=hidden", "-o", str(_SO), str(_SRC)]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return _SO
+
+
+class _Pron(C.Structure):
+    _fields_ = [("phone_off", C.c_int32), ("n_phones", C.c_int32), ("c0_ns", C.c_double), ("c0_s", C.c_double),
+                ("c0_start", C.c_double), ("w_ns", C.c_double), ("w_sil", C.c_double), ("has_sil", C.c_int32),
+                ("pad", C.c_int32)]
+
+
+class _Config(C.Structure):
+    _fields_ = [("context_width", C.c_int32), ("share_suffixes", C.c_int32), ("sil_phone", C.c_int32),
+                ("n_entries", C.c_int32), ("entry_word", C.c_void_p), ("entry_pron_off", C.c_void_p), ("prons", C.c_void_p),
+                ("phones", C.c_void_p), ("cost_init_sil", C.c_double), ("cost_init_eps", C.c_double),
+                ("final_ns", C.c_double), ("final_s", C.c_double), ("n_tids", C.c_int32), ("id2state", C.c_void_p),
+                ("n_tstates", C.c_int32), ("self_loop_of", C.c_void_p)]
+
+
+_vp, _i32, _i64 = C.c_void_p, C.c_int32, C.c_int64
+SIGNATURES = {
+    "mfa_gc_create": (_vp, [C.POINTER(_Config)]),
+    "mfa_gc_destroy": (None, [_vp]),
+    "mfa_gc_last_error": (C.c_char_p, [_vp]),
+    "mfa_gc_add_windows": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp]),
+    "mfa_gc_prepare": (_i64, [_vp, _i32, _vp, _vp, _i32]),
+    "mfa_gc_missing_windows": (C.c_int, [_vp, _vp]),
+    "mfa_gc_finish": (C.c_int, [_vp, _vp, _i32, C.POINTER(_i64), C.POINTER(_i64)]),
+    "mfa_gc_fetch": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+}
+_lib = None
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not _SO.exists():
+            build_native()
+        lib = C.CDLL(str(_SO))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+class GraphCompileError(RuntimeError):
+    pass
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data
+
+
+class NativeGraphCompiler:
+    """Batch front end of a ``graph.TrainingGraphCompiler``: ``compile_batch(texts)`` → the list ``[compile_fst(t) for t in
+    texts]`` (with ``scaled_log_probs``: ``add_transition_probs`` applied), built by the native library."""
+
+    def __init__(self, compiler: _graph.TrainingGraphCompiler, n_threads: Optional[int] = None):
+        self.compiler = compiler
+        self.lib = load()
+        try:
+            avail = len(os.sched_getaffinity(0))
+        except AttributeError:
+            avail = os.cpu_count() or 1
+        self.n_threads = max(1, min(32, avail)) if n_threads is None else max(1, int(n_threads))
+        lex = compiler.lexicon
+        if lex.phone_table is None:
+            lex.build_phone_table()
+        self._width = int(compiler.tree.context_width)
+        # ---- lexicon tables: one entry per word form with pronunciations, plus the out-of-vocabulary entry (last)
+        eps_cost = _graph._cost(1.0 - lex.initial_silence_probability)
+        words = list(lex._by_word.keys())
+        self._entry_of = {}
+        entry_word, pron_off, prons, phones = [], [0], [], []
+        self._bad_entries = set()          # a pronunciation with a phone outside the table: graph.py raises when it is used
+
+        def add_entry(wid: int, plist) -> int:
+            no_probs = all(p.probability is None for p in plist)
+            mark = len(prons)
+            try:
+                for p in plist:
+                    ids = lex.phone_ids(p)
+                    pc = 0.0 if no_probs else _graph._cost(p.probability if p.probability is not None else 1.0)
+                    p_after = p.silence_after_probability if p.silence_after_probability is not None else lex.silence_probability
+                    nsb = _graph._cost(p.non_silence_before_correction)
+                    prons.append((len(phones), len(ids), pc + nsb, pc + _graph._cost(p.silence_before_correction),
+                                  eps_cost + pc + nsb, _graph._cost(1.0 - p_after), _graph._cost(p_after), 1 if p_after > 0 else 0))
+                    phones.extend(ids)
+            except KeyError:
+                del prons[mark:]
+                self._bad_entries.add(len(entry_word))
+            entry_word.append(wid)
+            pron_off.append(len(prons))
+            return len(entry_word) - 1
+
+        for w in words:
+            self._entry_of[w] = add_entry(lex.word_table.find(w), lex._by_word[w])
+        self._oov_wid = lex.word_table.find(lex.oov_word)
+        self._oov_entry = add_entry(self._oov_wid, [_graph.Pronunciation(lex.oov_word, lex.oov_phone)])
+        self._entry_word = np.asarray(entry_word, dtype=np.int32)
+        self._pron_off = np.asarray(pron_off, dtype=np.int32)
+        self._prons = (_Pron * max(1, len(prons)))()
+        for k, t in enumerate(prons):
+            self._prons[k] = _Pron(t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], 0)
+        self._phones = np.asarray(phones if phones else [0], dtype=np.int32)
+        tm = compiler.tm
+        self._id2state = np.ascontiguousarray(tm.id2state, dtype=np.int32)
+        self._self_loop_of = np.ascontiguousarray(tm.self_loop_of, dtype=np.int32)
+        cfg = _Config()
+        cfg.context_width = self._width
+        cfg.share_suffixes = 1 if lex.share_suffixes else 0
+        cfg.sil_phone = int(lex.phone_table.find(lex.silence_phone))
+        cfg.n_entries = len(entry_word)
+        cfg.entry_word = _ptr(self._entry_word); cfg.entry_pron_off = _ptr(self._pron_off)
+        cfg.prons = C.addressof(self._prons); cfg.phones = _ptr(self._phones)
+        cfg.cost_init_sil = _graph._cost(lex.initial_silence_probability)
+        cfg.cost_init_eps = eps_cost
+        cfg.final_ns = _graph._cost(lex.final_non_silence_correction)
+        cfg.final_s = _graph._cost(lex.final_silence_correction)
+        cfg.n_tids = int(self._id2state.shape[0] - 1)
+        cfg.id2state = _ptr(self._id2state)
+        cfg.n_tstates = int(self._self_loop_of.shape[0] - 1)
+        cfg.self_loop_of = _ptr(self._self_loop_of)
+        self._h = self.lib.mfa_gc_create(C.byref(cfg))
+        if not self._h:
+            raise GraphCompileError("mfa_gc_create refused the configuration")
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and self.lib is not None:
+            self.lib.mfa_gc_destroy(h)
+
+    def _check(self, rc, what):
+        if rc < 0:
+            msg = self.lib.mfa_gc_last_error(self._h)
+            raise GraphCompileError(f"{what}: {msg.decode() if msg else 'error'}")
+        return rc
+
+    def _entries(self, text: str) -> Optional[List[int]]:
+        """Lexicon entries of a transcript, or None when graph.py has to take it (a word id the tables do not hold)."""
+        lex = self.compiler.lexicon
+        out = []
+        for word in text.split():
+            w = word.lower() if lex.ignore_case else word
+            e = self._entry_of.get(w)
+            if e is None:
+                if lex.to_int(word) != self._oov_wid:
+                    return None
+                e = self._oov_entry
+            if e in self._bad_entries:
+                return None
+            out.append(e)
+        return out
+
+    def compile_batch(self, texts: Sequence[str], scaled_log_probs: Optional[np.ndarray] = None) -> List[Fst]:
+        ent = [self._entries(t) for t in texts]
+        native = [k for k, e in enumerate(ent) if e is not None]
+        out: List[Optional[Fst]] = [None] * len(texts)
+        for k, e in enumerate(ent):
+            if e is None:       # (raises what graph.py raises for an unknown phone)
+                f = self.compiler.compile_fst(texts[k])
+                out[k] = _graph.add_transition_probs(f, scaled_log_probs) if scaled_log_probs is not None else f
+        if not native:
+            return out  # type: ignore[return-value]
+        word_off = np.zeros(len(native) + 1, dtype=np.int64)
+        for j, k in enumerate(native):
+            word_off[j + 1] = word_off[j] + len(ent[k])
+        entries = np.asarray([e for k in native for e in ent[k]] or [0], dtype=np.int32)
+        missing = self._check(self.lib.mfa_gc_prepare(self._h, len(native), _ptr(word_off), _ptr(entries), self.n_threads),
+                              "mfa_gc_prepare")
+        if missing:
+            wins = np.zeros((missing, self._width), dtype=np.int32)
+            self._check(self.lib.mfa_gc_missing_windows(self._h, _ptr(wins)), "mfa_gc_missing_windows")
+            toff, trans, nfin = [0], [], []
+            for row in wins:
+                tr, n_final = self.compiler._hmm(tuple(int(x) for x in row))
+                trans.extend(tr)
+                toff.append(len(trans))
+                nfin.append(n_final)
+            t_off = np.asarray(toff, dtype=np.int32)
+            t_arr = np.asarray(trans if trans else [(0, 0, 0)], dtype=np.int32).reshape(-1, 3)
+            n_fin = np.asarray(nfin, dtype=np.int32)
+            self._check(self.lib.mfa_gc_add_windows(self._h, int(missing), _ptr(wins), _ptr(t_off), _ptr(t_arr), _ptr(n_fin)),
+                        "mfa_gc_add_windows")
+        neg = None
+        if scaled_log_probs is not None:
+            neg = np.ascontiguousarray(-scaled_log_probs.astype(np.float32))
+            if neg.shape[0] != self._id2state.shape[0]:
+                raise GraphCompileError("scaled_log_probs does not match the transition model")
+        n_states, n_arcs = C.c_int64(0), C.c_int64(0)
+        self._check(self.lib.mfa_gc_finish(self._h, _ptr(neg), self.n_threads, C.byref(n_states), C.byref(n_arcs)), "mfa_gc_finish")
+        S, A, n = int(n_states.value), int(n_arcs.value), len(native)
+        state_off = np.zeros(n + 1, dtype=np.int64)
+        arc_base = np.zeros(n + 1, dtype=np.int64)
+        arc_off = np.zeros(S + n, dtype=np.int64)
+        arcs = np.zeros(A, dtype=ARC_DTYPE)
+        final = np.zeros(S, dtype=np.float32)
+        self._check(self.lib.mfa_gc_fetch(self._h, _ptr(state_off), _ptr(arc_base), _ptr(arc_off), _ptr(arcs), _ptr(final)), "mfa_gc_fetch")
+        for j, k in enumerate(native):
+            s0, s1, a0, a1 = int(state_off[j]), int(state_off[j + 1]), int(arc_base[j]), int(arc_base[j + 1])
+            out[k] = Fst(0, arc_off[s0 + j: s1 + j + 1], arcs[a0:a1], final[s0:s1])
+        return out  # type: ignore[return-value]

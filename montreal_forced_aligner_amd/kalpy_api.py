@@ -362,11 +362,20 @@ class TrainingGraphCompiler(_graph.TrainingGraphCompiler):
             raise NotImplementedError("interjection words (transcript verification) are not part of the alignment path")
         text_column = "normalized_character_text" if self.use_g2p else "normalized_text"
         with open(file_name, "wb") as f:
+            chunk: List[Tuple[str, str]] = []
+
+            def flush():
+                for (key, _t), fst in zip(chunk, self.compile_fsts([t for _k, t in chunk])):   # native, batch_size at a time
+                    kaldi_io.write_ark_entry(f, key, fst, "fst")
+                    if callback:
+                        callback(key)
+                chunk.clear()
+
             for rec in records:
-                key, text = (rec["kaldi_id"], rec[text_column]) if isinstance(rec, dict) else rec
-                kaldi_io.write_ark_entry(f, key, self.compile_fst(text), "fst")
-                if callback:
-                    callback(key)
+                chunk.append((rec["kaldi_id"], rec[text_column]) if isinstance(rec, dict) else tuple(rec))
+                if len(chunk) >= max(1, int(self.batch_size)):
+                    flush()
+            flush()
 
 
 class FstArchive:

@@ -1,0 +1,96 @@
+"""The native batch graph compiler (libmfa_graph.so, include/mfa_graph.h) against its specification, graph.py: the same
+graphs bit for bit — start state, arc offsets, arcs (transition-id, word id, float32 weight, next state) in the same
+order, final costs — for the reference's monophone fixture (position-dependent phones, real dictionary, context width 1)
+and for a synthetic triphone model (context width 3), with and without AddTransitionProbs; out-of-vocabulary words, the
+empty transcript and one-word transcripts included.  Replaces kalpy's C++ TrainingGraphCompiler.compile_fst / export_graphs
+(MFA/alignment/multiprocessing.py:537-571) for whole batches."""
+import ctypes as C
+import re
+import time
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import synth_workload as synth
+from montreal_forced_aligner_amd import graph as G
+from montreal_forced_aligner_amd import graph_native as GN
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _same(a, b):
+    assert a.start == b.start
+    assert np.array_equal(a.arc_offsets, b.arc_offsets)
+    assert a.arcs.dtype == b.arcs.dtype and a.arcs.shape == b.arcs.shape
+    for f in ("ilabel", "olabel", "nextstate"):
+        assert np.array_equal(a.arcs[f], b.arcs[f]), f
+    assert np.array_equal(a.arcs["weight"].view(np.uint32), b.arcs["weight"].view(np.uint32)), "weights differ in their bits"
+    assert np.array_equal(a.final.view(np.uint32), b.final.view(np.uint32))
+
+
+def test_library_exports_every_declared_symbol():
+    GN.build_native()
+    lib = C.CDLL(str(GN._SO))
+    declared = set(re.findall(r"\b(mfa_gc_\w+)\s*\(", (ROOT / "include" / "mfa_graph.h").read_text()))
+    assert declared == set(GN.SIGNATURES), declared ^ set(GN.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_monophone_fixture_graphs_are_identical(fx):
+    rng = np.random.default_rng(3)
+    vocab = list(fx.mono_lex._by_word.keys())
+    texts = ["", "this", fx.text, "zzzunknown this is zzzother", "THIS Is The ACOUSTIC corpus"]
+    for _ in range(40):
+        n = int(rng.integers(1, 25))
+        words = [vocab[int(rng.integers(0, len(vocab)))] if rng.random() > 0.1 else "oov%d" % rng.integers(0, 5) for _ in range(n)]
+        texts.append(" ".join(words))
+    nat = GN.NativeGraphCompiler(fx.mono_gc, n_threads=4)
+    got = nat.compile_batch(texts)
+    for t, g in zip(texts, got):
+        _same(g, fx.mono_gc.compile_fst(t))
+    scaled = fx.mono_tm.scaled_log_probs(1.0, 0.1)
+    got = nat.compile_batch(texts, scaled)
+    for t, g in zip(texts, got):
+        _same(g, G.add_transition_probs(fx.mono_gc.compile_fst(t), scaled))
+    # one thread, and a second compiler on the same tables: nothing depends on scheduling or on what was compiled before
+    again = GN.NativeGraphCompiler(fx.mono_gc, n_threads=1).compile_batch(texts[::-1], scaled)
+    for a, b in zip(again, got[::-1]):
+        _same(a, b)
+
+
+def test_triphone_graphs_are_identical_and_fast():
+    world = synth.SynthWorld.build()
+    rng = np.random.default_rng(0)
+    model = synth.train_triphone(world, lambda pcm, spk: rng.normal(size=(len(pcm) // 160, 40)).astype(np.float32),
+                                 n_train=12, n_gauss=1)
+    gc = G.TrainingGraphCompiler(model.tm, model.tree, world.lexicon)
+    scaled = model.tm.scaled_log_probs(1.0, 0.1)
+    texts = [world.utterance(500 + i, n_words=int(rng.integers(1, 36)))[1] for i in range(48)] + ["", "nosuchword"]
+    nat = GN.NativeGraphCompiler(gc, n_threads=4)
+    t0 = time.time()
+    got = nat.compile_batch(texts, scaled)
+    t_first = time.time() - t0
+    t0 = time.time()
+    ref = [G.add_transition_probs(gc.compile_fst(t), scaled) for t in texts]
+    t_py = time.time() - t0
+    for a, b in zip(got, ref):
+        _same(a, b)
+    assert max(f.num_states for f in got) > 500
+    t0 = time.time()
+    nat.compile_batch(texts, scaled)           # context windows registered: the steady state
+    t_nat = time.time() - t0
+    print(f"native {1e3 * t_nat / len(texts):.3f} ms/utterance (first batch {1e3 * t_first / len(texts):.3f}), "
+          f"graph.py {1e3 * t_py / len(texts):.2f} ms/utterance")
+    assert t_nat < t_py / 5
+
+
+def test_bad_input_is_refused(fx):
+    nat = GN.NativeGraphCompiler(fx.mono_gc, n_threads=1)
+    word_off = np.array([0, 1], dtype=np.int64)
+    entries = np.array([10 ** 6], dtype=np.int32)
+    rc = nat.lib.mfa_gc_prepare(nat._h, 1, word_off.ctypes.data, entries.ctypes.data, 1)
+    assert rc < 0 and b"lexicon entry" in nat.lib.mfa_gc_last_error(nat._h)
+    with pytest.raises(GN.GraphCompileError):
+        nat.compile_batch(["this"], np.zeros(3, dtype=np.float32))
