@@ -276,6 +276,21 @@ MFA_API int mfa_build_score_plan_grouped(int32_t n_states, const int32_t *h_arc_
                                          int32_t *h_col_pdf, int32_t *h_col_first, int32_t *h_col_last, int32_t *h_class_counts,
                                          int32_t *h_group_counts, int32_t *h_n_cols);
 
+/* The score plans of a whole batch, utterances spread over n_threads host threads (the per-utterance call above costs more
+ * in its Python caller than in itself once graphs arrive at 20 k per second).  Graphs concatenated as the device layout
+ * has them: h_state_off / h_arc_base [n_utt + 1] prefix sums; utterance u's arc offsets (S_u + 1 values, relative to its
+ * first arc) at h_arc_off[h_state_off[u] + u]; h_arc_next / h_arc_pdf [total arcs]; h_start [n_utt].  Outputs as above,
+ * concatenated: h_state_depth [total states][2], h_arc_col [total arcs]; utterance u's columns at h_col_*[h_arc_base[u] ..
+ * + h_n_cols[u]) (capacity = its arcs); h_class_counts [n_utt][6]; h_group_counts [n_utt][groups] (groups > 1);
+ * h_n_cols [n_utt].  Returns 0, or the first failing utterance's code with its index in *h_bad_utt. */
+MFA_API int mfa_build_score_plans_batch(int32_t n_utt, const int64_t *h_state_off, const int64_t *h_arc_base,
+                                        const int32_t *h_arc_off, const int32_t *h_arc_next, const int32_t *h_arc_pdf,
+                                        const int32_t *h_start, int32_t num_pdfs, const int32_t *h_pdf_class,
+                                        int32_t cluster_span, int32_t groups, int32_t n_threads, int32_t *h_state_depth,
+                                        int32_t *h_arc_col, int32_t *h_col_pdf, int32_t *h_col_first, int32_t *h_col_last,
+                                        int32_t *h_class_counts, int32_t *h_group_counts, int32_t *h_n_cols,
+                                        int32_t *h_bad_utt);
+
 /* ---- fMLLR statistics: replaces the accumulation of CalcFmllrFunction / kalpy FmllrComputer
  *      (MFA/corpus/features.py:506-527; Kaldi FmllrDiagGmmAccs) between the two alignment passes
  *      (MFA/alignment/base.py:510-539).  d_feats [total_frames][dim]: the features the transform will be applied to;

@@ -110,6 +110,8 @@ SIGNATURES = {
     "mfa_fst_last_depths": (C.c_int, [_i32, _vp, _vp, _i32, _vp, _vp]),
     "mfa_build_score_plan": (C.c_int, [_i32, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mfa_build_score_plan_grouped": (C.c_int, [_i32, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mfa_build_score_plans_batch": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp,
+                                              _vp, _vp, _vp, _vp, _vp]),
     "mfa_fmllr_acc_batch": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
     "mfa_fmllr_acc_ali_batch": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
     "mfa_fmllr_stats_model": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp]),

@@ -27,11 +27,13 @@
 // its frames can be asked for.
 // Output: [T][P_u] row-major, the layout the Viterbi kernel gathers from.
 #include <algorithm>
+#include <atomic>
 #include <climits>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <type_traits>
 #include <utility>
 #include <vector>
@@ -2436,6 +2438,42 @@ MFA_API int mfa_build_score_plan(int32_t n_states, const int32_t *h_arc_off, con
   return mfa_build_score_plan_grouped(n_states, h_arc_off, h_arc_next, h_arc_pdf, start, num_pdfs, h_pdf_class, cluster_span,
                                       1, h_state_depth, h_arc_col, h_col_pdf, h_col_first, h_col_last, h_class_counts, nullptr,
                                       h_n_cols);
+}
+
+MFA_API int mfa_build_score_plans_batch(int32_t n_utt, const int64_t *h_state_off, const int64_t *h_arc_base,
+                                        const int32_t *h_arc_off, const int32_t *h_arc_next, const int32_t *h_arc_pdf,
+                                        const int32_t *h_start, int32_t num_pdfs, const int32_t *h_pdf_class,
+                                        int32_t cluster_span, int32_t groups, int32_t n_threads, int32_t *h_state_depth,
+                                        int32_t *h_arc_col, int32_t *h_col_pdf, int32_t *h_col_first, int32_t *h_col_last,
+                                        int32_t *h_class_counts, int32_t *h_group_counts, int32_t *h_n_cols,
+                                        int32_t *h_bad_utt) {
+  if (n_utt < 0) return -1;
+  std::atomic<int> next(0), first_bad(INT32_MAX);
+  std::vector<int> codes((size_t)std::max(n_utt, 1), 0);
+  auto work = [&]() {
+    for (;;) {
+      const int u = next.fetch_add(1);
+      if (u >= n_utt) break;
+      const int64_t s0 = h_state_off[u], a0 = h_arc_base[u];
+      const int32_t ns = (int32_t)(h_state_off[u + 1] - s0);
+      const int rc = mfa_build_score_plan_grouped(ns, h_arc_off + s0 + u, h_arc_next + a0, h_arc_pdf + a0, h_start[u], num_pdfs,
+                                                  h_pdf_class, cluster_span, groups, h_state_depth + 2 * s0, h_arc_col + a0,
+                                                  h_col_pdf + a0, h_col_first + a0, h_col_last + a0, h_class_counts + 6 * (size_t)u,
+                                                  groups > 1 ? h_group_counts + (size_t)groups * u : nullptr, h_n_cols + u);
+      codes[u] = rc;
+      if (rc != 0) { int cur = first_bad.load(); while (u < cur && !first_bad.compare_exchange_weak(cur, u)) {} }
+    }
+  };
+  const int nt = std::max(1, std::min(n_threads, n_utt));
+  if (nt == 1) work();
+  else {
+    std::vector<std::thread> ts;
+    for (int t = 0; t < nt; t++) ts.emplace_back(work);
+    for (auto &t : ts) t.join();
+  }
+  const int bad = first_bad.load();
+  if (bad != INT32_MAX) { if (h_bad_utt) *h_bad_utt = bad; return codes[bad]; }
+  return 0;
 }
 
 MFA_API int mfa_build_score_plan_grouped(int32_t n_states, const int32_t *h_arc_off, const int32_t *h_arc_next,

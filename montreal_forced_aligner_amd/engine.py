@@ -345,47 +345,51 @@ class AlignmentEngine:
         arcs = np.concatenate([f.arcs for f in fsts])
         if np.any(arcs["ilabel"] <= 0):
             raise _lib.MfaHipError("graphs with epsilon input arcs are not supported by the device decoder")
-        max_deg = max(int(np.diff(f.arc_offsets).max()) for f in fsts) if n else 0
+        # (the concatenated offsets restart at every utterance: those steps are <= 0 and do not disturb the maximum)
+        max_deg = int(np.diff(arc_off).max()) if arc_off.shape[0] > 1 else 0
         if max_deg > 64:
             raise _lib.MfaHipError(f"a graph state has {max_deg} arcs; the device decoder supports at most 64")
-        pdf_of_arc = tm.id2pdf[arcs["ilabel"]]
-        cols = np.empty(arcs.shape[0], dtype=np.int32)
-        pdf_lists, counts, first_frames, last_depths, state_depths, group_counts = [], [], [], [], [], []
+        pdf_of_arc = np.ascontiguousarray(tm.id2pdf[arcs["ilabel"]], dtype=np.int32)
         span = 0 if cluster_gap is None else int(cluster_gap)
-        n_cols = C.c_int32(0)
         if self.slot_class is None:
             raise _lib.MfaHipError("pack_graphs needs the acoustic model's slot classes: call load_gmm first")
         pdf_class = np.ascontiguousarray(self.slot_class, dtype=np.int32)
-        for u in range(n):
-            a0, a1 = int(arc_base[u]), int(arc_base[u + 1])
-            f = fsts[u]
-            na = a1 - a0
-            f_off = np.ascontiguousarray(f.arc_offsets, dtype=np.int32)
-            f_nxt = np.ascontiguousarray(arcs["nextstate"][a0:a1], dtype=np.int32)
-            f_pdf = np.ascontiguousarray(pdf_of_arc[a0:a1], dtype=np.int32)
-            sd = np.empty((f.num_states, 2), dtype=np.int32)
-            col = np.empty(na, dtype=np.int32)
-            cp, cf, cl = np.empty(na, dtype=np.int32), np.empty(na, dtype=np.int32), np.empty(na, dtype=np.int32)
-            cc = np.zeros(6, dtype=np.int32)
-            gc = np.zeros(groups, dtype=np.int32)
-            # columns (pdf, depth cluster) in kernel order, their depth keys, and every arc's column: one host call
-            rc = self.lib.mfa_build_score_plan_grouped(f.num_states, f_off.ctypes.data, f_nxt.ctypes.data, f_pdf.ctypes.data,
-                                                       int(f.start), int(pdf_class.shape[0]), pdf_class.ctypes.data, span,
-                                                       groups, sd.ctypes.data, col.ctypes.data, cp.ctypes.data,
-                                                       cf.ctypes.data, cl.ctypes.data, cc.ctypes.data, gc.ctypes.data,
-                                                       C.byref(n_cols))
-            if rc != 0:
-                raise _lib.MfaHipError(f"mfa_build_score_plan: utterance {u}: " +
-                                       ("a pdf id outside the loaded model" if rc == -2 else "malformed graph"))
-            k = int(n_cols.value)
-            cols[a0:a1] = col
-            pdf_lists.append(cp[:k].copy())
-            counts.append(cc)
-            group_counts.append(gc)
-            first_frames.append(cf[:k].copy())
-            last_depths.append(cl[:k].copy())
-            state_depths.append(sd)
-        pdf_off = np.concatenate([[0], np.cumsum([len(p) for p in pdf_lists])]).astype(np.int64)
+        # columns (pdf, depth cluster) in kernel order, their depth keys, and every arc's column: one host call for the batch,
+        # utterances spread over the host's threads (mfa_build_score_plans_batch)
+        total_s, total_a = int(state_off[-1]), int(arc_base[-1])
+        nxt = np.ascontiguousarray(arcs["nextstate"], dtype=np.int32)
+        starts = np.array([f.start for f in fsts], dtype=np.int32)
+        sd_all = np.empty((max(total_s, 1), 2), dtype=np.int32)
+        cols = np.empty(max(total_a, 1), dtype=np.int32)
+        cp, cf, cl = (np.empty(max(total_a, 1), dtype=np.int32) for _ in range(3))
+        cc_all = np.zeros((max(n, 1), 6), dtype=np.int32)
+        gc_all = np.zeros((max(n, 1), max(groups, 1)), dtype=np.int32)
+        n_cols = np.zeros(max(n, 1), dtype=np.int32)
+        bad = C.c_int32(-1)
+        try:
+            threads = len(os.sched_getaffinity(0))
+        except AttributeError:
+            threads = os.cpu_count() or 1
+        rc = self.lib.mfa_build_score_plans_batch(n, state_off.ctypes.data, arc_base.ctypes.data, arc_off.ctypes.data,
+                                                  nxt.ctypes.data, pdf_of_arc.ctypes.data, starts.ctypes.data,
+                                                  int(pdf_class.shape[0]), pdf_class.ctypes.data, span, groups,
+                                                  max(1, min(32, threads)), sd_all.ctypes.data, cols.ctypes.data, cp.ctypes.data,
+                                                  cf.ctypes.data, cl.ctypes.data, cc_all.ctypes.data, gc_all.ctypes.data,
+                                                  n_cols.ctypes.data, C.byref(bad)) if n else 0
+        if rc != 0:
+            raise _lib.MfaHipError(f"mfa_build_score_plan: utterance {int(bad.value)}: " +
+                                   ("a pdf id outside the loaded model" if rc == -2 else
+                                    "unsupported number of plan groups" if rc == -3 else "malformed graph"))
+        cols = cols[:total_a]
+        n_cols = n_cols[:n].astype(np.int64)
+        pdf_off = np.concatenate([[0], np.cumsum(n_cols)]).astype(np.int64)
+        # utterance u's columns sit at [arc_base[u], arc_base[u] + n_cols[u]) of the column arrays: compact them
+        take = np.repeat(arc_base[:-1] - pdf_off[:-1], n_cols) + np.arange(int(pdf_off[-1]), dtype=np.int64)
+        pdf_all, first_all, last_all = cp[take], cf[take], cl[take]
+        cuts = pdf_off[1:-1]
+        pdf_lists = np.split(pdf_all, cuts) if n else []
+        first_frames = np.split(first_all, cuts) if n else []
+        counts, group_counts = cc_all[:n], gc_all[:n]
         t = dict(
             state_off=self._dev(state_off), arc_base=self._dev(arc_base),
             start=self._dev(np.array([f.start for f in fsts], dtype=np.int32)),
@@ -394,12 +398,11 @@ class AlignmentEngine:
             arc_col=self._dev(cols), arc_ilabel=self._dev(arcs["ilabel"].astype(np.int32)),
             arc_olabel=self._dev(arcs["olabel"].astype(np.int32)),
         )
-        return PackedGraphs(n, int(S.max()) if n else 0, int(A.max()) if n else 0, int(A.sum()), t, self._dev(np.concatenate(pdf_lists).astype(np.int32)),
-                            self._dev(pdf_off), self._dev(np.stack(counts).astype(np.int32)), pdf_off, pdf_lists,
-                            self._dev(np.concatenate(first_frames).astype(np.int32)), first_frames,
-                            self._dev(np.concatenate(last_depths).astype(np.int32)),
-                            self._dev(np.concatenate(state_depths).astype(np.int32)), groups,
-                            self._dev(np.stack(group_counts).astype(np.int32)) if groups > 1 else None)
+        return PackedGraphs(n, int(S.max()) if n else 0, int(A.max()) if n else 0, int(A.sum()), t, self._dev(pdf_all),
+                            self._dev(pdf_off), self._dev(counts), pdf_off, pdf_lists,
+                            self._dev(first_all), first_frames, self._dev(last_all),
+                            self._dev(sd_all[:total_s]), groups,
+                            self._dev(group_counts) if groups > 1 else None)
 
     def align(self, graphs: PackedGraphs, loglikes: torch.Tensor, ll_off: np.ndarray, ll_cols: torch.Tensor,
               frame_off: np.ndarray, beam: float = 10.0, retry_beam: float = 40.0, acoustic_scale: float = 0.1,
