@@ -99,7 +99,48 @@ class HierarchicalCtm:
 
 def split_to_phones(alignment: Sequence[int], tm) -> List[tuple]:
     """Kaldi SplitToPhones (reordered): [(first frame, n frames, phone id)].  Raises if the alignment is not a sequence
-    of complete phones."""
+    of complete phones.
+
+    Array form of ``_split_to_phones_loop`` (the rule as Kaldi writes it, one frame at a time): a phone ends with its final
+    transition plus the self-loops that follow it, i.e. right before the next forward transition.  Anything irregular is
+    handed to the loop, which raises the specific error."""
+    ali = np.asarray(alignment, dtype=np.int64)
+    T = ali.shape[0]
+    if T == 0:
+        return []
+    if ali.min() < 1 or ali.max() >= tm.is_final.shape[0]:
+        return _split_to_phones_loop(ali, tm)
+    fin = np.asarray(tm.is_final)[ali].astype(bool)
+    loop = np.asarray(tm.is_self_loop)[ali].astype(bool)
+    st = np.asarray(tm.id2state)[ali]
+    ph = np.asarray(tm.id2phone)[ali]
+    fwd = np.flatnonzero(~loop)                        # forward transitions
+    fpos = np.flatnonzero(fin)                         # final transitions (forward ones, by construction of the model)
+    if fpos.shape[0] == 0 or np.any(loop[fpos]):
+        return _split_to_phones_loop(ali, tm)
+    # end of every phone: the frame before the forward transition that follows its final transition
+    nxt = np.searchsorted(fwd, fpos, side="right")
+    ends = np.where(nxt < fwd.shape[0], fwd[np.minimum(nxt, fwd.shape[0] - 1)] - 1, T - 1)
+    starts = np.concatenate([[0], ends[:-1] + 1])
+    ok = ends[-1] == T - 1
+    # frames inside a final run (final transition + its self-loops) — the loop form skips its checks there
+    mark = np.zeros(T + 1, dtype=np.int32)
+    np.add.at(mark, fpos, 1)
+    np.add.at(mark, ends + 1, -1)
+    in_run = np.cumsum(mark[:T]) > 0
+    same_state = st[1:] == st[:-1]
+    # (1) self-loops after a final transition stay in its transition-state
+    ok = ok and not np.any(in_run[1:] & in_run[:-1] & ~fin[1:] & ~same_state)
+    # (3) outside those runs the phone only changes across a final transition
+    ok = ok and not np.any(~in_run[:-1] & ~same_state & (ph[1:] != ph[:-1]))
+    if not ok:
+        return _split_to_phones_loop(ali, tm)
+    phones = ph[starts]
+    return list(zip(starts.tolist(), (ends + 1 - starts).tolist(), phones.tolist()))
+
+
+def _split_to_phones_loop(alignment: Sequence[int], tm) -> List[tuple]:
+    """SplitToPhones frame by frame (the specification of ``split_to_phones``; raises CtmError on irregular input)."""
     ali = np.asarray(alignment, dtype=np.int64)
     T = ali.shape[0]
     out = []

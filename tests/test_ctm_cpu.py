@@ -128,3 +128,47 @@ def test_fix_unk_words_restores_transcript_spelling():
         lex, [lex.to_int("ab"), lex.to_int("zork"), lex.to_int("c"), lex.to_int("blip")],
         _ivs(["a", "b", "spn", "c", "spn"])).word_intervals, lex)
     assert [w.label for w in fixed][0] == "ab" and [w.label for w in fixed][-2:] == ["c", "blip"]
+
+
+def test_split_to_phones_array_form_equals_the_frame_loop(fx):
+    """``split_to_phones`` (array form) against ``_split_to_phones_loop`` (Kaldi's rule frame by frame): random complete
+    paths through training graphs give the same phones; corrupted alignments raise in both."""
+    import pytest
+
+    rng = np.random.default_rng(11)
+    tm = fx.mono_tm
+    texts = ["this is the acoustic corpus", "um and that should be all thanks", "there's nothing going else going on", ""]
+    n_ok = n_bad = 0
+    for text in texts:
+        f = fx.mono_gc.compile_fst(text)
+        for _ in range(25):
+            s, seq = 0, []
+            while True:
+                a0, a1 = int(f.arc_offsets[s]), int(f.arc_offsets[s + 1])
+                if np.isfinite(f.final[s]) and (a0 == a1 or rng.random() < 0.3):
+                    break
+                arc = f.arcs[int(rng.integers(a0, a1))]
+                seq.append(int(arc["ilabel"]))
+                s = int(arc["nextstate"])
+            ali = np.asarray(seq, dtype=np.int32)
+            assert C.split_to_phones(ali, tm) == C._split_to_phones_loop(ali, tm)
+            n_ok += 1
+            if len(seq) > 4:
+                for kind in range(3):
+                    bad = ali.copy()
+                    k = int(rng.integers(1, len(seq) - 1))
+                    if kind == 0:
+                        bad = bad[:k]                                   # may end inside a phone
+                    elif kind == 1:
+                        bad[k] = int(rng.integers(1, tm.num_transition_ids + 1))
+                    else:
+                        bad[k:] = bad[k:][::-1]
+                    try:
+                        ref = C._split_to_phones_loop(bad, tm)
+                    except C.CtmError:
+                        with pytest.raises(C.CtmError):
+                            C.split_to_phones(bad, tm)
+                        n_bad += 1
+                    else:
+                        assert C.split_to_phones(bad, tm) == ref
+    assert n_ok == 100 and n_bad > 20

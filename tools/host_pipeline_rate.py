@@ -38,6 +38,7 @@ def main():
     eng.pack_graphs(fsts, model.tm)
     t_pack = (time.time() - t0) / n
     print(f"pack_graphs (depths, score columns, upload): {1e3 * t_pack:.3f} ms/utterance = {1 / t_pack:.0f} utterances/s", flush=True)
+    pt = world.lexicon.phone_table
     # intervals: real alignments (of noise features: valid transition-id sequences is all that matters here)
     import torch
     m = 256
