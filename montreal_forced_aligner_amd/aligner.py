@@ -70,6 +70,8 @@ class AlignOptions:
     # (MFA/corpus/features.py:235, :356-365) and therefore aligns features quantised twice; `align_one` / the online path
     # keep float32 (the default here).  True reproduces the corpus path's two quantisations (host-side codec).
     corpus_compression: bool = False
+    # raw MFCCs of a run stay on the device between the CMVN pass and the alignment passes up to this many bytes
+    mfcc_cache_bytes: int = 64 << 30
 
 
 class CorpusAligner:
@@ -108,6 +110,10 @@ class CorpusAligner:
         self.failure_reasons: Dict[str, str] = {}
         self.fallback_first_pass: List[str] = []
         self.transforms: Optional[np.ndarray] = None
+        self._mfcc_cache: Dict[tuple, tuple] = {}
+        self._mfcc_cache_bytes = 0
+        self._pcm_stage = None
+        self._pcm_stage_free = None
 
     def _boosted(self, am: DiagGmmModel) -> DiagGmmModel:
         import copy
@@ -144,8 +150,23 @@ class CorpusAligner:
     def _mfcc(self, utts: Sequence[CorpusUtterance], idx: Sequence[int]):
         import torch
 
+        key = (id(utts), tuple(idx))          # (the list object of the run in progress; align() empties the cache at both ends)
+        hit = self._mfcc_cache.get(key)
+        if hit is not None:          # the CMVN pass computed them already (and a second alignment pass asks a third time)
+            return hit
         so = np.concatenate([[0], np.cumsum([len(utts[i].pcm) for i in idx])]).astype(np.int64)
-        pcm = torch.from_numpy(np.concatenate([np.ascontiguousarray(utts[i].pcm, dtype=np.int16) for i in idx])).to(self.engine.device)
+        total = int(so[-1])
+        # PCM gathered straight into a pinned staging buffer (one pass over the samples), then one asynchronous H2D copy
+        if self._pcm_stage is None or self._pcm_stage.shape[0] < total:
+            self._pcm_stage = torch.empty(max(total, 1), dtype=torch.int16).pin_memory()
+            self._pcm_stage_free = None
+        if self._pcm_stage_free is not None:
+            self._pcm_stage_free.synchronize()          # the previous batch's copy has left the buffer
+        if total:
+            np.concatenate([np.asarray(utts[i].pcm, dtype=np.int16) for i in idx], out=self._pcm_stage.numpy()[:total])
+        pcm = self._pcm_stage[:total].to(self.engine.device, non_blocking=True)
+        self._pcm_stage_free = torch.cuda.Event()
+        self._pcm_stage_free.record()
         mfcc, fo = self.engine.mfcc(pcm, so)
         if self.opt.corpus_compression:      # feats.*.ark of MfccFunction: compute_mfccs_for_export(seg, compress=True)
             from . import kaldi_io as _kio
@@ -155,6 +176,10 @@ class CorpusAligner:
                 if b > a:
                     host[a:b] = _kio.compress_round_trip(host[a:b])
             mfcc = torch.from_numpy(host).to(self.engine.device)
+        size = mfcc.numel() * mfcc.element_size()
+        if self._mfcc_cache_bytes + size <= self.opt.mfcc_cache_bytes:      # 52 KB per 10 s utterance: HBM holds millions
+            self._mfcc_cache[key] = (mfcc, fo)
+            self._mfcc_cache_bytes += size
         return mfcc, fo
 
     def _final_features(self, mfcc, fo, rows, cmvn, d_lda, fmllr):
@@ -216,6 +241,11 @@ class CorpusAligner:
         for idx_all in self._batches(utts):
             fsts_all = self.compiler.compile_fsts([utts[i].text for i in idx_all], self.scaled)   # native, batched
             idx, fsts, gidx, gfsts = [], [], [], []
+            whole = getattr(fsts_all, "arcs", None)
+            if whole is not None and len(fsts_all) and whole.shape[0] and int(whole["ilabel"].min()) > 0 \
+                    and int(np.diff(fsts_all.arc_off).max()) <= 64 and int(np.diff(fsts_all.arc_base).min()) > 0:
+                # a batch straight from the native compiler with nothing for the general decoder in it: taken as it is
+                idx, fsts, fsts_all = list(idx_all), fsts_all, []
             for i, f in zip(idx_all, fsts_all):
                 if f.num_arcs == 0 or f.num_states == 0 or np.any(f.arcs["ilabel"] < 0):
                     self.failure_reasons[utts[i].utt_id] = "empty or malformed training graph"   # this utterance only
@@ -309,6 +339,7 @@ class CorpusAligner:
 
         utts = list(utterances)
         self.failed, self.failure_reasons, self.fallback_first_pass = [], {}, []
+        self._mfcc_cache, self._mfcc_cache_bytes = {}, 0
         spk_ids, cmvn = self.speaker_cmvn(utts)
         first_model = self.ali_am if self.ali_am is not None else self.am
         self._load(first_model)
@@ -359,6 +390,7 @@ class CorpusAligner:
                 if u.text is not None:   # <unk> intervals get their transcript spelling (MFA/alignment/multiprocessing.py:1749-1751)
                     ur.ctm.word_intervals = _ctm.fix_unk_words(u.text.split(), ur.ctm.word_intervals, self.lexicon)
             out.append(ur)
+        self._mfcc_cache, self._mfcc_cache_bytes = {}, 0
         return out
 
     def export_textgrids(self, utterances: Sequence[CorpusUtterance], results: Sequence[Optional[UtteranceResult]], output_directory,

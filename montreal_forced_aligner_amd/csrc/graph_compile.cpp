@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <memory_resource>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -31,11 +32,16 @@ inline bool parc_lt(const PArc &a, const PArc &b) {   // Python tuple order of (
   return a.w < b.w;
 }
 
+// Every container of a phone graph lives on a per-utterance bump allocator (std::pmr::monotonic_buffer_resource): the
+// graphs are thousands of three-arc vectors, and malloc/free of those was most of the compile time.
+using ArcVec = std::pmr::vector<PArc>;
 struct PhoneGraph {
+  std::pmr::memory_resource *mr;
   int start = 0;
-  std::vector<std::vector<PArc>> arcs;
-  std::vector<double> fin;        // per node; has_fin tells whether the node is in graph.py's `final` dict
-  std::vector<char> has_fin;
+  std::pmr::vector<ArcVec> arcs;
+  std::pmr::vector<double> fin;   // per node; has_fin tells whether the node is in graph.py's `final` dict
+  std::pmr::vector<char> has_fin;
+  explicit PhoneGraph(std::pmr::memory_resource *r) : mr(r), arcs(r), fin(r), has_fin(r) {}
   int add_node() { arcs.emplace_back(); fin.push_back(0.0); has_fin.push_back(0); return (int)arcs.size() - 1; }
   void set_final(int u, double w) { fin[u] = w; has_fin[u] = 1; }
 
@@ -49,12 +55,19 @@ struct PhoneGraph {
       const int u = stack.back(); stack.pop_back();
       for (const PArc &a : arcs[u]) if (!fwd[a.dst]) { fwd[a.dst] = 1; stack.push_back(a.dst); }
     }
-    std::vector<std::vector<int>> rev(n);
-    for (int u = 0; u < n; u++) for (const PArc &a : arcs[u]) rev[a.dst].push_back(u);
+    // reverse adjacency in CSR form (co-accessibility is a set: the order predecessors are visited in does not matter)
+    std::vector<int> rev_off(n + 1, 0), rev;
+    for (int u = 0; u < n; u++) for (const PArc &a : arcs[u]) rev_off[a.dst + 1]++;
+    for (int u = 0; u < n; u++) rev_off[u + 1] += rev_off[u];
+    rev.resize(rev_off[n]);
+    {
+      std::vector<int> fill(rev_off.begin(), rev_off.end() - 1);
+      for (int u = 0; u < n; u++) for (const PArc &a : arcs[u]) rev[fill[a.dst]++] = u;
+    }
     for (int u = 0; u < n; u++) if (has_fin[u] && std::isfinite(fin[u])) { bwd[u] = 1; stack.push_back(u); }
     while (!stack.empty()) {
       const int u = stack.back(); stack.pop_back();
-      for (int v : rev[u]) if (!bwd[v]) { bwd[v] = 1; stack.push_back(v); }
+      for (int k = rev_off[u]; k < rev_off[u + 1]; k++) { const int v = rev[k]; if (!bwd[v]) { bwd[v] = 1; stack.push_back(v); } }
     }
     std::vector<int> order, new_id(n, -1);
     auto keep = [&](int i) { return fwd[i] && bwd[i]; };
@@ -66,9 +79,9 @@ struct PhoneGraph {
           if (keep(a.dst) && new_id[a.dst] == -1) { new_id[a.dst] = (int)order.size(); order.push_back(a.dst); }
       }
     }
-    std::vector<std::vector<PArc>> na(order.size());
-    std::vector<double> nf(order.size(), 0.0);
-    std::vector<char> nh(order.size(), 0);
+    std::pmr::vector<ArcVec> na(order.size(), mr);
+    std::pmr::vector<double> nf(order.size(), 0.0, mr);
+    std::pmr::vector<char> nh(order.size(), 0, mr);
     for (size_t k = 0; k < order.size(); k++) {
       const int u = order[k];
       for (const PArc &a : arcs[u]) if (keep(a.dst)) na[k].push_back({new_id[a.dst], a.ph, a.ol, a.w});
@@ -89,7 +102,7 @@ struct PhoneGraph {
       for (const PArc &x : arcs[u]) if (--indeg[x.dst] == 0) topo.push_back(x.dst);
     }
     if ((int)topo.size() != n) return;   // a cycle: left alone
-    struct Sig { bool hf; double f; std::vector<PArc> a; };
+    struct Sig { bool hf; double f; ArcVec a; };
     struct SigHash {
       static uint64_t dbits(double d) { if (d == 0.0) return 0; uint64_t b; memcpy(&b, &d, 8); return b; }   // 0.0 == -0.0
       size_t operator()(const Sig &s) const {
@@ -112,11 +125,11 @@ struct PhoneGraph {
     };
     std::vector<int> rep(n);
     for (int i = 0; i < n; i++) rep[i] = i;
-    std::unordered_map<Sig, int, SigHash, SigEq> seen;
+    std::pmr::unordered_map<Sig, int, SigHash, SigEq> seen(mr);
     seen.reserve((size_t)n * 2);
     for (int k = n - 1; k >= 0; k--) {
       const int u = topo[k];
-      std::vector<PArc> na;
+      ArcVec na(mr);
       for (const PArc &x : arcs[u]) {
         const PArc a{rep[x.dst], x.ph, x.ol, x.w};
         bool dup = false;
@@ -124,7 +137,7 @@ struct PhoneGraph {
         if (!dup) na.push_back(a);
       }
       arcs[u] = na;
-      Sig sig{has_fin[u] != 0, has_fin[u] ? fin[u] : 0.0, na};
+      Sig sig{has_fin[u] != 0, has_fin[u] ? fin[u] : 0.0, ArcVec(na, mr)};
       std::stable_sort(sig.a.begin(), sig.a.end(), parc_lt);
       auto it = seen.find(sig);
       if (it == seen.end()) { seen.emplace(std::move(sig), u); rep[u] = u; }
@@ -136,9 +149,10 @@ struct PhoneGraph {
 };
 
 struct CArc { int dst; int win[3]; int ol; double w; };
-struct CtxGraph {
+struct CtxGraph {                 // CSR: node u's arcs are arcs[off[u] .. off[u + 1]) (kept between the two phases of a batch)
   int num_nodes = 0, start = 0;
-  std::vector<std::vector<CArc>> arcs;
+  std::vector<int> off;
+  std::vector<CArc> arcs;
   std::vector<double> fin;
   std::vector<char> has_fin;
 };
@@ -233,70 +247,104 @@ void build_phone_graph(const mfa_gc &gc, const int32_t *entries, int n, PhoneGra
 }
 
 // graph.py _expand_context
-void expand_context(const PhoneGraph &pg, int width, CtxGraph &cg) {
+void expand_context(const PhoneGraph &pg, int width, CtxGraph &cg, std::pmr::memory_resource *mr) {
   if (width == 1) {
-    cg.num_nodes = (int)pg.arcs.size(); cg.start = pg.start;
-    cg.arcs.resize(pg.arcs.size());
-    for (size_t u = 0; u < pg.arcs.size(); u++)
-      for (const PArc &a : pg.arcs[u]) cg.arcs[u].push_back({a.dst, {a.ph, 0, 0}, a.ol, a.w});
-    cg.fin = pg.fin; cg.has_fin = pg.has_fin;
+    const int n = (int)pg.arcs.size();
+    cg.num_nodes = n; cg.start = pg.start;
+    cg.off.assign(n + 1, 0);
+    for (int u = 0; u < n; u++) cg.off[u + 1] = cg.off[u] + (int)pg.arcs[u].size();
+    cg.arcs.reserve(cg.off[n]);
+    for (int u = 0; u < n; u++)
+      for (const PArc &a : pg.arcs[u]) cg.arcs.push_back({a.dst, {a.ph, 0, 0}, a.ol, a.w});
+    cg.fin.assign(pg.fin.begin(), pg.fin.end()); cg.has_fin.assign(pg.has_fin.begin(), pg.has_fin.end());
     return;
   }
   struct EArc { int u, v, ph, ol; double w; };
-  std::vector<EArc> earcs;
-  std::vector<std::vector<int>> out_of(pg.arcs.size());
-  for (size_t u = 0; u < pg.arcs.size(); u++)
-    for (const PArc &a : pg.arcs[u]) { out_of[u].push_back((int)earcs.size()); earcs.push_back({(int)u, a.dst, a.ph, a.ol, a.w}); }
-  std::unordered_map<uint64_t, int> key2id;
-  std::vector<std::pair<int, int>> order;
-  std::vector<std::vector<CArc>> arcs(1);
+  const int n = (int)pg.arcs.size();
+  std::pmr::vector<EArc> earcs(mr);
+  std::pmr::vector<int> out_off(n + 1, 0, mr);        // phone-graph arcs are numbered node by node: out_of[u] is a range
+  for (int u = 0; u < n; u++) out_off[u + 1] = out_off[u] + (int)pg.arcs[u].size();
+  earcs.reserve(out_off[n]);
+  for (int u = 0; u < n; u++)
+    for (const PArc &a : pg.arcs[u]) earcs.push_back({u, a.dst, a.ph, a.ol, a.w});
+  // state = (pending arc e2, left phone c) → id in first-seen order (graph.py's key2id / order): open addressing on the arena
+  size_t cap = 64;
+  while (cap < earcs.size() * 4 + 16) cap <<= 1;
+  std::pmr::vector<uint64_t> hkey(cap, ~0ull, mr);
+  std::pmr::vector<int> hval(cap, -1, mr);
+  std::pmr::vector<std::pair<int, int>> order(mr);
+  order.reserve(earcs.size() + 16);
   const int END = -1;
   auto sid = [&](int e2, int c) {
-    const uint64_t key = ((uint64_t)(uint32_t)e2 << 32) | (uint32_t)c;
-    auto it = key2id.find(key);
-    if (it != key2id.end()) return it->second;
-    const int id = (int)order.size() + 1;
-    key2id.emplace(key, id);
-    order.push_back({e2, c});
-    arcs.emplace_back();
-    return id;
-  };
-  auto expand = [&](int e, int l, std::vector<CArc> &out) {
-    const EArc ea = earcs[e];
-    for (int e2 : out_of[ea.v]) {
-      const int r = earcs[e2].ph;
-      const int id = sid(e2, ea.ph);
-      out.push_back({id, {l, ea.ph, r}, ea.ol, ea.w});
+    const uint64_t k = ((uint64_t)(uint32_t)e2 << 32) | (uint32_t)c;
+    size_t h = (size_t)((k * 0x9E3779B97F4A7C15ull) >> 17) & (cap - 1);
+    for (;;) {
+      if (hkey[h] == k) return hval[h];
+      if (hkey[h] == ~0ull) {
+        if (order.size() * 2 + 2 > cap) {   // (cannot happen for trimmed graphs of sane size; keep the table sparse anyway)
+          std::pmr::vector<uint64_t> nk(cap * 2, ~0ull, mr);
+          std::pmr::vector<int> nv(cap * 2, -1, mr);
+          for (size_t i = 0; i < cap; i++) if (hkey[i] != ~0ull) {
+            size_t g = (size_t)((hkey[i] * 0x9E3779B97F4A7C15ull) >> 17) & (cap * 2 - 1);
+            while (nk[g] != ~0ull) g = (g + 1) & (cap * 2 - 1);
+            nk[g] = hkey[i]; nv[g] = hval[i];
+          }
+          hkey.swap(nk); hval.swap(nv); cap *= 2;
+          h = (size_t)((k * 0x9E3779B97F4A7C15ull) >> 17) & (cap - 1);
+          continue;
+        }
+        hkey[h] = k; hval[h] = (int)order.size() + 1; order.push_back({e2, c});
+        return hval[h];
+      }
+      h = (h + 1) & (cap - 1);
     }
-    if (pg.has_fin[ea.v]) out.push_back({END, {l, ea.ph, 0}, ea.ol, ea.w + pg.fin[ea.v]});
   };
-  {
-    std::vector<CArc> out;
-    for (int e : out_of[pg.start]) expand(e, 0, out);
-    arcs[0] = out;
-  }
+  cg.off.clear(); cg.arcs.clear();
+  cg.off.push_back(0);
+  auto expand = [&](int e, int l) {
+    const EArc ea = earcs[e];
+    for (int e2 = out_off[ea.v]; e2 < out_off[ea.v + 1]; e2++) {
+      const int id = sid(e2, ea.ph);
+      cg.arcs.push_back({id, {l, ea.ph, earcs[e2].ph}, ea.ol, ea.w});
+    }
+    if (pg.has_fin[ea.v]) cg.arcs.push_back({END, {l, ea.ph, 0}, ea.ol, ea.w + pg.fin[ea.v]});
+  };
+  for (int e = out_off[pg.start]; e < out_off[pg.start + 1]; e++) expand(e, 0);
+  cg.off.push_back((int)cg.arcs.size());
   for (size_t qi = 0; qi < order.size(); qi++) {
-    std::vector<CArc> out;
-    expand(order[qi].first, order[qi].second, out);
-    arcs[qi + 1] = out;
+    const std::pair<int, int> st = order[qi];    // (copy: expand may grow `order`)
+    expand(st.first, st.second);
+    cg.off.push_back((int)cg.arcs.size());
   }
-  const int end = (int)arcs.size();
-  arcs.emplace_back();
-  for (auto &a : arcs) for (CArc &x : a) if (x.dst == END) x.dst = end;
-  cg.num_nodes = (int)arcs.size(); cg.start = 0;
-  cg.fin.assign(arcs.size(), 0.0); cg.has_fin.assign(arcs.size(), 0);
+  const int end = (int)cg.off.size() - 1;
+  cg.off.push_back((int)cg.arcs.size());
+  for (CArc &x : cg.arcs) if (x.dst == END) x.dst = end;
+  cg.num_nodes = end + 1; cg.start = 0;
+  cg.fin.assign(cg.num_nodes, 0.0); cg.has_fin.assign(cg.num_nodes, 0);
   cg.fin[end] = 0.0; cg.has_fin[end] = 1;
   if (pg.has_fin[pg.start]) { cg.fin[0] = pg.fin[pg.start]; cg.has_fin[0] = 1; }
-  cg.arcs.swap(arcs);
 }
 
 // graph.py TrainingGraphCompiler._expand_hmm (+ add_transition_probs)
 bool expand_hmm(const mfa_gc &gc, const CtxGraph &cg, const float *neg_scaled, UttResult &r, std::string &err) {
-  struct GArc { int dst, tid, ol; double w; };
+  // "G0" (forward transitions only) as one arc pool with a per-node chain in insertion order — nodes are created on the fly
+  // and a vector per node was most of this function's time
+  struct GArc { int dst, tid, ol, next; double w; };
   const int J = cg.num_nodes;
-  std::vector<std::vector<GArc>> g0(J);
+  std::vector<GArc> pool;
+  std::vector<int> head(J, -1), tail(J, -1);
+  const size_t n_ctx_arcs = cg.arcs.size();
+  pool.reserve(n_ctx_arcs * 3 + 16);
+  head.reserve(J + n_ctx_arcs * 2 + 16); tail.reserve(J + n_ctx_arcs * 2 + 16);
+  auto add_arc = [&](int src, int dst, int tid, int ol, double w) {
+    const int id = (int)pool.size();
+    pool.push_back({dst, tid, ol, -1, w});
+    if (tail[src] < 0) head[src] = id; else pool[tail[src]].next = id;
+    tail[src] = id;
+  };
   for (int u = 0; u < J; u++) {
-    for (const CArc &ca : cg.arcs[u]) {
+    for (int ci = cg.off[u]; ci < cg.off[u + 1]; ci++) {
+      const CArc &ca = cg.arcs[ci];
       auto it = gc.hmm.find(win_key(ca.win, gc.width));
       if (it == gc.hmm.end()) { err = "context window without a registered HMM"; return false; }
       const Hmm &h = it->second;
@@ -310,34 +358,43 @@ bool expand_hmm(const mfa_gc &gc, const CtxGraph &cg, const float *neg_scaled, U
         for (int q = 0; q < 2; q++) {
           const int s = h.trans[3 * t + q];
           if (s < 0 || s >= 64) { err = "HMM state index out of range"; return false; }
-          if (node_of[s] == -1) { node_of[s] = (int)g0.size(); g0.emplace_back(); }
+          if (node_of[s] == -1) { node_of[s] = (int)head.size(); head.push_back(-1); tail.push_back(-1); }
         }
       for (size_t t = 0; t < nt; t++) {
         const int hs = h.trans[3 * t], dst = h.trans[3 * t + 1], tid = h.trans[3 * t + 2];
         const bool first = hs == 0;
-        g0[node_of[hs]].push_back({node_of[dst], tid, first ? ca.ol : 0, first ? ca.w : 0.0});
+        add_arc(node_of[hs], node_of[dst], tid, first ? ca.ol : 0, first ? ca.w : 0.0);
       }
     }
   }
-  std::unordered_map<uint64_t, int> key2id;
+  // (node, incoming transition-state) → output state: open addressing, keys in first-seen order in `order`
+  size_t cap = 64;
+  while (cap < pool.size() * 4 + 16) cap <<= 1;
+  std::vector<uint64_t> hkey(cap, ~0ull);
+  std::vector<int> hval(cap, -1);
   std::vector<std::pair<int, int>> order;
+  order.reserve(pool.size() + 16);
   auto key_of = [](int node, int ts) { return ((uint64_t)(uint32_t)node << 32) | (uint32_t)ts; };
-  key2id.reserve(g0.size() * 2);
-  key2id.emplace(key_of(cg.start, 0), 0);
-  order.push_back({cg.start, 0});
+  auto find_or_add = [&](int node, int ts) {
+    const uint64_t k = key_of(node, ts);
+    size_t h = (size_t)((k * 0x9E3779B97F4A7C15ull) >> 17) & (cap - 1);
+    for (;;) {
+      if (hkey[h] == k) return hval[h];
+      if (hkey[h] == ~0ull) { hkey[h] = k; hval[h] = (int)order.size(); order.push_back({node, ts}); return hval[h]; }
+      h = (h + 1) & (cap - 1);
+    }
+  };
+  find_or_add(cg.start, 0);
   r.offs.clear(); r.arcs.clear(); r.fin.clear();
+  r.arcs.reserve(pool.size() * 2 + 16); r.offs.reserve(pool.size() + 16); r.fin.reserve(pool.size() + 16);
   r.offs.push_back(0);
   const float inf = std::numeric_limits<float>::infinity();
   for (size_t qi = 0; qi < order.size(); qi++) {
     const int node = order[qi].first, ts_in = order[qi].second;
-    for (const GArc &a : g0[node]) {
+    for (int e = head[node]; e >= 0; e = pool[e].next) {
+      const GArc &a = pool[e];
       if (a.tid <= 0 || a.tid > gc.n_tids) { err = "transition-id out of range"; return false; }
-      const int ts = gc.id2state[a.tid];
-      const uint64_t k = key_of(a.dst, ts);
-      auto it = key2id.find(k);
-      int id;
-      if (it == key2id.end()) { id = (int)order.size(); key2id.emplace(k, id); order.push_back({a.dst, ts}); }
-      else id = it->second;
+      const int id = find_or_add(a.dst, gc.id2state[a.tid]);
       r.arcs.push_back({a.tid, a.ol, (float)a.w, id});
     }
     if (ts_in > 0) {
@@ -415,16 +472,16 @@ int64_t mfa_gc_prepare(mfa_gc *gc, int32_t n_utt, const int64_t *word_off, const
   gc->res.clear();
   std::vector<std::vector<int32_t>> miss((size_t)n_utt);
   parallel_for(n_utt, n_threads, [&](int u) {
-    PhoneGraph pg;
+    std::pmr::monotonic_buffer_resource arena(1 << 20);
+    PhoneGraph pg(&arena);
     build_phone_graph(*gc, entries + word_off[u], (int)(word_off[u + 1] - word_off[u]), pg);
-    expand_context(pg, gc->width, gc->ctx[u]);
+    expand_context(pg, gc->width, gc->ctx[u], &arena);
     std::unordered_map<uint64_t, char> seen;
-    for (const auto &a : gc->ctx[u].arcs)
-      for (const CArc &x : a) {
-        const uint64_t k = win_key(x.win, gc->width);
-        if (gc->hmm.find(k) == gc->hmm.end() && seen.emplace(k, 1).second)
-          for (int q = 0; q < gc->width; q++) miss[u].push_back(x.win[q]);
-      }
+    for (const CArc &x : gc->ctx[u].arcs) {
+      const uint64_t k = win_key(x.win, gc->width);
+      if (gc->hmm.find(k) == gc->hmm.end() && seen.emplace(k, 1).second)
+        for (int q = 0; q < gc->width; q++) miss[u].push_back(x.win[q]);
+    }
   });
   gc->missing.clear();
   std::unordered_map<uint64_t, char> seen;

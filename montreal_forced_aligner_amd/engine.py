@@ -336,13 +336,20 @@ class AlignmentEngine:
         if groups is None:
             groups = int(os.environ.get("MFA_PLAN_GROUPS", "8"))
         n = len(fsts)
-        S = np.array([f.num_states for f in fsts], dtype=np.int64)
-        A = np.array([f.num_arcs for f in fsts], dtype=np.int64)
-        state_off = np.concatenate([[0], np.cumsum(S)]).astype(np.int64)
-        arc_base = np.concatenate([[0], np.cumsum(A)]).astype(np.int64)
-        arc_off = np.concatenate([f.arc_offsets.astype(np.int32) for f in fsts]) if n else np.zeros(0, np.int32)
-        final = np.concatenate([f.final for f in fsts]).astype(np.float32)
-        arcs = np.concatenate([f.arcs for f in fsts])
+        if getattr(fsts, "arcs", None) is not None and len(getattr(fsts, "state_off", ())) == n + 1:
+            # a batch from the native compiler (graph_native.FstBatch): its elements are views of these arrays
+            state_off, arc_base = np.ascontiguousarray(fsts.state_off, dtype=np.int64), np.ascontiguousarray(fsts.arc_base, dtype=np.int64)
+            S, A = np.diff(state_off), np.diff(arc_base)
+            arc_off = fsts.arc_off.astype(np.int32)
+            final, arcs = np.ascontiguousarray(fsts.final, dtype=np.float32), fsts.arcs
+        else:
+            S = np.array([f.num_states for f in fsts], dtype=np.int64)
+            A = np.array([f.num_arcs for f in fsts], dtype=np.int64)
+            state_off = np.concatenate([[0], np.cumsum(S)]).astype(np.int64)
+            arc_base = np.concatenate([[0], np.cumsum(A)]).astype(np.int64)
+            arc_off = np.concatenate([f.arc_offsets.astype(np.int32) for f in fsts]) if n else np.zeros(0, np.int32)
+            final = np.concatenate([f.final for f in fsts]).astype(np.float32)
+            arcs = np.concatenate([f.arcs for f in fsts])
         if np.any(arcs["ilabel"] <= 0):
             raise _lib.MfaHipError("graphs with epsilon input arcs are not supported by the device decoder")
         # (the concatenated offsets restart at every utterance: those steps are <= 0 and do not disturb the maximum)

@@ -88,6 +88,17 @@ def _ptr(a: Optional[np.ndarray]):
     return None if a is None else a.ctypes.data
 
 
+class FstBatch(list):
+    """The list of ``Fst`` a batch compile returns, with the concatenated arrays its elements are views of — what
+    ``engine.pack_graphs`` needs, without gathering them again from the per-utterance objects."""
+
+    state_off: np.ndarray     # int64 [n + 1]
+    arc_base: np.ndarray      # int64 [n + 1]
+    arc_off: np.ndarray       # int64 [total states + n]: utterance u's S_u + 1 offsets at state_off[u] + u
+    arcs: np.ndarray          # ARC_DTYPE [total arcs]
+    final: np.ndarray         # float32 [total states]
+
+
 class NativeGraphCompiler:
     """Batch front end of a ``graph.TrainingGraphCompiler``: ``compile_batch(texts)`` → the list ``[compile_fst(t) for t in
     texts]`` (with ``scaled_log_probs``: ``add_transition_probs`` applied), built by the native library."""
@@ -236,4 +247,8 @@ class NativeGraphCompiler:
         for j, k in enumerate(native):
             s0, s1, a0, a1 = int(state_off[j]), int(state_off[j + 1]), int(arc_base[j]), int(arc_base[j + 1])
             out[k] = Fst(0, arc_off[s0 + j: s1 + j + 1], arcs[a0:a1], final[s0:s1])
-        return out  # type: ignore[return-value]
+        if len(native) != len(texts):
+            return out  # type: ignore[return-value]
+        batch = FstBatch(out)
+        batch.state_off, batch.arc_base, batch.arc_off, batch.arcs, batch.final = state_off, arc_base, arc_off, arcs, final
+        return batch

@@ -1,0 +1,56 @@
+"""End-to-end rate of CorpusAligner on configs[2]-shaped utterances: int16 PCM + transcripts in host memory → alignments
+(and, with --ctm, phone/word intervals) on the host; stage times of the host loop printed beside it.
+GPU box:  python tools/corpus_rate.py [n_utt] [--ctm]"""
+import cProfile
+import pstats
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, ".")
+import synth_workload as synth                                              # noqa: E402
+from montreal_forced_aligner_amd.aligner import AlignOptions, CorpusAligner, CorpusUtterance   # noqa: E402
+from montreal_forced_aligner_amd.engine import AlignmentEngine              # noqa: E402
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 2048
+    want_ctm = "--ctm" in sys.argv
+    import torch
+
+    world = synth.SynthWorld.build()
+    eng = AlignmentEngine(0)
+    eng.configure_mfcc()
+    lda = synth.seeded_lda()
+    d_lda = torch.from_numpy(lda).to(eng.device)
+
+    def feats_of(pcm, spk):
+        so = np.array([0, len(pcm)], dtype=np.int64)
+        mfcc, fo = eng.mfcc(torch.from_numpy(pcm).to(eng.device), so)
+        own = np.zeros(1, dtype=np.int32)
+        return eng.features(mfcc, fo, own, eng.cmvn_stats(mfcc, fo, own, 1), lda=d_lda).cpu().numpy()
+
+    model = synth.train_triphone(world, feats_of, n_train=60, n_gauss=32, n_classes=2)
+    pool = 128
+    base = [world.utterance(20000 + i, n_words=30) for i in range(pool)]
+    utts = [CorpusUtterance(f"{base[i % pool][3]}-{i}", str(base[i % pool][3]), base[i % pool][0], base[i % pool][1]) for i in range(n)]
+    al = CorpusAligner(model.tm, model.am, model.tree, world.lexicon, lda=lda, engine=eng,
+                       options=AlignOptions(batch_frames=4_096_000))
+    al.align(utts[:256], make_ctm=want_ctm)                                 # warm-up: context windows, allocations
+    torch.cuda.synchronize()
+    pr = cProfile.Profile()
+    t0 = time.time()
+    pr.enable()
+    res = al.align(utts, make_ctm=want_ctm)
+    pr.disable()
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    ok = sum(r is not None for r in res)
+    print(f"CorpusAligner.align(make_ctm={want_ctm}): {n} utterances in {dt:.2f} s = {n / dt:.0f} utterances/s; {ok} aligned", flush=True)
+    st = pstats.Stats(pr)
+    st.sort_stats("cumulative").print_stats(22)
+
+
+if __name__ == "__main__":
+    main()
