@@ -280,24 +280,28 @@ def fix_unk_words(ref: Sequence[str], test: Sequence[WordCtmInterval], lexicon) 
             return 0.0
         return -2.0
 
+    # Every aligned interval comes back, in order, whatever the alignment pairs it with (both traceback branches that
+    # consume an interval keep it); only intervals labelled with the OOV word can change.  Without one there is nothing to do.
+    if not any(t.label == oov_word for t in test):
+        return list(test)
     n, m = len(ref), len(test)
     gap = -2.0
-    S = np.full((n + 1, m + 1), -np.inf)
-    S[0, :] = gap * np.arange(m + 1)
-    S[:, 0] = gap * np.arange(n + 1)
+    sc = [[score(r, t) for t in test] for r in ref]
+    S = [[gap * j for j in range(m + 1)]] + [[gap * i] + [0.0] * m for i in range(1, n + 1)]     # (lists: 3x numpy scalars)
     for i in range(1, n + 1):
+        up, cur, row = S[i - 1], S[i], sc[i - 1]
         for j in range(1, m + 1):
-            S[i, j] = max(S[i - 1, j - 1] + score(ref[i - 1], test[j - 1]), S[i - 1, j] + gap, S[i, j - 1] + gap)
+            cur[j] = max(up[j - 1] + row[j - 1], up[j] + gap, cur[j - 1] + gap)
     out: List[WordCtmInterval] = []
     i, j = n, m
     while i > 0 or j > 0:
-        if i > 0 and j > 0 and S[i, j] == S[i - 1, j - 1] + score(ref[i - 1], test[j - 1]):
+        if i > 0 and j > 0 and S[i][j] == S[i - 1][j - 1] + sc[i - 1][j - 1]:
             t = test[j - 1]
             if ref[i - 1] != t.label and t.label == oov_word:
                 t.label = ref[i - 1]
             out.append(t)
             i, j = i - 1, j - 1
-        elif j > 0 and S[i, j] == S[i, j - 1] + gap:
+        elif j > 0 and S[i][j] == S[i][j - 1] + gap:
             out.append(test[j - 1])      # aligned interval without a transcript word (silence): kept
             j -= 1
         else:
