@@ -165,12 +165,26 @@ def _split_to_phones_loop(alignment: Sequence[int], tm) -> List[tuple]:
     return out
 
 
+def _frame_times(frames: np.ndarray, frame_shift: float) -> List[float]:
+    """``[round(f * frame_shift, 6) for f in frames]``.  When the shift is a whole number of microseconds (it is: 10 ms) the
+    rounded value is the decimal f·µs/10^6 exactly, and the double nearest to it is one correctly rounded division — the
+    same double Python's round returns — computed for all frames at once."""
+    us = round(frame_shift * 1e6)
+    if us > 0 and abs(frame_shift * 1e6 - us) < 1e-6 and (frames.size == 0 or int(frames.max()) * us < 2 ** 52):
+        return ((frames.astype(np.int64) * us).astype(np.float64) / 1e6).tolist()
+    return [round(int(f) * frame_shift, 6) for f in frames]
+
+
 def generate_ctm(alignment: Sequence[int], tm, phone_table, frame_shift: float = 0.01) -> List[CtmInterval]:
-    out = []
-    for first, n, phone in split_to_phones(alignment, tm):
-        label = phone_table.find(phone) if phone_table is not None else phone
-        out.append(CtmInterval(round(first * frame_shift, 6), round((first + n) * frame_shift, 6), label, phone))
-    return out
+    segs = split_to_phones(alignment, tm)
+    if not segs:
+        return []
+    arr = np.asarray(segs, dtype=np.int64)
+    begins, ends = _frame_times(arr[:, 0], frame_shift), _frame_times(arr[:, 0] + arr[:, 1], frame_shift)
+    phones = arr[:, 2].tolist()
+    find = phone_table.find if phone_table is not None else (lambda p: p)
+    names = {p: find(p) for p in set(phones)}
+    return [CtmInterval(b, e, names[p], p) for b, e, p in zip(begins, ends, phones)]
 
 
 def _position_labels(phones: Sequence[str]) -> List[str]:

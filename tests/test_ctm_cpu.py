@@ -172,3 +172,13 @@ def test_split_to_phones_array_form_equals_the_frame_loop(fx):
                     else:
                         assert C.split_to_phones(bad, tm) == ref
     assert n_ok == 100 and n_bad > 20
+
+
+def test_frame_times_are_pythons_rounding():
+    """generate_ctm's interval ends are ``round(frame * frame_shift, 6)`` (MFA/data.py:2074-2075 rounds to 6 places): the
+    array form returns the same doubles for whole-microsecond shifts and takes the scalar path otherwise."""
+    rng = np.random.default_rng(4)
+    frames = np.concatenate([np.arange(0, 4000), rng.integers(0, 10 ** 7, size=4000)])
+    for shift in (0.01, 0.0125, 0.005, 0.02, 0.010001, 0.0100001, 1.0 / 3.0):
+        want = [round(int(f) * shift, 6) for f in frames]
+        assert C._frame_times(frames, shift) == want, shift
