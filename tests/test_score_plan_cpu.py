@@ -133,3 +133,48 @@ def test_band_rule_on_a_training_graph_and_column_clusters(fx):
     ext_lo = np.full(len(cp), 1 << 30); ext_hi = np.zeros(len(cp), np.int64)
     np.minimum.at(ext_lo, col, sd[src, 0]); np.maximum.at(ext_hi, col, sd[src, 0])
     assert np.all(ext_hi - ext_lo <= 32)
+
+
+def test_batched_plans_equal_the_per_utterance_call(fx):
+    """mfa_build_score_plans_batch (a whole batch over host threads — what engine.pack_graphs calls) writes, per utterance,
+    exactly what mfa_build_score_plan_grouped writes; a bad utterance is reported by index with the per-utterance code."""
+    rng = np.random.default_rng(9)
+    tm = fx.mono_tm
+    lib = _lib.lib()
+    pdf_class = rng.integers(0, 6, size=tm.num_pdfs).astype(np.int32)
+    fsts = [_random_graph(rng, tm, int(rng.choice([3, 8, 40, 150]))) for _ in range(23)]
+    for groups, span, threads in ((1, 0, 1), (8, 32, 4), (16, 8, 7)):
+        S = np.array([f.num_states for f in fsts]); A = np.array([f.num_arcs for f in fsts])
+        state_off = np.concatenate([[0], np.cumsum(S)]).astype(np.int64)
+        arc_base = np.concatenate([[0], np.cumsum(A)]).astype(np.int64)
+        arc_off = np.concatenate([f.arc_offsets.astype(np.int32) for f in fsts])
+        nxt = np.concatenate([f.arcs["nextstate"] for f in fsts]).astype(np.int32)
+        pdf = np.concatenate([tm.id2pdf[f.arcs["ilabel"]] for f in fsts]).astype(np.int32)
+        starts = np.array([f.start for f in fsts], dtype=np.int32)
+        sd = np.full((int(S.sum()), 2), -7, np.int32)
+        col, cp, cf, cl = (np.full(int(A.sum()), -7, np.int32) for _ in range(4))
+        cc = np.zeros((len(fsts), 6), np.int32); gc = np.zeros((len(fsts), groups), np.int32)
+        ncol = np.zeros(len(fsts), np.int32); bad = C.c_int32(-1)
+        rc = lib.mfa_build_score_plans_batch(len(fsts), state_off.ctypes.data, arc_base.ctypes.data, arc_off.ctypes.data,
+                                             nxt.ctypes.data, pdf.ctypes.data, starts.ctypes.data, len(pdf_class),
+                                             pdf_class.ctypes.data, span, groups, threads, sd.ctypes.data, col.ctypes.data,
+                                             cp.ctypes.data, cf.ctypes.data, cl.ctypes.data, cc.ctypes.data, gc.ctypes.data,
+                                             ncol.ctypes.data, C.byref(bad))
+        assert rc == 0
+        for u, f in enumerate(fsts):
+            sd1, col1, cp1, cf1, cl1, cc1, gc1 = _plan(f, tm.id2pdf[f.arcs["ilabel"]], pdf_class, span, groups)
+            s0, a0, k = int(state_off[u]), int(arc_base[u]), int(ncol[u])
+            assert k == len(cp1)
+            assert np.array_equal(sd[s0: s0 + f.num_states], sd1) and np.array_equal(col[a0: a0 + f.num_arcs], col1)
+            assert np.array_equal(cp[a0: a0 + k], cp1) and np.array_equal(cf[a0: a0 + k], cf1) and np.array_equal(cl[a0: a0 + k], cl1)
+            assert np.array_equal(cc[u], cc1)
+            if groups > 1:
+                assert np.array_equal(gc[u], gc1)
+    pdf_bad = pdf.copy()
+    pdf_bad[int(arc_base[5])] = tm.num_pdfs + 3          # utterance 5 names a pdf the model does not have
+    rc = lib.mfa_build_score_plans_batch(len(fsts), state_off.ctypes.data, arc_base.ctypes.data, arc_off.ctypes.data,
+                                         nxt.ctypes.data, pdf_bad.ctypes.data, starts.ctypes.data, len(pdf_class),
+                                         pdf_class.ctypes.data, span, groups, 3, sd.ctypes.data, col.ctypes.data,
+                                         cp.ctypes.data, cf.ctypes.data, cl.ctypes.data, cc.ctypes.data, gc.ctypes.data,
+                                         ncol.ctypes.data, C.byref(bad))
+    assert rc == -2 and bad.value == 5
