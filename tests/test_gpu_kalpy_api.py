@@ -122,3 +122,30 @@ def test_archives_follow_the_corpus_file_flow(fx, tmp_path):
         aa["1-3"]
     direct_al = aligner.align_utterance(graphs[1][1], feats["1-2"])
     assert direct_al.alignment == al.alignment and direct_al.words == al.words
+
+
+def test_native_graph_batch_packs_like_a_list_of_graphs(engine, fx):
+    """A batch from the native compiler (graph_native.FstBatch: views of concatenated arrays) and the same graphs as a plain
+    list of per-utterance objects give the same device layout, tensor for tensor — and the graphs are graph.py's."""
+    import torch
+
+    from montreal_forced_aligner_amd import graph as G
+
+    engine.load_gmm(fx.mono_am)
+    texts = ["this is the acoustic corpus", "um and that should be all thanks", "", "there's nothing going else going on zzzoov"]
+    scaled = fx.mono_tm.scaled_log_probs(1.0, 0.1)
+    batch = fx.mono_gc.compile_fsts(texts, scaled)
+    assert getattr(batch, "arcs", None) is not None
+    ref = [G.add_transition_probs(fx.mono_gc.compile_fst(t), scaled) for t in texts]
+    for a, b in zip(batch, ref):
+        assert np.array_equal(a.arc_offsets, b.arc_offsets) and np.array_equal(a.arcs, b.arcs) and np.array_equal(a.final, b.final)
+    keep = [0, 1, 3]                                   # (the empty transcript's graph has no arcs: not for the decoder)
+    sub = fx.mono_gc.compile_fsts([texts[k] for k in keep], scaled)
+    p1 = engine.pack_graphs(sub, fx.mono_tm)
+    p2 = engine.pack_graphs([ref[k] for k in keep], fx.mono_tm)
+    assert (p1.n_utt, p1.max_states, p1.max_arcs, p1.total_arcs, p1.groups) == (p2.n_utt, p2.max_states, p2.max_arcs, p2.total_arcs, p2.groups)
+    for k in p1.tensors:
+        assert torch.equal(p1.tensors[k], p2.tensors[k]), k
+    for name in ("pdf_list", "pdf_off", "class_counts", "pdf_first_frame", "pdf_last_depth", "state_depth", "group_counts"):
+        assert torch.equal(getattr(p1, name), getattr(p2, name)), name
+    assert np.array_equal(p1.pdf_off_host, p2.pdf_off_host)
