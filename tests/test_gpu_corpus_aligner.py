@@ -92,3 +92,26 @@ def test_corpus_path_double_compression_flag(engine, fx):
         assert abs(r.per_frame_likelihood - p.per_frame_likelihood) < 0.5     # same utterance, slightly different features
         moved += int((r.alignment != p.alignment).sum())
     assert moved < 0.2 * sum(len(r.alignment) for r in res)
+
+
+def test_two_rank_sharded_corpus_to_textgrids(tmp_path):
+    """BASELINE configs[3] at rehearsal scale (tools/sharded_corpus_demo.py): two ``torch.distributed`` ranks (gloo; on a
+    one-GPU box they share the device), speakers assigned by the reference's rule, results gathered on the host, TextGrids
+    written by rank 0 — alignments, likelihoods and files identical to the one-rank run."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", str(root / "tools" / "sharded_corpus_demo.py"), "--out", str(tmp_path), "--backend", "gloo"]
+    p = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    rep = json.loads((tmp_path / "report.json").read_text())
+    assert rep["world_size"] == 2 and rep["all_aligned"] and rep["identical_to_one_rank"] and rep["identical_files"]
+    assert rep["textgrids"] == ["file0.TextGrid", "file1.TextGrid", "file2.TextGrid", "file3.TextGrid"]
+    text = (tmp_path / "textgrids" / "file0.TextGrid").read_text(encoding="utf8")
+    assert 'name = "spk0 - words"' in text and 'name = "spk4 - phones"' in text
