@@ -112,6 +112,7 @@ class CorpusAligner:
         self.transforms: Optional[np.ndarray] = None
         self._mfcc_cache: Dict[tuple, tuple] = {}
         self._mfcc_cache_bytes = 0
+        self._mfcc_cache_on = False
         self._pcm_stage = None
         self._pcm_stage_free = None
 
@@ -150,8 +151,8 @@ class CorpusAligner:
     def _mfcc(self, utts: Sequence[CorpusUtterance], idx: Sequence[int]):
         import torch
 
-        key = (id(utts), tuple(idx))          # (the list object of the run in progress; align() empties the cache at both ends)
-        hit = self._mfcc_cache.get(key)
+        key = (id(utts), tuple(idx))          # (the list object of the run in progress; the cache only lives inside align())
+        hit = self._mfcc_cache.get(key) if self._mfcc_cache_on else None
         if hit is not None:          # the CMVN pass computed them already (and a second alignment pass asks a third time)
             return hit
         so = np.concatenate([[0], np.cumsum([len(utts[i].pcm) for i in idx])]).astype(np.int64)
@@ -177,7 +178,7 @@ class CorpusAligner:
                     host[a:b] = _kio.compress_round_trip(host[a:b])
             mfcc = torch.from_numpy(host).to(self.engine.device)
         size = mfcc.numel() * mfcc.element_size()
-        if self._mfcc_cache_bytes + size <= self.opt.mfcc_cache_bytes:      # 52 KB per 10 s utterance: HBM holds millions
+        if self._mfcc_cache_on and self._mfcc_cache_bytes + size <= self.opt.mfcc_cache_bytes:   # 52 KB per 10 s utterance: HBM holds millions
             self._mfcc_cache[key] = (mfcc, fo)
             self._mfcc_cache_bytes += size
         return mfcc, fo
@@ -207,14 +208,16 @@ class CorpusAligner:
         import torch
 
         spk_ids = {s: k for k, s in enumerate(dict.fromkeys(u.speaker for u in utts))}
-        total = torch.zeros((len(spk_ids), 2, self.engine.num_ceps + 1), dtype=torch.float64, device=self.engine.device)
+        # per-batch statistics come from the device kernel (float64, fixed order); batches are added up on the host, in
+        # batch order — a few hundred bytes per speaker, and no framework arithmetic on the path
+        total = np.zeros((len(spk_ids), 2, self.engine.num_ceps + 1), dtype=np.float64)
         for idx in self._batches(utts):
             mfcc, fo = self._mfcc(utts, idx)
             rows = np.array([spk_ids[utts[i].speaker] for i in idx], dtype=np.int32)
             local, inv = np.unique(rows, return_inverse=True)
             st = self.engine.cmvn_stats(mfcc, fo, inv.astype(np.int32), len(local))
-            total[torch.from_numpy(local.astype(np.int64)).to(self.engine.device)] += st
-        return spk_ids, total
+            total[local] += st.cpu().numpy()
+        return spk_ids, torch.from_numpy(total).to(self.engine.device)
 
     def _decode(self, graphs, feats, fo, max_tokens, bp_tokens):
         """One device call: scores evaluated lazily for the cells live tokens can reach (default), or the dense matrix."""
@@ -339,7 +342,15 @@ class CorpusAligner:
 
         utts = list(utterances)
         self.failed, self.failure_reasons, self.fallback_first_pass = [], {}, []
-        self._mfcc_cache, self._mfcc_cache_bytes = {}, 0
+        self._mfcc_cache, self._mfcc_cache_bytes, self._mfcc_cache_on = {}, 0, True
+        try:
+            return self._align(utts, speaker_adapted, make_ctm, previous_transforms)
+        finally:
+            self._mfcc_cache, self._mfcc_cache_bytes, self._mfcc_cache_on = {}, 0, False
+
+    def _align(self, utts, speaker_adapted, make_ctm, previous_transforms):
+        import torch
+
         spk_ids, cmvn = self.speaker_cmvn(utts)
         first_model = self.ali_am if self.ali_am is not None else self.am
         self._load(first_model)
@@ -390,7 +401,6 @@ class CorpusAligner:
                 if u.text is not None:   # <unk> intervals get their transcript spelling (MFA/alignment/multiprocessing.py:1749-1751)
                     ur.ctm.word_intervals = _ctm.fix_unk_words(u.text.split(), ur.ctm.word_intervals, self.lexicon)
             out.append(ur)
-        self._mfcc_cache, self._mfcc_cache_bytes = {}, 0
         return out
 
     def export_textgrids(self, utterances: Sequence[CorpusUtterance], results: Sequence[Optional[UtteranceResult]], output_directory,
