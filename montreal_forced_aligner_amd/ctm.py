@@ -25,7 +25,7 @@ class CtmError(ValueError):
     pass
 
 
-@dataclass
+@dataclass(slots=True)
 class CtmInterval:
     """Mirror of MFA/data.py:2017-2080."""
 
