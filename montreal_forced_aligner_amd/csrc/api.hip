@@ -26,7 +26,7 @@ MFA_API void mfa_destroy(mfa_ctx *c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   void *ptrs[] = {c->d_window, c->d_twiddle, c->d_melw, c->d_melidx, c->d_dct, c->d_lifter, c->d_w, c->d_gc,
-                  c->d_row0, c->d_nblk, c->d_slot, c->d_ws, c->d_nrows, c->d_gmm_queue, c->d_wb, c->d_wh, c->d_gch, c->d_fscale, c->d_gmm_redo, c->d_w_stats, c->d_gen_ws, c->d_xsplit, c->d_xsplit_bad, c->d_col_row0, c->d_band_ranges};
+                  c->d_row0, c->d_nblk, c->d_slot, c->d_ws, c->d_nrows, c->d_gmm_queue, c->d_wb, c->d_wh, c->d_gch, c->d_fscale, c->d_gmm_redo, c->d_w_stats, c->d_gen_ws, c->d_gen_list, c->d_xsplit, c->d_xsplit_bad, c->d_col_row0, c->d_band_ranges};
   // teardown: nothing useful can be done with a failure here
   for (void *p : ptrs) if (p) (void)hipFree(p);
   for (auto &p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }

@@ -91,6 +91,8 @@ struct mfa_ctx {
   size_t ws_bytes = 0;
   void *d_gen_ws = nullptr;    // workspace of the general-graph decoder (viterbi_general.hip)
   size_t gen_ws_bytes = 0;
+  int32_t *d_gen_list = nullptr;   // utterances of the general decoder's second tier (full token pool)
+  size_t gen_list_cap = 0;
 
   int fail(const char *fmt, ...) {
     char buf[1024];

@@ -44,8 +44,10 @@ struct GenParams {
   int32_t *rev;                                           // [n_utt][rev_cap] reversed best path (arc indices)
   int rev_cap;
   int32_t *ali; int32_t *words; int32_t *n_words; float *like; float *frame_like; int32_t *status;
-  int n_utt;                                              // end of the launch's utterance range
-  int utt_base;                                           // its first utterance (the batch is decoded in chunks that fit the workspace cap)
+  // work items [item_base, item_end) of this launch; item → utterance utt_list[item] (second tier: the utterances whose token
+  // pool overflowed in the first) or the item itself; workspace slot = item − item_base
+  int item_base, item_end;
+  const int32_t *utt_list;
 };
 
 // One utterance, one thread: the oracle's FasterDecoder (oracle/mfa_oracle.cpp) with arrays in place of std::vector.
@@ -64,7 +66,7 @@ struct Decoder {
   int list_head, bucket_list_tail; int hash_size;
   int status;
 
-  __device__ Decoder(const GenParams &pp, int u) : p(pp), utt(u) {
+  __device__ Decoder(const GenParams &pp, int u, int w) : p(pp), utt(u) {
     const int64_t so = p.g.d_state_off[u];
     S = (int)(p.g.d_state_off[u + 1] - so);
     ab = p.g.d_arc_base[u];
@@ -75,7 +77,6 @@ struct Decoder {
     const int64_t f0 = p.frame_off[u];
     T = (int)(p.frame_off[u + 1] - f0);
     ll = p.ll + p.ll_off[u]; P = p.ll_cols[u];
-    const int w = u - p.utt_base;                  // workspace slot: the launch covers utterances [utt_base, n_utt)
     const int64_t po = p.pool_off[w];
     pool_cap = p.pool_off[w + 1] - po;
     tok_cost = p.tok_cost + po; tok_arc = p.tok_arc + po; tok_prev = p.tok_prev + po;
@@ -285,9 +286,10 @@ struct Decoder {
 };
 
 __global__ __launch_bounds__(64) void viterbi_general_kernel(GenParams p) {
-  const int utt = p.utt_base + blockIdx.x * blockDim.x + threadIdx.x;
-  if (utt >= p.n_utt) return;
-  Decoder d(p, utt);
+  const int item = p.item_base + blockIdx.x * blockDim.x + threadIdx.x;
+  if (item >= p.item_end) return;
+  const int utt = p.utt_list ? p.utt_list[item] : item;
+  Decoder d(p, utt, item - p.item_base);
   const int64_t f0 = p.frame_off[utt];
   int32_t *ali = p.ali + f0, *words = p.words + f0;
   float *flike = p.frame_like ? p.frame_like + f0 : nullptr;
@@ -310,7 +312,7 @@ __global__ __launch_bounds__(64) void viterbi_general_kernel(GenParams p) {
     if (c < best_cost && c != INFINITY) { best_cost = c; best_tok = d.el_val[e]; }
   }
   if (best_tok < 0) { fail(G_FAILED); return; }
-  int32_t *rev = p.rev + (size_t)(utt - p.utt_base) * p.rev_cap;
+  int32_t *rev = p.rev + (size_t)(item - p.item_base) * p.rev_cap;
   int n_rev = 0;
   for (int tok = best_tok; tok != -1; tok = d.tok_prev[tok]) {
     if (n_rev >= p.rev_cap) { fail(G_INTERNAL); return; }
@@ -358,7 +360,6 @@ MFA_API int mfa_align_general_batch(mfa_ctx *c, const mfa_graph_batch *g, const 
   memset(&p, 0, sizeof(p));
   p.g = *g; p.ll = d_loglikes; p.ll_off = d_ll_off; p.ll_cols = d_ll_cols; p.frame_off = d_frame_off;
   p.beam = o->beam; p.retry_beam = o->retry_beam; p.scale = o->acoustic_scale;
-  p.n_utt = n_utt;
   // one token per graph state is a hard upper bound on the live tokens, one bucket per two tokens on the hash size
   p.ncap = (max_states + 63) & ~63;
   p.hcap = 2 * p.ncap > 1000 ? 2 * p.ncap : 1000;
@@ -368,56 +369,91 @@ MFA_API int mfa_align_general_batch(mfa_ctx *c, const mfa_graph_batch *g, const 
   const int ppf = std::min<int64_t>(max_arcs, std::max(4 * (o->bp_tokens_per_frame > 0 ? o->bp_tokens_per_frame : 512), 256));
   p.ppf = ppf;
   p.rev_cap = (int)(4 * max_frames + 64);
-  // Workspace per utterance: the token pool (frames × ppf × 16 bytes: 33 MB for 10 s at the default ppf) dominates.  The
-  // batch is decoded in chunks whose workspace stays under a cap (MFA_GENERAL_WS_GIB, default 64), one launch each.
+  // Workspace per utterance: the token pool (frames × tokens-per-frame × 16 bytes) dominates — 33 MB for 10 s at the full
+  // ppf.  A launch takes ≈0.5 s whatever its size (one thread walks one utterance), so throughput is utterances per launch:
+  // the first tier gives every utterance a pool of 256 tokens per frame (4 MB per 10 s: what the first beam creates fits
+  // several times over), the second tier decodes again, with the full pool, the few whose pool overflowed (wide retry
+  // beams).  Each tier runs in chunks whose workspace stays under a cap (MFA_GENERAL_WS_GIB, default 64), one launch each.
   const size_t per_utt_fixed = (size_t)3 * 2 * p.ncap * 4 + (size_t)2 * p.hcap * 4 + (size_t)p.qcap * 4 + (size_t)p.ncap * 8 +
                                (size_t)p.rev_cap * 4 + 8 + 12 * 256;
   size_t cap_bytes = (size_t)64 << 30;
   { const char *e = getenv("MFA_GENERAL_WS_GIB"); if (e && atof(e) > 0.0) cap_bytes = (size_t)(atof(e) * (double)((size_t)1 << 30)); }
   p.ali = d_ali; p.words = d_words; p.n_words = d_n_words; p.like = d_like; p.frame_like = d_frame_like; p.status = d_status;
   int n_chunks = 0;
-  for (int u0 = 0; u0 < n_utt;) {
-    // the chunk [u0, u1): at least one utterance, then as many as fit
-    int u1 = u0;
-    size_t need = 0;
-    while (u1 < n_utt) {
-      const size_t add = per_utt_fixed + (size_t)(2 + (h_frame_off[u1 + 1] - h_frame_off[u1]) * (int64_t)ppf) * 16;
-      if (u1 > u0 && need + add > cap_bytes) break;
-      need += add; u1++;
+  // one tier: items [0, n_items) (utterance = list[item] or the item), `tpf` pool entries per frame
+  auto run_tier = [&](int n_items, const std::vector<int32_t> *list, const int32_t *d_list, int tpf) -> int {
+    p.ppf = tpf; p.utt_list = d_list;
+    auto utt_of = [&](int item) { return list ? (*list)[item] : item; };
+    for (int i0 = 0; i0 < n_items;) {
+      int i1 = i0;
+      size_t need = 0;
+      while (i1 < n_items) {     // the chunk [i0, i1): at least one utterance, then as many as fit
+        const int u = utt_of(i1);
+        const size_t add = per_utt_fixed + (size_t)(2 + (h_frame_off[u + 1] - h_frame_off[u]) * (int64_t)tpf) * 16;
+        if (i1 > i0 && need + add > cap_bytes) break;
+        need += add; i1++;
+      }
+      const int nc = i1 - i0;
+      std::vector<int64_t> pool_off(nc + 1, 0);
+      for (int k = 0; k < nc; k++) {
+        const int u = utt_of(i0 + k);
+        pool_off[k + 1] = pool_off[k] + 2 + (h_frame_off[u + 1] - h_frame_off[u]) * (int64_t)tpf;
+      }
+      size_t off = 0;
+      auto take = [&](size_t bytes) { size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
+      const size_t o_cost = take((size_t)pool_off[nc] * 8), o_arc = take((size_t)pool_off[nc] * 4), o_prev = take((size_t)pool_off[nc] * 4);
+      const size_t o_poff = take((size_t)(nc + 1) * 8);
+      const size_t o_ek = take((size_t)nc * 2 * p.ncap * 4), o_ev = take((size_t)nc * 2 * p.ncap * 4), o_et = take((size_t)nc * 2 * p.ncap * 4);
+      const size_t o_bp = take((size_t)nc * p.hcap * 4), o_bl = take((size_t)nc * p.hcap * 4);
+      const size_t o_q = take((size_t)nc * p.qcap * 4), o_tmp = take((size_t)nc * p.ncap * 8);
+      const size_t o_rev = take((size_t)nc * p.rev_cap * 4);
+      if (c->gen_ws_bytes < off) {
+        if (c->d_gen_ws) { MFA_HIP_CHECK(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->d_gen_ws); c->d_gen_ws = nullptr; c->gen_ws_bytes = 0; }
+        MFA_HIP_CHECK(c, hipMalloc(&c->d_gen_ws, off));
+        c->gen_ws_bytes = off;
+      }
+      unsigned char *base = (unsigned char *)c->d_gen_ws;
+      p.tok_cost = (double *)(base + o_cost); p.tok_arc = (int32_t *)(base + o_arc); p.tok_prev = (int32_t *)(base + o_prev);
+      p.pool_off = (const int64_t *)(base + o_poff);
+      p.el_key = (int32_t *)(base + o_ek); p.el_val = (int32_t *)(base + o_ev); p.el_tail = (int32_t *)(base + o_et);
+      p.bk_prev = (int32_t *)(base + o_bp); p.bk_last = (int32_t *)(base + o_bl);
+      p.queue = (int32_t *)(base + o_q); p.tmp = (double *)(base + o_tmp); p.rev = (int32_t *)(base + o_rev);
+      MFA_HIP_CHECK(c, hipMemcpyAsync(base + o_poff, pool_off.data(), (size_t)(nc + 1) * 8, hipMemcpyHostToDevice, c->stream));
+      MFA_HIP_CHECK(c, hipStreamSynchronize(c->stream));   // pool_off is a host vector about to go out of scope
+      p.item_base = i0; p.item_end = i1;
+      {
+        KernelTimer kt(c, MFA_K_VITERBI);
+        hipLaunchKernelGGL(viterbi_general_kernel, dim3((nc + 63) / 64), dim3(64), 0, c->stream, p);
+      }
+      MFA_HIP_CHECK(c, hipGetLastError());
+      i0 = i1; n_chunks++;
     }
-    const int nc = u1 - u0;
-    std::vector<int64_t> pool_off(nc + 1, 0);
-    for (int u = 0; u < nc; u++) pool_off[u + 1] = pool_off[u] + 2 + (h_frame_off[u0 + u + 1] - h_frame_off[u0 + u]) * (int64_t)ppf;
-    size_t off = 0;
-    auto take = [&](size_t bytes) { size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
-    const size_t o_cost = take((size_t)pool_off[nc] * 8), o_arc = take((size_t)pool_off[nc] * 4), o_prev = take((size_t)pool_off[nc] * 4);
-    const size_t o_poff = take((size_t)(nc + 1) * 8);
-    const size_t o_ek = take((size_t)nc * 2 * p.ncap * 4), o_ev = take((size_t)nc * 2 * p.ncap * 4), o_et = take((size_t)nc * 2 * p.ncap * 4);
-    const size_t o_bp = take((size_t)nc * p.hcap * 4), o_bl = take((size_t)nc * p.hcap * 4);
-    const size_t o_q = take((size_t)nc * p.qcap * 4), o_tmp = take((size_t)nc * p.ncap * 8);
-    const size_t o_rev = take((size_t)nc * p.rev_cap * 4);
-    if (c->gen_ws_bytes < off) {
-      if (c->d_gen_ws) { MFA_HIP_CHECK(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->d_gen_ws); c->d_gen_ws = nullptr; c->gen_ws_bytes = 0; }
-      MFA_HIP_CHECK(c, hipMalloc(&c->d_gen_ws, off));
-      c->gen_ws_bytes = off;
+    return 0;
+  };
+  const int tpf_small = std::min(ppf, 256);
+  if (run_tier(n_utt, nullptr, nullptr, tpf_small) != 0) return -1;
+  int n_second = 0;
+  if (tpf_small < ppf) {
+    std::vector<int32_t> st((size_t)n_utt);
+    MFA_HIP_CHECK(c, hipMemcpyAsync(st.data(), d_status, (size_t)n_utt * 4, hipMemcpyDeviceToHost, c->stream));
+    MFA_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    std::vector<int32_t> again;
+    for (int u = 0; u < n_utt; u++) if (st[u] == G_BP_OVERFLOW) again.push_back(u);
+    n_second = (int)again.size();
+    if (n_second > 0) {
+      if (c->gen_list_cap < (size_t)n_second) {
+        if (c->d_gen_list) (void)hipFree(c->d_gen_list);
+        c->d_gen_list = nullptr; c->gen_list_cap = 0;
+        MFA_HIP_CHECK(c, hipMalloc((void **)&c->d_gen_list, (size_t)n_second * 4));
+        c->gen_list_cap = (size_t)n_second;
+      }
+      MFA_HIP_CHECK(c, hipMemcpyAsync(c->d_gen_list, again.data(), (size_t)n_second * 4, hipMemcpyHostToDevice, c->stream));
+      MFA_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+      if (run_tier(n_second, &again, c->d_gen_list, ppf) != 0) return -1;
     }
-    unsigned char *base = (unsigned char *)c->d_gen_ws;
-    p.tok_cost = (double *)(base + o_cost); p.tok_arc = (int32_t *)(base + o_arc); p.tok_prev = (int32_t *)(base + o_prev);
-    p.pool_off = (const int64_t *)(base + o_poff);
-    p.el_key = (int32_t *)(base + o_ek); p.el_val = (int32_t *)(base + o_ev); p.el_tail = (int32_t *)(base + o_et);
-    p.bk_prev = (int32_t *)(base + o_bp); p.bk_last = (int32_t *)(base + o_bl);
-    p.queue = (int32_t *)(base + o_q); p.tmp = (double *)(base + o_tmp); p.rev = (int32_t *)(base + o_rev);
-    MFA_HIP_CHECK(c, hipMemcpyAsync(base + o_poff, pool_off.data(), (size_t)(nc + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    MFA_HIP_CHECK(c, hipStreamSynchronize(c->stream));   // pool_off is a host vector about to go out of scope
-    p.utt_base = u0; p.n_utt = u1;
-    {
-      KernelTimer kt(c, MFA_K_VITERBI);
-      hipLaunchKernelGGL(viterbi_general_kernel, dim3((nc + 63) / 64), dim3(64), 0, c->stream, p);
-    }
-    MFA_HIP_CHECK(c, hipGetLastError());
-    u0 = u1; n_chunks++;
   }
-  MFA_DEBUG_POINT(c, "general decoder: %d utterances in %d launches, ncap %d hcap %d ppf %d", n_utt, n_chunks, p.ncap, p.hcap, ppf);
+  MFA_DEBUG_POINT(c, "general decoder: %d utterances in %d launches (%d again with the full pool), ncap %d hcap %d ppf %d", n_utt,
+                  n_chunks, n_second, p.ncap, p.hcap, ppf);
   return 0;
 }
 
