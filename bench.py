@@ -509,6 +509,11 @@ def main():
             if tr:
                 roofline["traffic"] = float(tr["bytes_per_step"])
                 roofline["traffic_source"] = f"profiles/{prof_name}: {tr['how']}"
+                # the same launches against the HBM roof (north_star asks for that fraction too): fabric bytes per step
+                # over the stage's time per step, of 8 TB/s
+                if roofline.get("ms_per_step"):
+                    gbps = roofline["traffic"] / (roofline["ms_per_step"] * 1e-3) / 1e9
+                    roofline["hbm"] = {"achieved": round(gbps, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbps / 8000.0, 4)}
         except (KeyError, ValueError, OSError):
             pass
 
