@@ -29,10 +29,12 @@ def short(name):
         return {"2": "gmm_split_single_kernel_f16", "3": "gmm_split_single_kernel_bf16"}.get(pieces, "gmm_split_single_kernel")
     for k in ("gmm_split_single_kernel", "gmm_bf16_single_kernel", "gmm_bf16_kernel", "gmm_presplit_kernel", "gmm_kernel",
               "viterbi_small_kernel", "viterbi_finish_kernel", "viterbi_kernel", "mfcc_kernel", "feats_lda_kernel", "feats_kernel", "cmvn_utt_kernel", "cmvn_spk_kernel",
-              "arcnext_kernel", "collect_pending_kernel", "finalize_pending_kernel", "gmm_max_first_frame_kernel"):
+              "arcnext_kernel", "collect_pending_kernel", "finalize_pending_kernel", "gmm_max_first_frame_kernel",
+              "gmm_band_ranges_kernel", "gmm_col_rows_kernel"):
         if k in name:
             return k
-    return name.split("(")[0][-60:]
+    base = name.replace("(anonymous namespace)::", "")
+    return (base.split("(")[0] or base)[-60:]
 
 
 summary = {"source": os.path.basename(root), "kernels": {}}
