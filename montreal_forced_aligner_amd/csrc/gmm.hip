@@ -2133,6 +2133,14 @@ int class_index(int slot) { return slot == 32 ? 0 : slot == 16 ? 1 : slot == 8 ?
 
 }  // namespace
 
+// Block counts of multi-block pdfs ride in the five low bits of their columns' row words when every pdf has at most 32 blocks
+// (MFA_GMM_PACK_NB=0: never — the lookup path, for tests)
+static int col_nb_packed_for(const mfa_ctx *c) {
+  const char *e = getenv("MFA_GMM_PACK_NB");
+  if (e && e[0] == '0') return 0;
+  return c->max_nblk <= 32 ? 1 : 0;
+}
+
 extern "C" {
 
 MFA_API int mfa_load_gmm(mfa_ctx *c, int32_t dim, int32_t num_pdfs, const int32_t *h_pdf_offsets, const float *h_gconsts,
@@ -2707,7 +2715,7 @@ int mfa_gmm_presplit(mfa_ctx *c, const MfaLazyScoring *lazy, const int64_t *d_fr
     GmmParams q;
     memset(&q, 0, sizeof(q));
     q.row0 = c->d_row0; q.pdf_list = lazy->plan.d_pdf_list; q.pdf_off = lazy->plan.d_pdf_off; q.n_utt = n_utt;
-    q.nblk = c->d_nblk; q.col_nb_packed = c->max_nblk <= 32 ? 1 : 0;
+    q.nblk = c->d_nblk; q.col_nb_packed = col_nb_packed_for(c);
     hipLaunchKernelGGL(gmm_col_rows_kernel, dim3(n_utt), dim3(256), 0, c->stream, q, c->d_col_row0);
     MFA_HIP_CHECK(c, hipGetLastError());
   }
@@ -2800,7 +2808,7 @@ int mfa_gmm_score_window(mfa_ctx *c, const MfaLazyScoring *lazy, const MfaWindow
     p.redo = c->d_gmm_redo;
     p.wb = (const uint4 *)c->d_wb;
     p.col_row0 = c->d_col_row0;
-    p.col_nb_packed = c->max_nblk <= 32 ? 1 : 0;
+    p.col_nb_packed = col_nb_packed_for(c);
     if (f16_ok) {
       p.wh = (const uint4 *)c->d_wh; p.gch = c->d_gch; p.fscale = c->d_fscale;
       p.acc_scale_inv = 1.0f / c->gmm_acc_scale;

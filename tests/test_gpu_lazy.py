@@ -176,6 +176,13 @@ def test_lazy_random_graphs_all_slot_classes(engine, fx, seed, dim, monkeypatch)
             if int(dense["status"][u]) in (0, 1):
                 assert abs(float(dense["like"][u]) - float(lazy["like"][u])) / (b - a) < 1e-3
     assert same >= len(fsts) - 1
+    # pdfs of several blocks: the block count packed into the column's row word (default) and looked up per column
+    # (MFA_GMM_PACK_NB=0, the path of models with more than 1 024 Gaussians in a pdf) score the same cells to the same bits
+    monkeypatch.setenv("MFA_GMM_PACK_NB", "0")
+    lookup = engine.align_features(graphs, d_feats, fo, **kw)
+    monkeypatch.delenv("MFA_GMM_PACK_NB")
+    assert torch.equal(lookup["loglikes"], lazy["loglikes"]) and torch.equal(lookup["ali"], lazy["ali"])
+    assert torch.equal(lookup["status"], lazy["status"])
 
 
 def test_lazy_path_matches_oracle_from_pcm(engine, tri):
