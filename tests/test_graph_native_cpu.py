@@ -83,7 +83,7 @@ def test_triphone_graphs_are_identical_and_fast():
     t_nat = time.time() - t0
     print(f"native {1e3 * t_nat / len(texts):.3f} ms/utterance (first batch {1e3 * t_first / len(texts):.3f}), "
           f"graph.py {1e3 * t_py / len(texts):.2f} ms/utterance")
-    assert t_nat < t_py / 5
+    assert t_nat < t_py / 3      # (measured: 12-16x with four threads; the bound leaves room for a loaded machine)
 
 
 def test_bad_input_is_refused(fx):
