@@ -217,28 +217,34 @@ __global__ __launch_bounds__(256) void feats_lda_kernel(FeatParams p) {
   const float m_off = lda_offset ? Y[o * p.lda_cols + kSdim] : 0.0f;
   __syncthreads();                                   // Y is free for the outputs
   if (active) {
-    for (int r = g; r < kTileLda; r += G) {
+    // two frames per trip (r and r + G): two independent multiply-add chains in flight per thread — each chain is the
+    // same 91 dependent fmaf's in the same order as before (results unchanged), but the VALU no longer waits on one
+    for (int r = g; r < kTileLda; r += 2 * G) {
       const int t = t0 + r;
       if (t >= T) break;
-      const float *xs = X + r * kXS;                 // frames t-ctx .. t+ctx: rows r .. r+2·ctx of the tile
-      float acc = 0.0f;
+      const int r2 = r + G;
+      const bool two = r2 < kTileLda && t0 + r2 < T;
+      const float *xa = X + r * kXS;                 // frames t-ctx .. t+ctx: rows r .. r+2·ctx of the tile
+      const float *xb = X + (two ? r2 : r) * kXS;
+      float acc = 0.0f, acc2 = 0.0f;
 #pragma unroll
       for (int j = 0; j < 2 * kCtx + 1; j++) {
-        const float *xr = xs + j * kXS;
+        const float *xr = xa + j * kXS, *xr2 = xb + j * kXS;
 #pragma unroll
         for (int d4 = 0; d4 + 4 <= kDim; d4 += 4) {
           const float4 x4 = *reinterpret_cast<const float4 *>(xr + d4);
-          acc = fmaf(m[j * kDim + d4], x4.x, acc);
-          acc = fmaf(m[j * kDim + d4 + 1], x4.y, acc);
-          acc = fmaf(m[j * kDim + d4 + 2], x4.z, acc);
-          acc = fmaf(m[j * kDim + d4 + 3], x4.w, acc);
+          const float4 y4 = *reinterpret_cast<const float4 *>(xr2 + d4);
+          acc = fmaf(m[j * kDim + d4], x4.x, acc);      acc2 = fmaf(m[j * kDim + d4], y4.x, acc2);
+          acc = fmaf(m[j * kDim + d4 + 1], x4.y, acc);  acc2 = fmaf(m[j * kDim + d4 + 1], y4.y, acc2);
+          acc = fmaf(m[j * kDim + d4 + 2], x4.z, acc);  acc2 = fmaf(m[j * kDim + d4 + 2], y4.z, acc2);
+          acc = fmaf(m[j * kDim + d4 + 3], x4.w, acc);  acc2 = fmaf(m[j * kDim + d4 + 3], y4.w, acc2);
         }
 #pragma unroll
-        for (int d = kDim & ~3; d < kDim; d++) acc = fmaf(m[j * kDim + d], xr[d], acc);
+        for (int d = kDim & ~3; d < kDim; d++) { acc = fmaf(m[j * kDim + d], xr[d], acc); acc2 = fmaf(m[j * kDim + d], xr2[d], acc2); }
       }
-      if (lda_offset) acc += m_off;
-      if (p.fmllr) Y[r * R + o] = acc;
-      else p.out[(f0 + t) * R + o] = acc;
+      if (lda_offset) { acc += m_off; acc2 += m_off; }
+      if (p.fmllr) { Y[r * R + o] = acc; if (two) Y[r2 * R + o] = acc2; }
+      else { p.out[(f0 + t) * R + o] = acc; if (two) p.out[(f0 + t0 + r2) * R + o] = acc2; }
     }
   }
   if (!p.fmllr) return;
@@ -251,18 +257,25 @@ __global__ __launch_bounds__(256) void feats_lda_kernel(FeatParams p) {
 #pragma unroll
   for (int k = 0; k < kR; k++) f[k] = X[o * (R + 1) + k];
   const float f_off = X[o * (R + 1) + R];
-  for (int r = g; r < kTileLda; r += G) {
+  for (int r = g; r < kTileLda; r += 2 * G) {        // two frames per trip, as above
     const int t = t0 + r;
     if (t >= T) break;
-    const float *ys = Y + r * R;
-    float acc = 0.0f;
+    const int r2 = r + G;
+    const bool two = r2 < kTileLda && t0 + r2 < T;
+    const float *ys = Y + r * R, *ys2 = Y + (two ? r2 : r) * R;
+    float acc = 0.0f, acc2 = 0.0f;
 #pragma unroll
     for (int k = 0; k < kR; k += 4) {
       const float4 y4 = *reinterpret_cast<const float4 *>(ys + k);
-      acc = fmaf(f[k], y4.x, acc); acc = fmaf(f[k + 1], y4.y, acc); acc = fmaf(f[k + 2], y4.z, acc); acc = fmaf(f[k + 3], y4.w, acc);
+      const float4 z4 = *reinterpret_cast<const float4 *>(ys2 + k);
+      acc = fmaf(f[k], y4.x, acc);          acc2 = fmaf(f[k], z4.x, acc2);
+      acc = fmaf(f[k + 1], y4.y, acc);      acc2 = fmaf(f[k + 1], z4.y, acc2);
+      acc = fmaf(f[k + 2], y4.z, acc);      acc2 = fmaf(f[k + 2], z4.z, acc2);
+      acc = fmaf(f[k + 3], y4.w, acc);      acc2 = fmaf(f[k + 3], z4.w, acc2);
     }
-    acc += f_off;
+    acc += f_off; acc2 += f_off;
     p.out[(f0 + t) * R + o] = acc;
+    if (two) p.out[(f0 + t0 + r2) * R + o] = acc2;
   }
 }
 
