@@ -136,13 +136,15 @@ def _gen_chunk(task):
     out = []
     for i in indices:
         pcm, text, _segs, spk = _WORLD.utterance(int(i))
-        out.append((pcm, G.add_transition_probs(gc.compile_fst(text), scaled), spk))
+        out.append((pcm, G.add_transition_probs(gc.compile_fst(text), scaled), spk, text))
     return out
 
 
 def _cpu_one(task):
-    """Whole oracle path for one utterance (worker process) — the cpu_baseline leg, the only user of oracle/ here."""
-    (pcm, spk_fm, lda, graph, pdf_list, tid2col, am, mono) = task
+    """Whole oracle path for one utterance (worker process) — the cpu_baseline leg, the only user of oracle/ here.
+    Scores are evaluated as Kaldi's decodable evaluates them: lazily, a (frame, pdf) cell when a live token's arc first
+    asks for it, cached for the frame (oracle/mfa_oracle.cpp `Decodable`, lazy form).  Returns (status, cells evaluated)."""
+    (pcm, spk_fm, lda, graph, tid2pdf, am, mono) = task
     from oracle import oracle as O
 
     mf = O.mfcc(pcm.astype(np.float32), O.default_mfcc_opts())
@@ -151,9 +153,8 @@ def _cpu_one(task):
         feats = O.deltas(x)
     else:
         feats = O.affine(O.affine(O.splice(x), lda), spk_fm)
-    ll = O.gmm_loglikes(feats, am[0], am[1], am[2], am[3], pdf_list)
-    r = O.align(graph[0], graph[1], graph[2], graph[3], graph[4], ll, tid2col, 0.1, 10.0, 40.0)
-    return r["status"]
+    r = O.align_feats(graph[0], graph[1], graph[2], graph[3], graph[4], feats, am[0], am[1], am[2], am[3], tid2pdf, 0.1, 10.0, 40.0)
+    return r["status"], r["cells"]
 
 
 def main():
@@ -206,6 +207,10 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(args.dist_backend)
+    if os.environ.get("MFA_BENCH_FAIL_RANK") == str(rank):
+        # test hook (tests/test_gpu_multirank_bench.py): a rank that dies must take the whole run down with a non-zero
+        # exit code, never leave rank 0 printing a line for a job that did not finish
+        raise SystemExit(f"rank {rank}: failing on request (MFA_BENCH_FAIL_RANK)")
     mono = args.workload == "mono"
     eng = AlignmentEngine(local_rank)
     eng.configure_mfcc()  # MFA defaults: 25/10 ms, 23 mel bins, 13 ceps, snip_edges False, dither 0
@@ -299,13 +304,13 @@ def main():
         if world > 1:
             dist.barrier()
 
-    # how much of the score matrix does one step write?  (lazy scoring: the cells inside the decoder's bands)
-    pipe.loglikes.zero_()
-    pipe.step()
-    torch.cuda.synchronize()
-    cells_scored = int((pipe.loglikes != 0).sum().item())
-    pipe.cells_scored_fraction = cells_scored / max(1, pipe.loglikes.numel())
-    log(rank, f"score cells written: {cells_scored}/{pipe.loglikes.numel()} = {pipe.cells_scored_fraction:.4f}")
+    # how much of the score matrix does one step write?  (lazy scoring: the cells inside the decoder's bands) — the work
+    # the scoring stage executes, which is what the roofline prices
+    sc = pipe.measure_scored_cells()
+    for p_ in pipes[1:]:
+        p_.cells_scored, p_.cells_scored_fraction, p_.scored_flops = pipe.cells_scored, pipe.cells_scored_fraction, pipe.scored_flops
+    log(rank, f"score cells written: {int(sc['cells'])}/{pipe.loglikes.numel()} = {sc['fraction']:.4f}; "
+              f"{sc['flops'] / 1e12:.3f} TFLOP executed per step ({pipe.gmm_flops / 1e12:.3f} for the whole reachable matrix)")
     if os.environ.get("MFA_GMM_STAMPS"):  # diagnostic (library built with -DGMM_BAND_STAMPS): band kernel phase ticks (100 MHz)
         import ctypes as C
         acc = torch.zeros(16, dtype=torch.int64, device=dev)
@@ -460,6 +465,76 @@ def main():
             step_resident()
         torch.cuda.synchronize()
 
+    # ---- end to end through the host side (SURVEY §8d restated for configs[3]: PCM + transcripts in host memory ->
+    # alignments on the host -> interval arrays -> TextGrid text): CorpusAligner over the same utterances, every rank its
+    # own, barrier + max over ranks like the device loops
+    if not args.no_extra_loops:
+        import shutil
+        import tempfile
+
+        from montreal_forced_aligner_amd.aligner import AlignOptions, CorpusAligner, CorpusUtterance
+
+        pt = world_.lexicon.phone_table
+        utts_e2e = [CorpusUtterance(f"s{int(utt_spk[b_])}-{b_}", f"s{int(utt_spk[b_])}", pool[idx[b_]][0], pool[idx[b_]][3],
+                                    file_name=f"u{b_:05d}") for b_ in range(B)]
+        spk_order = list(dict.fromkeys(u.speaker for u in utts_e2e))
+        prev_tf = None if mono else fm_np[np.array([int(s_[1:]) for s_ in spk_order]) % n_spk_total]
+        ca = CorpusAligner(model.tm, model.am, model.tree, world_.lexicon, lda=lda_np, engine=eng,
+                           options=AlignOptions(beam=args.beam, retry_beam=args.retry_beam, max_tokens=args.max_tokens,
+                                                bp_tokens_per_frame=args.bp_tokens, batch_frames=B * 1001),
+                           silence_phones=[pt.find("sil"), pt.find("spn")])
+        ca.align(utts_e2e[: min(B, 256)], make_ctm=False, previous_transforms=prev_tf)       # warm-up (allocations, tables)
+        e2e = {}
+        holder = {}
+        dt_a = timed_loop(lambda: holder.__setitem__("res", ca.align(utts_e2e, make_ctm=False, previous_transforms=prev_tf)), 1)
+        ok_a = sum(r is not None for r in holder["res"])
+        e2e["alignments"] = {"value": round(B * world / dt_a, 2), "seconds": round(dt_a, 3), "aligned_fraction": ok_a / B}
+        out_dir = Path(tempfile.mkdtemp(prefix="mfa_bench_tg_"))
+
+        def to_textgrids():
+            res_ = ca.align(utts_e2e, make_ctm=True, previous_transforms=prev_tf)
+            holder["files"] = ca.export_textgrids(utts_e2e, res_, out_dir)
+
+        try:
+            dt_t = timed_loop(to_textgrids, 1)
+            n_files = len(holder["files"])
+            tg_bytes = sum(f_.stat().st_size for f_ in holder["files"])
+        finally:
+            shutil.rmtree(out_dir, ignore_errors=True)
+        e2e["textgrids"] = {"value": round(B * world / dt_t, 2), "seconds": round(dt_t, 3), "files": n_files, "bytes": tg_bytes}
+        e2e["what"] = ("CorpusAligner, one process per GPU: int16 PCM + transcripts in host memory -> graphs compiled -> device "
+                       "path -> alignments on the host ('alignments'); -> phone/word intervals -> one long-format TextGrid "
+                       "file per utterance written to a temporary directory ('textgrids')")
+        extra["value_end_to_end"] = e2e["alignments"]["value"]
+        extra["value_end_to_end_textgrid"] = e2e["textgrids"]["value"]
+        extra["end_to_end"] = e2e
+
+    # ---- CPU baseline (rank 0, one GPU): the oracle with Kaldi's lazy decodable on a bounded sample.  Run before the
+    # rooflines are written: its count of score cells the decoder asks for prices the Viterbi stage's score bytes.
+    cpu_baseline, score_cells_read = None, None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        n_s = args.cpu_sample or min(n_pool, (16 if mono else 8) * cores)
+        am = model.am
+        tid2pdf = np.maximum(model.tm.id2pdf, 0).astype(np.int32)
+        sample = []
+        for i in range(n_s):
+            pcm, fst, spk, _text = pool[i]
+            sample.append((pcm, None if mono else fm_np[spk % n_spk_total], lda_np,
+                           (fst.num_states, fst.start, fst.arc_offsets, fst.arcs, fst.final),
+                           tid2pdf, (am.gconsts, am.means_invvars, am.inv_vars, am.pdf_offsets), mono))
+        log(rank, f"CPU baseline: oracle (lazy decodable) on {n_s} utterances over {cores} worker processes ...")
+        t0 = time.time()
+        st = pool_proc.map(_cpu_one, sample, chunksize=1)
+        secs = time.time() - t0
+        rate = n_s / secs
+        cells_per_utt = float(np.mean([c for _s, c in st]))
+        score_cells_read = cells_per_utt * B
+        cpu_baseline = {"value": round(rate, 3), "unit": "utterances/s", "cores": cores, "kind": "port",
+                        "sample": f"{n_s} utterances of the same workload, full oracle path (MFCC .. Viterbi), scores evaluated "
+                                  f"lazily and cached per frame as Kaldi's decodable does ({cells_per_utt:.0f} (frame, pdf) cells "
+                                  f"per utterance), {secs:.1f}s wall, one process per core; CPU restatement, not stock Kaldi",
+                        "score_cells_per_utterance": round(cells_per_utt, 1)}
+
     # ---- the same stages with ONE batch in flight (no other stream's kernels sharing the chip): clean per-kernel times
     single = None
     kt_ss, n_ss = None, 0
@@ -480,31 +555,31 @@ def main():
                   "stage_ms_per_step": {k: round(v["ms"] / n_ss, 3) for k, v in kt_ss.items()},
                   "launches_per_step": {k: v["launches"] / n_ss for k, v in kt_ss.items()},
                   "roofline_scoring": pipe.roofline("gmm", kt_ss, n_ss, mono, args.gauss_per_pdf),
-                  "roofline_viterbi": pipe.roofline("viterbi", kt_ss, n_ss, mono, args.gauss_per_pdf)}
+                  "roofline_viterbi": pipe.roofline("viterbi", kt_ss, n_ss, mono, args.gauss_per_pdf, score_cells_read)}
 
     # ---- roofline of the dominant kernel of the step (largest share of the per-stage HIP-event times; with several
     # batches in flight these are measured while other streams' kernels share the chip — what rocprofv3 sees too)
     stage_ms = {k: v["ms"] / args.steps for k, v in ktimes.items()}
     dominant = max(stage_ms, key=stage_ms.get)
-    roofline_concurrent = pipe.roofline(dominant, ktimes, args.steps, mono, args.gauss_per_pdf)
+    roofline_concurrent = pipe.roofline(dominant, ktimes, args.steps, mono, args.gauss_per_pdf, score_cells_read)
     roofline_concurrent["measured"] = (f"timed region, {n_inflight} batches in flight: launch durations include the time other "
                                        "streams' kernels share the chip")
     if kt_ss is not None:
         # the kernel's own roofline: its launch durations with the chip to itself (the one-batch-in-flight loop of this
         # very run, HIP events on the launch stream) — what tools/profile_round.sh's --inflight 1 stats pass and the PMC
         # passes see too.  The figure taken inside the timed region stays in the line as roofline_batches_in_flight.
-        roofline = pipe.roofline(dominant, kt_ss, n_ss, mono, args.gauss_per_pdf)   # (dominant: by the timed region's stage times)
+        roofline = pipe.roofline(dominant, kt_ss, n_ss, mono, args.gauss_per_pdf, score_cells_read)   # (dominant: by the timed region's stage times)
         roofline["measured"] = "one batch in flight (same run, after the timed region): the kernel has the chip to itself"
     else:
         roofline = roofline_concurrent
     # fabric-side bytes of that kernel's launches: PMC counters cannot be collected from inside this process, so the
     # figure is the one tools/profile_round.sh measured (separate rocprofv3 --pmc passes of this very command), committed
     # under profiles/; it applies to the default workload at the batch size in the file's name
-    prof_name = f"r02_profile_summary_triphone_b{B}.json"
-    prof = ROOT / "profiles" / prof_name
-    if not mono and prof.exists():
+    prof_name = next((n_ for n_ in (f"r03_profile_summary_triphone_b{B}.json", f"r02_profile_summary_triphone_b{B}.json")
+                      if (ROOT / "profiles" / n_).exists()), None)
+    if not mono and prof_name is not None:
         try:
-            with open(prof) as fh:
+            with open(ROOT / "profiles" / prof_name) as fh:
                 tr = json.load(fh).get("bench_roofline_traffic", {}).get(roofline.get("kernel_key", ""))
             if tr:
                 roofline["traffic"] = float(tr["bytes_per_step"])
@@ -537,6 +612,12 @@ def main():
             "batches_in_flight": n_inflight, "hip_hardware_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
             "scores": pipe.scores_string(),
         },
+        "value_definition": ("value = the bench contract's rate: inputs (PCM, graphs) resident in HBM when the timed region "
+                             "starts, alignments copied to pinned host memory inside every step.  value_host_fed = SURVEY 8(d)'s "
+                             "wording (PCM in pinned host memory -> alignments in host memory, PCIe inside the timed region); "
+                             "value_end_to_end[_textgrid] = from PCM + transcripts on the host through graph compilation to "
+                             "alignments [and TextGrid files]"),
+        "value_resident": round(value, 2),
         "real_time_factor": dt / (pipe.audio_seconds * args.steps * world),
         "aligned_fraction": n_ok / B, **({"diagnostic_variant": os.environ["MFA_GMM_DIAG"]} if diagnostic else {}),
         "stage_ms_per_step": {k: round(v, 3) for k, v in stage_ms.items()},
@@ -545,29 +626,9 @@ def main():
         "roofline_batches_in_flight": roofline_concurrent,
         **({"single_batch_in_flight": single} if single is not None else {}),
     }
-
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        n_s = args.cpu_sample or min(n_pool, (16 if mono else 8) * cores)
-        am = model.am
-        tid2pdf = np.maximum(model.tm.id2pdf, 0)
-        sample = []
-        for i in range(n_s):
-            pcm, fst, spk = pool[i]
-            pl = graphs.pdf_lists_host[i]
-            lut = np.zeros(am.num_pdfs, np.int32)
-            lut[pl] = np.arange(len(pl), dtype=np.int32)
-            sample.append((pcm, None if mono else fm_np[spk % n_spk_total], lda_np,
-                           (fst.num_states, fst.start, fst.arc_offsets, fst.arcs, fst.final), pl,
-                           lut[tid2pdf].astype(np.int32), (am.gconsts, am.means_invvars, am.inv_vars, am.pdf_offsets), mono))
-        log(rank, f"CPU baseline: oracle on {n_s} utterances over {cores} worker processes ...")
-        t0 = time.time()
-        st = pool_proc.map(_cpu_one, sample, chunksize=1)
-        secs = time.time() - t0
-        rate = n_s / secs
-        out["cpu_baseline"] = {"value": round(rate, 3), "unit": "utterances/s", "cores": cores, "kind": "port",
-                               "sample": f"{n_s} utterances of the same workload, full oracle path (MFCC..Viterbi), "
-                                         f"{secs:.1f}s wall, one process per core; CPU restatement, not stock Kaldi"}
-        out["gpu_over_cpu"] = round(value / rate, 1) if rate > 0 else None
+    if cpu_baseline is not None:
+        out["cpu_baseline"] = cpu_baseline
+        out["gpu_over_cpu"] = round(value / cpu_baseline["value"], 1) if cpu_baseline["value"] > 0 else None
     pool_proc.close()
     pool_proc.join()
     if rank == 0:

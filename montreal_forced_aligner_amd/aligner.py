@@ -109,6 +109,7 @@ class CorpusAligner:
         self.failed: List[str] = []
         self.failure_reasons: Dict[str, str] = {}
         self.fallback_first_pass: List[str] = []
+        self.ctm_failed: List[str] = []          # aligned, but the interval stage raised (alignment kept, ctm None)
         self.transforms: Optional[np.ndarray] = None
         self._mfcc_cache: Dict[tuple, tuple] = {}
         self._mfcc_cache_bytes = 0
@@ -165,9 +166,12 @@ class CorpusAligner:
             self._pcm_stage_free.synchronize()          # the previous batch's copy has left the buffer
         if total:
             np.concatenate([np.asarray(utts[i].pcm, dtype=np.int16) for i in idx], out=self._pcm_stage.numpy()[:total])
-        pcm = self._pcm_stage[:total].to(self.engine.device, non_blocking=True)
-        self._pcm_stage_free = torch.cuda.Event()
-        self._pcm_stage_free.record()
+        # the copy and the event that guards the staging buffer go on the ENGINE's stream (the current device of the process
+        # may be another one: align_sharded creates CorpusAligner(device=rank) without torch.cuda.set_device)
+        with torch.cuda.device(self.engine.device):
+            pcm = self._pcm_stage[:total].to(self.engine.device, non_blocking=True)
+            self._pcm_stage_free = torch.cuda.Event()
+            self._pcm_stage_free.record(torch.cuda.current_stream(self.engine.device))
         mfcc, fo = self.engine.mfcc(pcm, so)
         if self.opt.corpus_compression:      # feats.*.ark of MfccFunction: compute_mfccs_for_export(seg, compress=True)
             from . import kaldi_io as _kio
@@ -341,7 +345,7 @@ class CorpusAligner:
         import torch
 
         utts = list(utterances)
-        self.failed, self.failure_reasons, self.fallback_first_pass = [], {}, []
+        self.failed, self.failure_reasons, self.fallback_first_pass, self.ctm_failed = [], {}, [], []
         self._mfcc_cache, self._mfcc_cache_bytes, self._mfcc_cache_on = {}, 0, True
         try:
             return self._align(utts, speaker_adapted, make_ctm, previous_transforms)
@@ -394,14 +398,26 @@ class CorpusAligner:
                 continue
             ur = UtteranceResult(u.utt_id, u.speaker, r["ali"], r["words"], r["like"], r["frames"])
             if make_ctm:
-                ivs = _ctm.generate_ctm(r["ali"], self.tm, self.lexicon.phone_table, self.frame_shift)
-                ur.ctm = _ctm.phones_to_pronunciations(self.lexicon, r["words"], ivs, text=u.text)
-                ur.ctm.likelihood = ur.per_frame_likelihood
-                ur.ctm.update_utterance_boundaries(u.begin, u.begin + len(u.pcm) / float(self.mfcc_options.get("sample_frequency", 16000.0)))
-                if u.text is not None:   # <unk> intervals get their transcript spelling (MFA/alignment/multiprocessing.py:1749-1751)
-                    ur.ctm.word_intervals = _ctm.fix_unk_words(u.text.split(), ur.ctm.word_intervals, self.lexicon)
+                # per utterance, as the reference's extraction loop: an exception concerns this utterance only
+                # (MFA/alignment/multiprocessing.py:1739-1770 catches, logs and continues)
+                try:
+                    ur.ctm = self._make_ctm(u, r, ur.per_frame_likelihood)
+                except Exception as e:  # noqa: BLE001
+                    self.failure_reasons[u.utt_id] = f"interval extraction failed: {e}"
+                    self.ctm_failed.append(u.utt_id)
             out.append(ur)
         return out
+
+    def _make_ctm(self, u: CorpusUtterance, r: dict, per_frame_likelihood: float) -> _ctm.HierarchicalCtm:
+        """generate_ctm → phones_to_pronunciations → update_utterance_boundaries → fix_unk_words
+        (MFA/alignment/multiprocessing.py:1733-1751)."""
+        ivs = _ctm.generate_ctm(r["ali"], self.tm, self.lexicon.phone_table, self.frame_shift)
+        ctm = _ctm.phones_to_pronunciations(self.lexicon, r["words"], ivs, text=u.text)
+        ctm.likelihood = per_frame_likelihood
+        ctm.update_utterance_boundaries(u.begin, u.begin + len(u.pcm) / float(self.mfcc_options.get("sample_frequency", 16000.0)))
+        if u.text is not None:   # <unk> intervals get their transcript spelling (MFA/alignment/multiprocessing.py:1749-1751)
+            ctm.word_intervals = _ctm.fix_unk_words(u.text.split(), ctm.word_intervals, self.lexicon)
+        return ctm
 
     def export_textgrids(self, utterances: Sequence[CorpusUtterance], results: Sequence[Optional[UtteranceResult]], output_directory,
                          output_format: str = "long_textgrid", cleanup_silence: bool = True) -> List[Path]:

@@ -610,8 +610,11 @@ class Pipeline:
             return "f32 scores from 3-way bf16-split products (2^-24 per term), f64 path costs"
         return "f32 (scores), f64 (path costs)"
 
-    def algorithmic_bytes(self) -> Dict[str, float]:
-        """SURVEY §8(d) staged-pipeline bytes of one step, per stage (each tensor written once and read once)."""
+    def algorithmic_bytes(self, score_cells_read: Optional[float] = None) -> Dict[str, float]:
+        """SURVEY §8(d) staged-pipeline bytes of one step, per stage (each tensor written once and read once).  The score
+        matrix counts for what is actually moved: the scoring stage writes the cells it computes, the decoder reads
+        ``score_cells_read`` cells (counted by the oracle's lazy decodable on a sample — the device decoder asks for exactly
+        the same cells) or, without that count, at most the cells written."""
         T = np.diff(self.frame_off).astype(np.float64)
         P = np.diff(self.graphs.pdf_off_host).astype(np.float64)
         n_samples = float(self.pcm.numel())
@@ -619,54 +622,89 @@ class Pipeline:
         S = float(self.graphs.tensors["final"].numel())
         D = float(self.feat_dim)
         tot = float(T.sum())
+        written = getattr(self, "cells_scored", None) if self.lazy else None
+        if written is None:
+            written = float((P * T).sum())
+        if score_cells_read is not None:
+            read, how = float(score_cells_read), "4 B x cells the decoder read (oracle's lazy-decodable count on the CPU sample, scaled to the batch)"
+        else:
+            read, how = written, "4 B x cells the scoring stage wrote (upper bound of the cells the decoder read)"
+        if not hasattr(self, "_states_times_frames"):
+            self._states_times_frames = float((T * np.diff(self.graphs.tensors["state_off"].cpu().numpy())).sum())
         return {
             "mfcc": 2.0 * n_samples + 4.0 * self.num_ceps * tot,
             "feats": 4.0 * self.num_ceps * tot + 4.0 * D * tot,
-            "gmm": 4.0 * D * tot + 4.0 * float((P * T).sum()),            # model slice cache-resident (SURVEY's 6.0 MB variant)
-            "viterbi": 4.0 * float((P * T).sum()) + 16.0 * A + 2.0 * float((T * np.diff(self.graphs.tensors["state_off"].cpu().numpy())).sum()) + 6.0 * tot,
+            "gmm": 4.0 * D * tot + 4.0 * written,                  # model slice cache-resident (SURVEY's 6.0 MB variant)
+            "viterbi": 4.0 * read + 16.0 * A + 2.0 * self._states_times_frames + 6.0 * tot,
+            "viterbi_score_bytes_how": how,
             "states": S,
         }
 
-    def _executed_share(self) -> float:
-        """Cells the scoring kernels actually computed ÷ cells the algorithmic flop count prices (the reachability-bounded
-        matrix): < 1 on the lazy path, which scores only what live decoder tokens can ask for."""
-        frac = getattr(self, "cells_scored_fraction", None)
-        if frac is None or not self.lazy:
-            return 1.0
-        T = np.diff(self.frame_off).astype(np.float64)
-        total = float((T * np.diff(self.graphs.pdf_off_host)).sum())
-        g_of_pdf = np.diff(self.e.gmm.pdf_offsets).astype(np.float64)
-        priced = self.gmm_flops / (4.0 * self.e.gmm.dim) / max(1.0, float(g_of_pdf.mean()))
-        return min(1.0, frac * total / max(1.0, priced))
+    def measure_scored_cells(self) -> Dict[str, float]:
+        """One step on a zero-filled score scratch: which cells did the scoring kernels write?  Returns the count, the
+        fraction of the T x P matrix, and the flops those cells cost (4*D*g per cell, g = Gaussians of the cell's pdf) —
+        the work the scoring stage EXECUTES, which is what bench.py's roofline prices."""
+        self.loglikes.zero_()
+        self.step()
+        torch.cuda.synchronize(self.e.device)
+        g_of_pdf = torch.from_numpy(np.diff(self.e.gmm.pdf_offsets).astype(np.float64)).to(self.e.device)
+        pdf_list = self.graphs.pdf_list.long()
+        T = np.diff(self.frame_off)
+        cells = torch.zeros((), dtype=torch.float64, device=self.e.device)
+        weighted = torch.zeros((), dtype=torch.float64, device=self.e.device)
+        po = self.graphs.pdf_off_host
+        for u in range(self.n_utt):
+            a, b = int(self.ll_off[u]), int(self.ll_off[u + 1])
+            if b == a:
+                continue
+            per_col = (self.loglikes[a:b].view(int(T[u]), -1) != 0).sum(dim=0).to(torch.float64)
+            cells += per_col.sum()
+            weighted += (per_col * g_of_pdf[pdf_list[int(po[u]): int(po[u + 1])]]).sum()
+        self.cells_scored = float(cells.item())
+        self.cells_scored_fraction = self.cells_scored / max(1, self.loglikes.numel())
+        self.scored_flops = 4.0 * self.e.gmm.dim * float(weighted.item())
+        return {"cells": self.cells_scored, "fraction": self.cells_scored_fraction, "flops": self.scored_flops}
 
-    def roofline(self, dominant: str, ktimes: Dict[str, Dict[str, float]], steps: int, mono: bool, gauss_per_pdf: int) -> Dict:
-        """Roofline object for the dominant stage of the step (bench.py): per-step stage time from the HIP-event timers."""
+    def roofline(self, dominant: str, ktimes: Dict[str, Dict[str, float]], steps: int, mono: bool, gauss_per_pdf: int,
+                 score_cells_read: Optional[float] = None) -> Dict:
+        """Roofline object for a stage of the step (bench.py): per-step stage time from the HIP-event timers.  Everything
+        priced here is work the kernels EXECUTE: scoring = the cells the lazy path wrote (``measure_scored_cells``), the
+        decoder's score bytes = the cells it read (``score_cells_read`` when the oracle counted them on a sample, else the
+        cells written — an upper bound)."""
         import os
         ms = ktimes[dominant]["ms"] / max(1, steps)
         launches = ktimes[dominant]["launches"] / max(1, steps)
+        lazy_measured = self.lazy and getattr(self, "scored_flops", None) is not None
         if dominant == "gmm":
             split = os.environ.get("MFA_GMM_BF16", "1") != "0" and not mono and gauss_per_pdf != 1
             f16 = split and os.environ.get("MFA_GMM_F16", "1") != "0"
             mult = 3.0 if f16 else (6.0 if split else 1.0)
             peak = 2500.0 if split else 157.3
-            ach = self.gmm_flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            flops = self.scored_flops if lazy_measured else self.gmm_flops
+            ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            equiv = self.gmm_flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             return {"kernel": "diagonal-GMM scoring (" + ("f16x2" if f16 else "bf16x3" if split else "f32") + " MFMA)",
                     "kernel_key": "gmm", "bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4), "traffic": None,
-                    "algorithmic_flops_per_step": self.gmm_flops, "mfma_flops_per_algorithmic_flop": int(mult),
+                    "executed_flops_per_step": flops, "mfma_flops_per_algorithmic_flop": int(mult),
+                    "executed_mfma_tflops": round(mult * ach, 3), "executed_mfma_frac_of_peak": round(mult * ach / peak, 4),
                     "cells_scored_fraction": getattr(self, "cells_scored_fraction", None),
-                    "executed_mfma_frac_of_peak": round(mult * ach / peak * self._executed_share(), 4), "ms_per_step": round(ms, 4),
-                    "launches_per_step": launches,
-                    "note": "algorithmic flops = 4*D*g per (frame, pdf) cell of the reachability-bounded matrix (SURVEY 8d)"}
-        by = self.algorithmic_bytes()
+                    "algorithmic_equivalent_tflops": round(equiv, 3), "ms_per_step": round(ms, 4), "launches_per_step": launches,
+                    "note": "achieved = 4*D*g flops of the (frame, pdf) cells the scoring kernels actually computed / stage time; "
+                            "executed_mfma_* = the same times the split-operand products per term; algorithmic_equivalent_tflops "
+                            "prices every cell of the reachability-bounded matrix (what a dense scorer would do) and is NOT work done"}
+        by = self.algorithmic_bytes(score_cells_read)
         b = by.get(dominant, 0.0)
         gbs = b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        names = {"viterbi": "viterbi_kernel (beam Viterbi, one wavefront per utterance)", "mfcc": "mfcc_kernel",
+        names = {"viterbi": "viterbi kernels (beam Viterbi, one wavefront per utterance)", "mfcc": "mfcc_kernel",
                  "feats": "feats_lda_kernel / feats_kernel", "cmvn": "cmvn kernels"}
-        return {"kernel": names.get(dominant, dominant), "kernel_key": dominant, "bound": "hbm", "achieved": round(gbs, 2),
-                "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 5), "traffic": None,
-                "algorithmic_bytes_per_step": b, "ms_per_step": round(ms, 4), "launches_per_step": launches,
-                "note": "algorithmic bytes = SURVEY 8(d) staged-pipeline bytes of this stage (each tensor written once, read once)"}
+        out = {"kernel": names.get(dominant, dominant), "kernel_key": dominant, "bound": "hbm", "achieved": round(gbs, 2),
+               "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 5), "traffic": None,
+               "algorithmic_bytes_per_step": b, "ms_per_step": round(ms, 4), "launches_per_step": launches,
+               "note": "algorithmic bytes = SURVEY 8(d) staged-pipeline bytes of this stage (each tensor written once, read once)"}
+        if dominant == "viterbi":
+            out["score_bytes"] = by["viterbi_score_bytes_how"]
+        return out
 
     def front(self) -> None:
         """PCM → MFCC → CMVN statistics → final features (three launches on the engine's stream)."""

@@ -16,6 +16,7 @@ the C ABI; a missing library or GPU raises ``MfaHipError`` — there is no CPU p
 """
 from __future__ import annotations
 
+import logging
 from dataclasses import dataclass
 from pathlib import Path
 from typing import Dict, Iterable, Iterator, List, Optional, Sequence, Tuple, Union
@@ -28,6 +29,8 @@ from . import kaldi_io
 from . import model as _model
 from .graph import LexiconCompiler as _LexiconCompiler
 from .graph import Pronunciation as KalpyPronunciation  # noqa: F401  (name used by the reference)
+
+logger = logging.getLogger("kalpy.align")      # the reference's per-job logger name (MFA/utils.py:1435-1476)
 
 _ENGINE = None
 
@@ -406,6 +409,7 @@ class Alignment:
     words: List[int]
     likelihood: float
     per_frame_likelihoods: Optional[np.ndarray] = None
+    status: int = 0                 # 0 aligned with the first beam, 1 with the retry beam (include/mfa_hip.h)
 
     def generate_ctm(self, transition_model, phone_table, frame_shift: float = 0.01):
         return _ctm.generate_ctm(self.alignment, transition_model, phone_table, frame_shift)
@@ -464,15 +468,35 @@ class GmmAligner:
             graphs = eng.pack_graphs_general([_graph.add_transition_probs(f, self._scaled) for f in fsts], self.transition_model)
             res = eng.align_general(graphs, d_feats, frame_off, beam=self.beam, retry_beam=self.retry_beam,
                                     acoustic_scale=self.acoustic_scale, want_frame_likes=True)
-            res = {k: v.cpu().numpy() for k, v in res.items() if isinstance(v, torch.Tensor)}
+            res = {k: res[k].cpu().numpy() for k in self._RESULT_KEYS}
             return self._collect(res, frame_off, len(fsts), utterance_ids)
-        graphs = eng.pack_graphs([_graph.add_transition_probs(f, self._scaled) for f in fsts], self.transition_model)
+        scaled_fsts = [_graph.add_transition_probs(f, self._scaled) for f in fsts]
+        graphs = eng.pack_graphs(scaled_fsts, self.transition_model)
         # features in, alignments out — the decodable is evaluated lazily, as Kaldi's is: per window of frames only the
         # pdfs that arcs near the live tokens can emit are scored (mfa_align_features_batch)
         res = eng.align_features(graphs, d_feats, frame_off, beam=self.beam, retry_beam=self.retry_beam,
                                  acoustic_scale=self.acoustic_scale, want_frame_likes=True)
-        res = {k: v.cpu().numpy() for k, v in res.items() if isinstance(v, torch.Tensor)}
+        res = {k: res[k].cpu().numpy() for k in self._RESULT_KEYS}      # (not the score scratch: ΣT·P floats)
+        # Token / back-pointer capacity overflows (status 3 / 4) are not alignment failures — FasterDecoder has no such
+        # limit: those utterances are decoded again with the hard bounds (one token per graph state), which cannot
+        # overflow, exactly as CorpusAligner._pass does.
+        over = [u for u in range(len(fsts)) if int(res["status"][u]) in (3, 4)]
+        if over:
+            sub = eng.pack_graphs([scaled_fsts[u] for u in over], self.transition_model)
+            fo2 = np.concatenate([[0], np.cumsum([frame_off[u + 1] - frame_off[u] for u in over])]).astype(np.int64)
+            f2 = eng.gather_rows(d_feats, np.concatenate([np.arange(frame_off[u], frame_off[u + 1]) for u in over]))
+            r2 = eng.align_features(sub, f2, fo2, beam=self.beam, retry_beam=self.retry_beam, acoustic_scale=self.acoustic_scale,
+                                    max_tokens=sub.max_states, bp_tokens_per_frame=sub.max_states, want_frame_likes=True)
+            r2 = {k: r2[k].cpu().numpy() for k in self._RESULT_KEYS}
+            for j, u in enumerate(over):
+                a, b, a2, b2 = int(frame_off[u]), int(frame_off[u + 1]), int(fo2[j]), int(fo2[j + 1])
+                for k in ("ali", "words", "frame_like"):
+                    res[k][a:b] = r2[k][a2:b2]
+                for k in ("n_words", "like", "status"):
+                    res[k][u] = r2[k][j]
         return self._collect(res, frame_off, len(fsts), utterance_ids)
+
+    _RESULT_KEYS = ("ali", "words", "n_words", "like", "status", "frame_like")
 
     @staticmethod
     def _collect(res, frame_off, n, utterance_ids) -> List[Optional[Alignment]]:
@@ -480,14 +504,17 @@ class GmmAligner:
         for u in range(n):
             st = int(res["status"][u])
             if st not in (0, 1):
-                # the reference returns None and lets the caller count the failure (capacity / unsupported-graph statuses
-                # included: they concern this utterance only, never the rest of the batch)
+                # the reference returns None and lets the caller count the failure (statuses beyond "no final token"
+                # concern this utterance only, never the rest of the batch; they are logged with their code)
+                if st != 2:
+                    logger.warning("utterance %s: device decoder status %d (include/mfa_hip.h)",
+                                   utterance_ids[u] if utterance_ids else u, st)
                 out.append(None)
                 continue
             a, b = int(frame_off[u]), int(frame_off[u + 1])
             nw = int(res["n_words"][u])
             out.append(Alignment(utterance_ids[u] if utterance_ids else None, res["ali"][a:b].tolist(),
-                                 res["words"][a: a + nw].tolist(), float(res["like"][u]), res["frame_like"][a:b].copy()))
+                                 res["words"][a: a + nw].tolist(), float(res["like"][u]), res["frame_like"][a:b].copy(), st))
         return out
 
     def align_utterance(self, training_graph: kaldi_io.Fst, features: np.ndarray, utterance_id: Optional[str] = None):

@@ -500,9 +500,32 @@ struct Graph {
   int32_t num_states, start; const int64_t *arc_off; const orc_arc *arcs; const float *final_w;
 };
 
+// Two forms of the decodable.  Dense: a precomputed [T][ncols] matrix (gmm_compute_likes-style callers, and what most tests
+// feed).  Lazy: Kaldi's own, DecodableAmDiagGmmScaled over DecodableAmDiagGmmUnmapped (gmm/decodable-am-diag-gmm.{h,cc}):
+// LogLikelihood(frame, tid) = scale * LogLikelihoodZeroBased(frame, TransitionIdToPdf(tid)), and LogLikelihoodZeroBased
+// keeps one cached value per pdf, valid while its hit_time equals the frame asked for — so a (frame, pdf) score is computed
+// only when a live token's arc asks for it, once.  Same gauss_ll / log_sum_exp as orc_gmm_loglikes: identical floats.
 struct Decodable {
   const float *loglikes; int32_t T, ncols; const int32_t *tid2col; float scale;
-  inline float LogLikelihood(int frame, int tid) const { return scale * loglikes[(size_t)frame * ncols + tid2col[tid]]; }
+  // lazy form (feats != nullptr): tid2col then maps transition-id -> pdf id
+  const float *feats = nullptr; int32_t D = 0; const float *gconsts = nullptr, *means_invvars = nullptr, *inv_vars = nullptr;
+  const int32_t *pdf_offsets = nullptr;
+  mutable std::vector<float> cache, x2, ll; mutable std::vector<int32_t> hit; mutable int x2_frame = -1; mutable int64_t evals = 0;
+  void InitLazy(int32_t num_pdfs) { cache.assign(num_pdfs, 0.0f); hit.assign(num_pdfs, -1); x2.resize(D); }
+  inline float LogLikelihood(int frame, int tid) const {
+    if (!feats) return scale * loglikes[(size_t)frame * ncols + tid2col[tid]];
+    int p = tid2col[tid];
+    if (hit[p] == frame) return scale * cache[p];
+    const float *x = feats + (size_t)frame * D;
+    if (x2_frame != frame) { for (int d = 0; d < D; d++) x2[d] = x[d] * x[d]; x2_frame = frame; }
+    int g0 = pdf_offsets[p], g1 = pdf_offsets[p + 1];
+    ll.resize(g1 - g0);
+    for (int g = g0; g < g1; g++)
+      ll[g - g0] = gauss_ll(x, x2.data(), D, gconsts[g], means_invvars + (size_t)g * D, inv_vars + (size_t)g * D);
+    float v = log_sum_exp(ll.data(), g1 - g0);
+    cache[p] = v; hit[p] = frame; evals++;
+    return scale * v;
+  }
 };
 
 struct FasterDecoder {
@@ -679,13 +702,9 @@ struct FasterDecoder {
 
 // arcs' weights must already include the scaled transition log-probs (orc_add_transition_probs).
 // status: 0 ok first beam, 1 ok after retry, 2 failed.  like = -(graph+ac)/acoustic_scale.
-ORC_API int32_t orc_align(int32_t num_states, int32_t start, const int64_t *arc_off, const orc_arc *arcs, const float *final_w,
-                          const float *loglikes, int32_t T, int32_t ncols, const int32_t *tid2col, float acoustic_scale,
-                          float beam, float retry_beam, int32_t *ali /*[T]*/, int32_t *words /*[cap_words]*/, int32_t cap_words,
-                          int32_t *n_words, float *like, float *per_frame_loglike /*[T] or NULL*/, int64_t *stats /*[2] or NULL*/) {
-  if (start < 0 || num_states == 0) return 2;
-  Graph g{num_states, start, arc_off, arcs, final_w};
-  Decodable dec{loglikes, T, ncols, tid2col, acoustic_scale};
+static int32_t align_with(const Graph &g, const Decodable &dec, int32_t T, float acoustic_scale, float beam, float retry_beam,
+                          int32_t *ali, int32_t *words, int32_t cap_words, int32_t *n_words, float *like,
+                          float *per_frame_loglike, int64_t *stats) {
   FasterDecoder d(g, beam, std::numeric_limits<int32_t>::max(), 20, 0.5f, 2.0f);
   d.Decode(dec);
   bool ans = d.ReachedFinal(); int status = 0;
@@ -701,6 +720,36 @@ ORC_API int32_t orc_align(int32_t num_states, int32_t start, const int64_t *arc_
   *like = -(gc + ac) / acoustic_scale;
   if (per_frame_loglike) for (int t = 0; t < T; t++) per_frame_loglike[t] = pf[t] * (-1.0f / acoustic_scale);
   return status;
+}
+
+ORC_API int32_t orc_align(int32_t num_states, int32_t start, const int64_t *arc_off, const orc_arc *arcs, const float *final_w,
+                          const float *loglikes, int32_t T, int32_t ncols, const int32_t *tid2col, float acoustic_scale,
+                          float beam, float retry_beam, int32_t *ali /*[T]*/, int32_t *words /*[cap_words]*/, int32_t cap_words,
+                          int32_t *n_words, float *like, float *per_frame_loglike /*[T] or NULL*/, int64_t *stats /*[2] or NULL*/) {
+  if (start < 0 || num_states == 0) return 2;
+  Graph g{num_states, start, arc_off, arcs, final_w};
+  Decodable dec{loglikes, T, ncols, tid2col, acoustic_scale};
+  return align_with(g, dec, T, acoustic_scale, beam, retry_beam, ali, words, cap_words, n_words, like, per_frame_loglike, stats);
+}
+
+// The same alignment with Kaldi's LAZY decodable: features and the acoustic model in, a (frame, pdf) log-likelihood
+// computed when a live token's arc first asks for it — GmmAligner.align_utterance(fst, feats) as the reference runs it
+// (MFA/alignment/multiprocessing.py:846-853).  tid2pdf[tid] = pdf id of a transition-id.  stats[2] (when given) receives
+// the number of (frame, pdf) cells evaluated, both beams included.  Results equal orc_gmm_loglikes + orc_align bit for bit.
+ORC_API int32_t orc_align_feats(int32_t num_states, int32_t start, const int64_t *arc_off, const orc_arc *arcs,
+                                const float *final_w, const float *feats, int32_t T, int32_t D, const float *gconsts,
+                                const float *means_invvars, const float *inv_vars, const int32_t *pdf_offsets, int32_t num_pdfs,
+                                const int32_t *tid2pdf, float acoustic_scale, float beam, float retry_beam, int32_t *ali,
+                                int32_t *words, int32_t cap_words, int32_t *n_words, float *like, float *per_frame_loglike,
+                                int64_t *stats /*[3] or NULL*/) {
+  if (start < 0 || num_states == 0) return 2;
+  Graph g{num_states, start, arc_off, arcs, final_w};
+  Decodable dec{nullptr, T, 0, tid2pdf, acoustic_scale};
+  dec.feats = feats; dec.D = D; dec.gconsts = gconsts; dec.means_invvars = means_invvars; dec.inv_vars = inv_vars;
+  dec.pdf_offsets = pdf_offsets; dec.InitLazy(num_pdfs);
+  int32_t st = align_with(g, dec, T, acoustic_scale, beam, retry_beam, ali, words, cap_words, n_words, like, per_frame_loglike, stats);
+  if (stats) stats[2] = dec.evals;
+  return st;
 }
 
 // AddTransitionProbs: arc.weight = Times(arc.weight, -scaled[tid]) for ilabel in [1, n_ids].

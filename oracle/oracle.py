@@ -212,6 +212,38 @@ def align(num_states, start, arc_offsets, arcs, final, loglikes, tid2col, acoust
     return out
 
 
+def align_feats(num_states, start, arc_offsets, arcs, final, feats, gconsts, means_invvars, inv_vars, pdf_offsets, tid2pdf,
+                acoustic_scale, beam, retry_beam):
+    """The alignment with Kaldi's LAZY decodable (orc_align_feats): features + acoustic model in; a (frame, pdf) score is
+    computed when a live token's arc first asks for it.  Same results as gmm_loglikes + align; also returns ``cells`` = the
+    number of (frame, pdf) scores evaluated.  ``tid2pdf``: pdf id per transition-id (entry 0 unused)."""
+    arc_offsets = np.ascontiguousarray(arc_offsets, np.int64)
+    arcs = np.ascontiguousarray(arcs.astype(ARC_DTYPE))
+    final = np.ascontiguousarray(final, np.float32)
+    feats = np.ascontiguousarray(feats, np.float32)
+    gconsts = np.ascontiguousarray(gconsts, np.float32)
+    means_invvars = np.ascontiguousarray(means_invvars, np.float32)
+    inv_vars = np.ascontiguousarray(inv_vars, np.float32)
+    pdf_offsets = np.ascontiguousarray(pdf_offsets, np.int32)
+    tid2pdf = np.ascontiguousarray(np.maximum(tid2pdf, 0), np.int32)
+    T, D = feats.shape
+    ali = np.zeros(T, np.int32)
+    cap_words = T + 16
+    words = np.zeros(cap_words, np.int32)
+    n_words = C.c_int32(0)
+    like = C.c_float(0)
+    pf = np.zeros(T, np.float32)
+    stats = np.zeros(3, np.int64)
+    fn = lib().orc_align_feats
+    fn.restype = C.c_int32
+    st = fn(C.c_int32(num_states), C.c_int32(start), _p(arc_offsets), _p(arcs), _p(final), _p(feats), C.c_int32(T), C.c_int32(D),
+            _p(gconsts), _p(means_invvars), _p(inv_vars), _p(pdf_offsets), C.c_int32(pdf_offsets.shape[0] - 1), _p(tid2pdf),
+            C.c_float(acoustic_scale), C.c_float(beam), C.c_float(retry_beam), _p(ali), _p(words), C.c_int32(cap_words),
+            C.byref(n_words), C.byref(like), _p(pf), _p(stats))
+    return dict(status=int(st), ali=ali, words=words[: n_words.value].copy(), like=float(like.value), per_frame=pf,
+                max_toks=int(stats[0]), sum_toks=int(stats[1]), cells=int(stats[2]))
+
+
 def split_to_phones(ali, id2state, is_self_loop, is_final, tuples):
     ali = np.ascontiguousarray(ali, np.int32)
     T = ali.shape[0]

@@ -218,14 +218,13 @@ def _gauss(mean, var, weight=1.0):
     return np.float32(gc), (mean * inv).astype(np.float32), inv.astype(np.float32)
 
 
-def train_monophone(world: SynthWorld, feature_fn: Callable[[np.ndarray, int], np.ndarray], n_train: int = 200,
-                    first_index: int = 1_000_000) -> SynthModel:
-    """BASELINE config 2: 3-state Bakis per phone + 5-state silence topology, 1 Gaussian per state, D = 39."""
-    pt = world.lexicon.phone_table
+def monophone_from_stats(lexicon: G.LexiconCompiler, stats: Dict[Tuple[int, int], List], silence_names=("sil", "spn")) -> SynthModel:
+    """3-state Bakis per phone + 5-state silence topology, one Gaussian per state from Σx, Σx², n per (phone id, state)
+    (variance floor 0.01; states with fewer than 5 frames take the global mean and variance)."""
+    pt = lexicon.phone_table
     ids = [k for k, s in pt if s != "<eps>"]
-    sil_ids = [pt.find("sil"), pt.find("spn")]
+    sil_ids = [pt.find(s) for s in silence_names if pt.find(s) != -1]
     topo = _topology(max(ids), sil_ids)
-    stats = _accumulate(world, feature_fn, n_train, first_index)
     dim = next(iter(stats.values()))[0].shape[0]
     glob = [sum(s[0] for s in stats.values()), sum(s[1] for s in stats.values()), sum(s[2] for s in stats.values())]
     gmean = glob[0] / glob[2]
@@ -255,6 +254,12 @@ def train_monophone(world: SynthWorld, feature_fn: Callable[[np.ndarray, int], n
                         np.asarray(offs, dtype=np.int32))
     tree = K.ContextDependency(1, 0, K.EventMap("TE", key=0, table=table))
     return SynthModel(M.TransitionModel(raw), am, tree)
+
+
+def train_monophone(world: SynthWorld, feature_fn: Callable[[np.ndarray, int], np.ndarray], n_train: int = 200,
+                    first_index: int = 1_000_000) -> SynthModel:
+    """BASELINE config 2: 3-state Bakis per phone + 5-state silence topology, 1 Gaussian per state, D = 39."""
+    return monophone_from_stats(world.lexicon, _accumulate(world, feature_fn, n_train, first_index))
 
 
 def seeded_lda(seed: int = SEED) -> np.ndarray:

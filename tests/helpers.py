@@ -59,6 +59,12 @@ def oracle_align(tm, fst, loglikes, pdf_list, acoustic_scale=0.1, beam=10.0, ret
                    beam, retry_beam, want_stats=want_stats)
 
 
+def oracle_align_feats(tm, fst, feats, am, acoustic_scale=0.1, beam=10.0, retry_beam=40.0):
+    """The oracle with Kaldi's lazy decodable (features + model in, scores on demand): what GmmAligner.align_utterance runs."""
+    return O.align_feats(fst.num_states, fst.start, fst.arc_offsets, fst.arcs, fst.final, feats, am.gconsts, am.means_invvars,
+                         am.inv_vars, am.pdf_offsets, tm.id2pdf, acoustic_scale, beam, retry_beam)
+
+
 def random_gmm(rng, dim, gauss_per_pdf):
     """Seeded diagonal GMM with the given number of Gaussians per pdf (Kaldi gconst convention)."""
     gconsts, mi, iv, offs = [], [], [], [0]

@@ -182,3 +182,36 @@ def test_frame_times_are_pythons_rounding():
     for shift in (0.01, 0.0125, 0.005, 0.02, 0.010001, 0.0100001, 1.0 / 3.0):
         want = [round(int(f) * shift, 6) for f in frames]
         assert C._frame_times(frames, shift) == want, shift
+
+
+def test_interval_stage_failure_concerns_one_utterance_only(fx, monkeypatch):
+    """The reference catches per utterance in its extraction loop (MFA/alignment/multiprocessing.py:1739-1770): an
+    alignment whose word ids cannot be spelt must not take the other utterances' results with it."""
+    from montreal_forced_aligner_amd.aligner import CorpusAligner, CorpusUtterance
+
+    class StubEngine:            # the interval stage is host code: no device needed
+        device = "cpu"
+
+        def configure_mfcc(self, **kw):
+            pass
+
+        def load_gmm(self, am):
+            pass
+
+    tm = fx.mono_tm
+    text = "this is the acoustic corpus"
+    f = fx.mono_graph(text)
+    pdfs = np.arange(tm.num_pdfs, dtype=np.int32)
+    ll = np.random.default_rng(3).normal(-60.0, 10.0, size=(200, tm.num_pdfs)).astype(np.float32)
+    r = helpers.oracle_align(tm, f, ll, pdfs, beam=1e4, retry_beam=0.0)
+    good = dict(ali=r["ali"], words=r["words"], like=r["like"], frames=200)
+    bad = dict(good, words=r["words"][::-1].copy())                   # same phones, word ids that do not spell them
+    al = CorpusAligner(tm, fx.mono_am, fx.mono_tree, fx.mono_lex, engine=StubEngine())
+    monkeypatch.setattr(al, "speaker_cmvn", lambda utts: ({"s": 0}, None))
+    monkeypatch.setattr(al, "_pass", lambda utts, spk_ids, cmvn, fmllr, want_feats=False: ([good, bad, good], []))
+    pcm = np.zeros(32000, dtype=np.int16)
+    res = al.align([CorpusUtterance(f"s-{k}", "s", pcm, text) for k in range(3)])
+    assert [x is not None for x in res] == [True, True, True] and al.failed == []
+    assert res[0].ctm is not None and res[2].ctm is not None and res[1].ctm is None
+    assert al.ctm_failed == ["s-1"] and "interval extraction failed" in al.failure_reasons["s-1"]
+    assert np.array_equal(res[1].alignment, r["ali"])                 # the alignment itself is kept

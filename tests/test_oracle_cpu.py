@@ -210,6 +210,50 @@ def test_real_audio_plumbing_with_reference_test_beams(fx):
     assert words == expect
 
 
+def test_lazy_decodable_equals_dense_scores_then_decode(fx):
+    """orc_align_feats evaluates a (frame, pdf) score when a live token's arc first asks for it (Kaldi's
+    DecodableAmDiagGmmUnmapped cache); everything it returns must equal scoring the whole matrix first — on the mixture
+    model of the reference's g2p fixture and on the monophone fixture, first beam, retry beam and failure alike — and it
+    must touch far fewer cells than the matrix holds."""
+    rng = np.random.default_rng(11)
+    tm, am = fx.mono_tm, fx.mono_am
+    seg = fx.pcm[: 16000 * 5]
+    x = fx.mono_feats(seg)
+    f = fx.mono_graph("this is the acoustic corpus i'm talking pretty fast here")
+    pdfs = np.arange(am.num_pdfs, dtype=np.int32)
+    ll = O.gmm_loglikes(x, am.gconsts, am.means_invvars, am.inv_vars, am.pdf_offsets, pdfs)
+    for beam, retry in ((100.0, 400.0), (10.0, 400.0), (2.0, 8.0)):
+        dense = helpers.oracle_align(tm, f, ll, pdfs, beam=beam, retry_beam=retry)
+        lazy = helpers.oracle_align_feats(tm, f, x, am, beam=beam, retry_beam=retry)
+        assert lazy["status"] == dense["status"]
+        if dense["status"] in (0, 1):
+            assert np.array_equal(lazy["ali"], dense["ali"]) and np.array_equal(lazy["words"], dense["words"])
+            assert lazy["like"] == dense["like"] and np.array_equal(lazy["per_frame"], dense["per_frame"])
+        assert 0 < lazy["cells"] < (2 if dense["status"] else 1) * ll.size
+    # mixtures (1..26 Gaussians per pdf) in a 40-dim space, random features
+    tm2, am2 = fx.g2p_tm, fx.g2p_am
+    x2 = rng.normal(0, 1.0, size=(120, am2.dim)).astype(np.float32)
+    # a left-to-right chain over the model's first phones' transition-ids is enough to drive the decodable
+    from montreal_forced_aligner_amd import kaldi_io as K
+    fwd = [t for t in range(1, tm2.num_transition_ids + 1) if not tm2.is_self_loop[t]][:40]
+    arcs, offs = [], [0]
+    for s, t in enumerate(fwd):
+        loops = [u for u in range(1, tm2.num_transition_ids + 1) if tm2.is_self_loop[u] and tm2.id2state[u] == tm2.id2state[t]]
+        for u in loops[:1]:
+            arcs.append((u, 0, 0.1, s))
+        arcs.append((t, 0, 0.2, s + 1))
+        offs.append(len(arcs))
+    offs.append(len(arcs))          # the last state: final, no arcs
+    fst = K.Fst(0, np.asarray(offs, np.int64), np.asarray(arcs, dtype=O.ARC_DTYPE),
+                np.asarray([np.inf] * len(fwd) + [0.0], np.float32))
+    pdfs2 = np.arange(am2.num_pdfs, dtype=np.int32)
+    ll2 = O.gmm_loglikes(x2, am2.gconsts, am2.means_invvars, am2.inv_vars, am2.pdf_offsets, pdfs2)
+    d2 = helpers.oracle_align(tm2, fst, ll2, pdfs2, beam=50.0, retry_beam=5000.0)
+    l2 = helpers.oracle_align_feats(tm2, fst, x2, am2, beam=50.0, retry_beam=5000.0)
+    assert d2["status"] == l2["status"] and d2["status"] in (0, 1)
+    assert np.array_equal(d2["ali"], l2["ali"]) and d2["like"] == l2["like"]
+
+
 def test_parallel_formulation_of_the_decoder_matches_sequential_oracle(fx):
     """tests/viterbi_emul.py restates the GPU kernel's data-parallel formulation (prefix-min cutoff, first-creator
     ordering, bucket order) in numpy; it must reproduce the sequential decoder exactly, including under tight beams,
