@@ -71,6 +71,35 @@ MFA_GC_API int mfa_gc_add_windows(mfa_gc *gc, int32_t n, const int32_t *windows,
 MFA_GC_API int64_t mfa_gc_prepare(mfa_gc *gc, int32_t n_utt, const int64_t *word_off, const int32_t *entries, int32_t n_threads);
 MFA_GC_API int mfa_gc_missing_windows(mfa_gc *gc, int32_t *windows /* [missing][context_width] */);
 
+/* The context-dependency tree (Kaldi ContextDependency / EventMap), the HMM topology and the
+ * transition-state table, flattened, so that the HMM of a context window is worked out HERE instead of by a callback into
+ * the host for every window not seen before (a 5k-leaf triphone model meets ~10^5 distinct windows in a batch of 4 096
+ * transcripts).  Optional: without it every window goes through mfa_gc_missing_windows / mfa_gc_add_windows.
+ * Tree nodes: kind 0 = CE (answer), 1 = TE (key, children table[a .. a + b), -1 = NULL), 2 = SE (key, yes-set
+ * yes_vals[yes_off[i] .. yes_off[i + 1]) sorted ascending, child a when the value is in it, else child b); event keys 0 ..
+ * width - 1 are the window's phones, key -1 the pdf-class.
+ * Topology: phone2entry[phone] (-1 = none) for phone <= max_phone; entry e has HMM states entry_state_off[e] ..
+ * entry_state_off[e + 1]; state s: forward / self-loop pdf-class, transitions trans_off[s] .. trans_off[s + 1] with
+ * destinations trans_dst (relative to the entry's first state).  tuples [n_tuples][4] = (phone, hmm state, forward pdf,
+ * self-loop pdf) of transition-state 1 .. n_tuples; state2id [n_tuples + 2] first transition-id of a transition-state. */
+typedef struct {
+  int32_t n_nodes, root;
+  const int32_t *kind, *key, *answer, *a, *b, *yes_off;
+  const int32_t *table, *yes_vals;
+  int32_t max_phone;
+  const int32_t *phone2entry;
+  int32_t n_entries;
+  const int32_t *entry_state_off;
+  const int32_t *fwd_class, *slf_class, *trans_off, *trans_dst;
+  int32_t n_tuples;
+  const int32_t *tuples;
+  const int32_t *state2id;
+} mfa_gc_model;
+MFA_GC_API int mfa_gc_set_model(mfa_gc *gc, const mfa_gc_model *model);
+/* After mfa_gc_prepare: works out the HMMs of the missing windows from the model given to mfa_gc_set_model; returns how many
+ * are still missing (those the tree or the tuple table has no answer for — the host's code raises its error for them). */
+MFA_GC_API int64_t mfa_gc_resolve_windows(mfa_gc *gc);
+
 /* Phase 2: HMM expansion.  neg_scaled_log_probs (float32 [n_tids + 1], may be NULL): Kaldi AddTransitionProbs applied
  * to the result (weight ← weight + table[tid] in float32 for tid > 0), as graph.add_transition_probs does.
  * Totals of the batch go to n_states / n_arcs. */
@@ -80,6 +109,13 @@ MFA_GC_API int mfa_gc_finish(mfa_gc *gc, const float *neg_scaled_log_probs, int3
  * offsets relative to its first arc), arcs as {ilabel, olabel, weight, nextstate} records of 16 bytes, final [n_states]
  * (+inf = not final).  Start state of every graph is 0. */
 MFA_GC_API int mfa_gc_fetch(mfa_gc *gc, int64_t *state_off, int64_t *arc_base, int64_t *arc_off, void *arcs, float *final_w);
+/* The same copy by n_threads host threads, plus the columns the score-plan builder (mfa_build_score_plans_batch) and the
+ * device layout read, so that no pass over the arcs is left to the host language: arc_off32 [n_states + n_utt] (int32 copy
+ * of arc_off), arc_next [n_arcs] (next state), arc_pdf [n_arcs] = id2pdf[ilabel] (id2pdf [n_tids + 1], entry 0 unused; NULL:
+ * arc_pdf is not written).  Any output pointer may be NULL.  The batch stays fetchable until the next mfa_gc_prepare. */
+MFA_GC_API int mfa_gc_fetch_columns(mfa_gc *gc, const int32_t *id2pdf, int32_t n_threads, int64_t *state_off, int64_t *arc_base,
+                                    int64_t *arc_off, int32_t *arc_off32, void *arcs, float *final_w, int32_t *arc_next,
+                                    int32_t *arc_pdf);
 
 #ifdef __cplusplus
 }

@@ -79,6 +79,13 @@ MFA_API int32_t mfa_mfcc_num_frames(mfa_ctx *ctx, int64_t num_samples);
 MFA_API int mfa_mfcc_batch(mfa_ctx *ctx, const int16_t *d_pcm, const int64_t *d_sample_off, const int64_t *d_frame_off,
                            int32_t n_utt, int32_t max_frames, float *d_mfcc);
 
+/* Host helper for the call above: utterance u's samples h_src[u][0 .. h_sample_off[u+1] - h_sample_off[u]) copied to
+ * h_dst + h_sample_off[u] by n_threads host threads (<= 0: hardware concurrency).  h_dst is the caller's staging buffer
+ * (pinned memory, followed by ONE asynchronous host-to-device copy): the reference hands kalpy one Segment per utterance
+ * (MFA/corpus/features.py:223-235); a batch of 4 096 ten-second utterances is 1.3 GB of samples. */
+MFA_API int mfa_gather_pcm(int32_t n_utt, const int16_t *const *h_src, const int64_t *h_sample_off, int16_t *h_dst,
+                           int32_t n_threads);
+
 /* ---- CMVN statistics: replaces CmvnComputer().compute_cmvn_from_features / export_cmvn
  *      (MFA/corpus/acoustic_corpus.py:1315-1367; MFA/online/alignment.py:86-88).
  * d_spk_utt_off[n_spk+1] / d_spk_utt[…]: utterances of each speaker; d_stats: float64 [n_spk][2][dim+1]

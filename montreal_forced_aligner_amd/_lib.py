@@ -91,6 +91,7 @@ SIGNATURES = {
     "mfa_mfcc_configure": (C.c_int, [_vp, C.POINTER(MfccOpts)]),
     "mfa_mfcc_num_frames": (_i32, [_vp, _i64]),
     "mfa_mfcc_batch": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp]),
+    "mfa_gather_pcm": (C.c_int, [_i32, _vp, _vp, _vp, _i32]),
     "mfa_cmvn_stats": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp]),
     "mfa_feats_batch": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp]),
     "mfa_load_gmm": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp]),

@@ -38,19 +38,46 @@ class CorpusUtterance:
     file_duration: Optional[float] = None
 
 
-@dataclass
 class UtteranceResult:
-    utt_id: str
-    speaker: str
-    alignment: np.ndarray           # transition-ids, one per frame
-    words: np.ndarray
-    likelihood: float               # total; MFA reports likelihood / num_frames (mixins.py:351-357)
-    num_frames: int
-    ctm: Optional[_ctm.HierarchicalCtm] = None
+    """One aligned utterance.  ``alignment`` / ``words`` are views of the batch arrays the device handed back; ``ctm`` — the
+    ``HierarchicalCtm`` of MFA/alignment/multiprocessing.py:1733-1751 — is built from the batch's interval arrays the first
+    time it is asked for (``CorpusAligner.export_textgrids`` writes files from the arrays and never asks)."""
+
+    __slots__ = ("utt_id", "speaker", "alignment", "words", "likelihood", "num_frames", "_ctm", "_lazy")
+
+    def __init__(self, utt_id: str, speaker: str, alignment: np.ndarray, words: np.ndarray, likelihood: float, num_frames: int,
+                 ctm: Optional[_ctm.HierarchicalCtm] = None):
+        self.utt_id, self.speaker, self.alignment, self.words = utt_id, speaker, alignment, words
+        self.likelihood, self.num_frames = likelihood, num_frames          # total; MFA reports likelihood / num_frames
+        self._ctm = ctm
+        self._lazy = None            # (IntervalBatch, index, text, begin, end) until the objects are wanted
 
     @property
     def per_frame_likelihood(self) -> float:
         return self.likelihood / max(1, self.num_frames)
+
+    @property
+    def ctm(self) -> Optional[_ctm.HierarchicalCtm]:
+        if self._ctm is None and self._lazy is not None:
+            batch, k, text, begin, end = self._lazy
+            self._ctm = batch.ctm(k, text=text, begin=begin, end=end, likelihood=self.per_frame_likelihood)
+            self._lazy = None
+        return self._ctm
+
+    @ctm.setter
+    def ctm(self, value) -> None:
+        self._ctm, self._lazy = value, None
+
+    @property
+    def has_intervals(self) -> bool:
+        return self._ctm is not None or self._lazy is not None
+
+    def __getstate__(self):          # (rank-to-rank gather: the objects travel, not the batch arrays they would be built from)
+        return (self.utt_id, self.speaker, np.array(self.alignment), np.array(self.words), self.likelihood, self.num_frames, self.ctm)
+
+    def __setstate__(self, st):
+        self.utt_id, self.speaker, self.alignment, self.words, self.likelihood, self.num_frames, self._ctm = st
+        self._lazy = None
 
 
 @dataclass
@@ -72,6 +99,18 @@ class AlignOptions:
     corpus_compression: bool = False
     # raw MFCCs of a run stay on the device between the CMVN pass and the alignment passes up to this many bytes
     mfcc_cache_bytes: int = 64 << 30
+
+
+class _BatchOut:
+    """What the device handed back for one batch, on the host: ragged arrays in the device layout (utterance k of the batch
+    at frame_off[k]; its word ids packed at the same offset)."""
+
+    __slots__ = ("idx", "frame_off", "ali", "words", "n_words", "like", "status", "intervals")
+
+    def __init__(self, idx, frame_off, ali, words, n_words, like, status):
+        self.idx, self.frame_off, self.ali, self.words = list(idx), np.asarray(frame_off, dtype=np.int64), ali, words
+        self.n_words, self.like, self.status = n_words, like, status
+        self.intervals = None          # intervals_native.IntervalBatch once extracted
 
 
 class CorpusAligner:
@@ -114,8 +153,7 @@ class CorpusAligner:
         self._mfcc_cache: Dict[tuple, tuple] = {}
         self._mfcc_cache_bytes = 0
         self._mfcc_cache_on = False
-        self._pcm_stage = None
-        self._pcm_stage_free = None
+        self._intervals = None          # intervals_native.IntervalExtractor, built on first use
 
     def _boosted(self, am: DiagGmmModel) -> DiagGmmModel:
         import copy
@@ -156,22 +194,8 @@ class CorpusAligner:
         hit = self._mfcc_cache.get(key) if self._mfcc_cache_on else None
         if hit is not None:          # the CMVN pass computed them already (and a second alignment pass asks a third time)
             return hit
-        so = np.concatenate([[0], np.cumsum([len(utts[i].pcm) for i in idx])]).astype(np.int64)
-        total = int(so[-1])
-        # PCM gathered straight into a pinned staging buffer (one pass over the samples), then one asynchronous H2D copy
-        if self._pcm_stage is None or self._pcm_stage.shape[0] < total:
-            self._pcm_stage = torch.empty(max(total, 1), dtype=torch.int16).pin_memory()
-            self._pcm_stage_free = None
-        if self._pcm_stage_free is not None:
-            self._pcm_stage_free.synchronize()          # the previous batch's copy has left the buffer
-        if total:
-            np.concatenate([np.asarray(utts[i].pcm, dtype=np.int16) for i in idx], out=self._pcm_stage.numpy()[:total])
-        # the copy and the event that guards the staging buffer go on the ENGINE's stream (the current device of the process
-        # may be another one: align_sharded creates CorpusAligner(device=rank) without torch.cuda.set_device)
-        with torch.cuda.device(self.engine.device):
-            pcm = self._pcm_stage[:total].to(self.engine.device, non_blocking=True)
-            self._pcm_stage_free = torch.cuda.Event()
-            self._pcm_stage_free.record(torch.cuda.current_stream(self.engine.device))
+        # PCM gathered by host threads straight into pinned staging memory, then one asynchronous H2D copy (mfa_gather_pcm)
+        pcm, so = self.engine.gather_pcm([utts[i].pcm for i in idx])
         mfcc, fo = self.engine.mfcc(pcm, so)
         if self.opt.corpus_compression:      # feats.*.ark of MfccFunction: compute_mfccs_for_export(seg, compress=True)
             from . import kaldi_io as _kio
@@ -234,104 +258,142 @@ class CorpusAligner:
         return eng.align(graphs, ll, ll_off, ll_cols, fo, beam=o.beam, retry_beam=o.retry_beam, acoustic_scale=o.acoustic_scale,
                          max_tokens=max_tokens, bp_tokens_per_frame=bp_tokens)
 
-    def _pass(self, utts, spk_ids, cmvn, fmllr, want_feats=False):
-        """One alignment pass over all batches.  Returns per-utterance dicts (None where alignment failed) and, when
-        asked, what fMLLR estimation needs (features, alignments, frame offsets per batch).  Nothing an individual
-        utterance does aborts the pass: unsupported graphs and decoder statuses beyond "failed" are recorded in
-        ``failure_reasons`` (the reference logs and continues, MFA/alignment/mixins.py:308-314)."""
-        import torch
-
-        eng, o = self.engine, self.opt
-        d_lda = None if self.lda is None else torch.from_numpy(self.lda).to(eng.device)
-        results: List[Optional[dict]] = [None] * len(utts)
-        kept = []
-        for idx_all in self._batches(utts):
-            fsts_all = self.compiler.compile_fsts([utts[i].text for i in idx_all], self.scaled)   # native, batched
-            idx, fsts, gidx, gfsts = [], [], [], []
-            whole = getattr(fsts_all, "arcs", None)
-            if whole is not None and len(fsts_all) and whole.shape[0] and int(whole["ilabel"].min()) > 0 \
-                    and int(np.diff(fsts_all.arc_off).max()) <= 64 and int(np.diff(fsts_all.arc_base).min()) > 0:
-                # a batch straight from the native compiler with nothing for the general decoder in it: taken as it is
-                idx, fsts, fsts_all = list(idx_all), fsts_all, []
+    # ------------------------------------------------------------------ one alignment pass, batch by batch
+    def _prepare(self, utts, idx_all):
+        """Host side of a batch, no device results needed: transcripts → training graphs (native, threaded, straight into the
+        batch's pinned staging buffers) → device layout + score plan.  Called for batch b + 1 while the device works on b."""
+        eng = self.engine
+        pool = eng.next_staging()
+        fsts_all = self.compiler.compile_fsts([utts[i].text for i in idx_all], self.scaled, columns=True, alloc=pool.get)
+        prep = dict(idx_all=list(idx_all), idx=[], fsts=[], gidx=[], gfsts=[], graphs=None)
+        pdf = getattr(fsts_all, "arc_pdf", None)
+        if pdf is not None and len(fsts_all) and pdf.shape[0] and int(pdf.min()) >= 0 \
+                and int(np.diff(fsts_all.arc_off32).max()) <= 64 and int(np.diff(fsts_all.arc_base).min()) > 0:
+            # a batch straight from the native compiler with nothing for the general decoder in it: taken as it is
+            prep["idx"], prep["fsts"] = list(idx_all), fsts_all
+        else:
             for i, f in zip(idx_all, fsts_all):
                 if f.num_arcs == 0 or f.num_states == 0 or np.any(f.arcs["ilabel"] < 0):
                     self.failure_reasons[utts[i].utt_id] = "empty or malformed training graph"   # this utterance only
                 elif eng.needs_general_decoder(f):    # epsilon input arcs / a state with more than 64 arcs
-                    gidx.append(i); gfsts.append(f)
+                    prep["gidx"].append(i); prep["gfsts"].append(f)
                 else:
-                    idx.append(i); fsts.append(f)
-            if gidx:
-                # FasterDecoder as Kaldi runs it, ProcessNonemitting included (mfa_align_general_batch): the slow, exact path
-                mfcc, fo = self._mfcc(utts, gidx)
-                rows = np.array([spk_ids[utts[i].speaker] for i in gidx], dtype=np.int32)
-                feats = self._final_features(mfcc, fo, rows, cmvn, d_lda, fmllr)
-                gg = eng.pack_graphs_general(gfsts, self.tm)
-                rg = eng.align_general(gg, feats, fo, beam=o.beam, retry_beam=o.retry_beam, acoustic_scale=o.acoustic_scale,
-                                       bp_tokens_per_frame=max(o.bp_tokens_per_frame, 512))
-                st_g, ali_g, w_g = rg["status"].cpu().numpy(), rg["ali"].cpu().numpy(), rg["words"].cpu().numpy()
-                nw_g, like_g = rg["n_words"].cpu().numpy(), rg["like"].cpu().numpy()
-                for k, i in enumerate(gidx):
-                    a, b = int(fo[k]), int(fo[k + 1])
-                    if st_g[k] in (0, 1):
-                        results[i] = dict(ali=ali_g[a:b].copy(), words=w_g[a: a + int(nw_g[k])].copy(), like=float(like_g[k]), frames=b - a)
-                    else:
-                        self.failure_reasons[utts[i].utt_id] = ("no alignment within the retry beam" if st_g[k] == 2 else
-                                                               f"general decoder status {int(st_g[k])} (include/mfa_hip.h)")
-                if want_feats:
-                    ali_dev = rg["ali"].clone()
-                    for k in range(len(gidx)):
-                        if st_g[k] not in (0, 1):
-                            ali_dev[int(fo[k]): int(fo[k + 1])] = 0
-                    kept.append((gidx, feats, ali_dev, fo, rows))
-            if not idx:
-                continue
-            mfcc, fo = self._mfcc(utts, idx)
-            rows = np.array([spk_ids[utts[i].speaker] for i in idx], dtype=np.int32)
-            feats = self._final_features(mfcc, fo, rows, cmvn, d_lda, fmllr)
-            graphs = eng.pack_graphs(fsts, self.tm)
-            res = self._decode(graphs, feats, fo, o.max_tokens, o.bp_tokens_per_frame)
-            status = res["status"].cpu().numpy()
-            ali, words = res["ali"].cpu().numpy(), res["words"].cpu().numpy()
-            n_words, like = res["n_words"].cpu().numpy(), res["like"].cpu().numpy()
-            # Capacity overflows (status 3 tokens / 4 back-pointers) are not alignment failures: those utterances are decoded
-            # again on their own with the hard upper bounds (one token per graph state), which cannot overflow.
-            over = [k for k in range(len(idx)) if status[k] in (3, 4)]
-            if over:
-                sub = eng.pack_graphs([fsts[k] for k in over], self.tm)
-                fo2 = np.concatenate([[0], np.cumsum([fo[k + 1] - fo[k] for k in over])]).astype(np.int64)
-                sel = np.concatenate([np.arange(fo[k], fo[k + 1]) for k in over])
-                f2 = eng.gather_rows(feats, sel)
-                r2 = self._decode(sub, f2, fo2, sub.max_states, sub.max_states)
-                st2, ali2, w2 = r2["status"].cpu().numpy(), r2["ali"].cpu().numpy(), r2["words"].cpu().numpy()
-                nw2, like2 = r2["n_words"].cpu().numpy(), r2["like"].cpu().numpy()
-                ali, words = ali.copy(), words.copy()
-                for j, k in enumerate(over):
-                    status[k] = st2[j]
-                    a, b = int(fo[k]), int(fo[k + 1])
-                    ali[a:b] = ali2[fo2[j]: fo2[j + 1]]
-                    n_words[k] = nw2[j]
-                    words[a: a + int(nw2[j])] = w2[fo2[j]: fo2[j] + int(nw2[j])]
-                    like[k] = like2[j]
-                if want_feats:
-                    res["ali"] = torch.from_numpy(ali).to(eng.device)
-            for k, i in enumerate(idx):
+                    prep["idx"].append(i); prep["fsts"].append(f)
+        if prep["idx"]:
+            prep["graphs"] = eng.pack_graphs(prep["fsts"], self.tm, pool=pool if prep["fsts"] is fsts_all else None)
+        return prep
+
+    def _launch(self, utts, prep, spk_ids, cmvn, d_lda, fmllr):
+        """Device side of a batch: features and the alignment call for the utterances the wavefront-parallel decoder takes —
+        enqueued, not waited for."""
+        if not prep["idx"]:
+            return None
+        idx = prep["idx"]
+        mfcc, fo = self._mfcc(utts, idx)
+        rows = np.array([spk_ids[utts[i].speaker] for i in idx], dtype=np.int32)
+        feats = self._final_features(mfcc, fo, rows, cmvn, d_lda, fmllr)
+        res = self._decode(prep["graphs"], feats, fo, self.opt.max_tokens, self.opt.bp_tokens_per_frame)
+        return dict(res=res, feats=feats, fo=fo, rows=rows)
+
+    def _general(self, utts, prep, spk_ids, cmvn, d_lda, fmllr, results, kept, want_feats):
+        """FasterDecoder as Kaldi runs it, ProcessNonemitting included (mfa_align_general_batch): the slow, exact path for
+        graphs with epsilon input arcs or very wide states."""
+        eng, o = self.engine, self.opt
+        gidx, gfsts = prep["gidx"], prep["gfsts"]
+        mfcc, fo = self._mfcc(utts, gidx)
+        rows = np.array([spk_ids[utts[i].speaker] for i in gidx], dtype=np.int32)
+        feats = self._final_features(mfcc, fo, rows, cmvn, d_lda, fmllr)
+        gg = eng.pack_graphs_general(gfsts, self.tm)
+        rg = eng.align_general(gg, feats, fo, beam=o.beam, retry_beam=o.retry_beam, acoustic_scale=o.acoustic_scale,
+                               bp_tokens_per_frame=max(o.bp_tokens_per_frame, 512))
+        out = _BatchOut(gidx, fo, rg["ali"].cpu().numpy(), rg["words"].cpu().numpy(), rg["n_words"].cpu().numpy(),
+                        rg["like"].cpu().numpy(), rg["status"].cpu().numpy())
+        for k, i in enumerate(gidx):
+            if out.status[k] in (0, 1):
+                results[i] = (out, k)
+            else:
+                self.failure_reasons[utts[i].utt_id] = ("no alignment within the retry beam" if out.status[k] == 2 else
+                                                       f"general decoder status {int(out.status[k])} (include/mfa_hip.h)")
+        if want_feats:
+            import torch
+            ali_dev = rg["ali"].clone()
+            for k in range(len(gidx)):
+                if out.status[k] not in (0, 1):
+                    ali_dev[int(fo[k]): int(fo[k + 1])] = 0
+            kept.append((gidx, feats, ali_dev, fo, rows))
+
+    def _collect(self, utts, prep, launched, results, kept, want_feats):
+        """Results of a launched batch back on the host (this is where the host waits for the device)."""
+        import torch
+
+        eng, o = self.engine, self.opt
+        idx, fsts = prep["idx"], prep["fsts"]
+        res, feats, fo, rows = launched["res"], launched["feats"], launched["fo"], launched["rows"]
+        status = res["status"].cpu().numpy()
+        ali, words = res["ali"].cpu().numpy(), res["words"].cpu().numpy()
+        n_words, like = res["n_words"].cpu().numpy(), res["like"].cpu().numpy()
+        # Capacity overflows (status 3 tokens / 4 back-pointers) are not alignment failures: those utterances are decoded
+        # again on their own with the hard upper bounds (one token per graph state), which cannot overflow.
+        over = np.flatnonzero((status == 3) | (status == 4)).tolist()
+        if over:
+            sub = eng.pack_graphs([fsts[k] for k in over], self.tm)
+            fo2 = np.concatenate([[0], np.cumsum([fo[k + 1] - fo[k] for k in over])]).astype(np.int64)
+            sel = np.concatenate([np.arange(fo[k], fo[k + 1]) for k in over])
+            f2 = eng.gather_rows(feats, sel)
+            r2 = self._decode(sub, f2, fo2, sub.max_states, sub.max_states)
+            st2, ali2, w2 = r2["status"].cpu().numpy(), r2["ali"].cpu().numpy(), r2["words"].cpu().numpy()
+            nw2, like2 = r2["n_words"].cpu().numpy(), r2["like"].cpu().numpy()
+            for j, k in enumerate(over):
+                status[k] = st2[j]
                 a, b = int(fo[k]), int(fo[k + 1])
-                if status[k] in (0, 1):
-                    results[i] = dict(ali=ali[a:b].copy(), words=words[a: a + int(n_words[k])].copy(), like=float(like[k]), frames=b - a)
-                elif status[k] == 2:
-                    self.failure_reasons.setdefault(utts[i].utt_id, "no alignment within the retry beam")
-                else:
-                    self.failure_reasons[utts[i].utt_id] = f"device decoder status {int(status[k])} (include/mfa_hip.h)"
+                ali[a:b] = ali2[fo2[j]: fo2[j + 1]]
+                n_words[k] = nw2[j]
+                words[a: a + int(nw2[j])] = w2[fo2[j]: fo2[j] + int(nw2[j])]
+                like[k] = like2[j]
             if want_feats:
-                if over:   # frames of utterances that still failed must not vote in the fMLLR statistics
-                    pass
-                bad = [k for k in range(len(idx)) if status[k] not in (0, 1)]
-                if bad:
-                    ali_dev = res["ali"].clone()
-                    for k in bad:
-                        ali_dev[int(fo[k]): int(fo[k + 1])] = 0
-                    res["ali"] = ali_dev
-                kept.append((idx, feats, res["ali"], fo, rows))
+                res["ali"] = torch.from_numpy(ali).to(eng.device)
+        out = _BatchOut(idx, fo, ali, words, n_words, like, status)
+        ok = (status == 0) | (status == 1)
+        for k in np.flatnonzero(ok).tolist():
+            results[idx[k]] = (out, k)
+        for k in np.flatnonzero(~ok).tolist():
+            if status[k] == 2:
+                self.failure_reasons.setdefault(utts[idx[k]].utt_id, "no alignment within the retry beam")
+            else:
+                self.failure_reasons[utts[idx[k]].utt_id] = f"device decoder status {int(status[k])} (include/mfa_hip.h)"
+        if want_feats:
+            bad = np.flatnonzero(~ok).tolist()
+            if bad:   # frames of utterances that failed must not vote in the fMLLR statistics
+                ali_dev = res["ali"].clone()
+                for k in bad:
+                    ali_dev[int(fo[k]): int(fo[k + 1])] = 0
+                res["ali"] = ali_dev
+            kept.append((idx, feats, res["ali"], fo, rows))
+
+    def _pass(self, utts, spk_ids, cmvn, fmllr, want_feats=False):
+        """One alignment pass over all batches.  Returns per utterance ``(batch output, index)`` (None where alignment
+        failed) and, when asked, what fMLLR estimation needs (features, alignments, frame offsets per batch).  Nothing an
+        individual utterance does aborts the pass: unsupported graphs and decoder statuses beyond "failed" are recorded in
+        ``failure_reasons`` (the reference logs and continues, MFA/alignment/mixins.py:308-314).
+
+        Software pipeline over batches: launch b (asynchronous), prepare b + 1 on the host while the device works, then
+        collect b."""
+        import torch
+
+        eng = self.engine
+        d_lda = None if self.lda is None else torch.from_numpy(self.lda).to(eng.device)
+        results: List[Optional[tuple]] = [None] * len(utts)
+        kept: List[tuple] = []
+        batches = self._batches(utts)
+        prep = self._prepare(utts, batches[0]) if batches else None
+        for b in range(len(batches)):
+            launched = self._launch(utts, prep, spk_ids, cmvn, d_lda, fmllr)
+            nxt = self._prepare(utts, batches[b + 1]) if b + 1 < len(batches) else None
+            if prep["gidx"]:
+                self._general(utts, prep, spk_ids, cmvn, d_lda, fmllr, results, kept, want_feats)
+            if launched is not None:
+                self._collect(utts, prep, launched, results, kept, want_feats)
+            prep = nxt
         return results, kept
 
     # ------------------------------------------------------------------ public
@@ -389,6 +451,26 @@ class CorpusAligner:
                         results[i] = r1
                         self.fallback_first_pass.append(utts[i].utt_id)
                         self.failure_reasons.pop(utts[i].utt_id, None)
+        return self._results(utts, results, make_ctm)
+
+    def _extractor(self):
+        if self._intervals is None:
+            from . import intervals_native
+            self._intervals = intervals_native.IntervalExtractor(self.tm, self.lexicon, self.frame_shift)
+        return self._intervals
+
+    def _results(self, utts, results, make_ctm) -> List[Optional[UtteranceResult]]:
+        """Per-utterance results from the batch outputs.  With ``make_ctm`` the interval stage — generate_ctm →
+        phones_to_pronunciations → update_utterance_boundaries → fix_unk_words, MFA/alignment/multiprocessing.py:1733-1751 —
+        runs once per batch over the arrays (intervals_native); the ``HierarchicalCtm`` objects are built when a caller asks
+        an ``UtteranceResult`` for its ``ctm``.  Per utterance, as the reference's extraction loop: an alignment the stage
+        cannot take concerns this utterance only (:1739-1770 catches, logs and continues)."""
+        sr = float(self.mfcc_options.get("sample_frequency", 16000.0))
+        if make_ctm:
+            ex = self._extractor()
+            for bo in {id(r[0]): r[0] for r in results if r is not None}.values():
+                if bo.intervals is None:
+                    bo.intervals = ex.extract(bo.frame_off, bo.ali, bo.words, bo.n_words, bo.status)
         out: List[Optional[UtteranceResult]] = []
         for u, r in zip(utts, results):
             if r is None:
@@ -396,57 +478,110 @@ class CorpusAligner:
                 self.failure_reasons.setdefault(u.utt_id, "no alignment")
                 out.append(None)
                 continue
-            ur = UtteranceResult(u.utt_id, u.speaker, r["ali"], r["words"], r["like"], r["frames"])
+            bo, k = r
+            a, b = int(bo.frame_off[k]), int(bo.frame_off[k + 1])
+            ur = UtteranceResult(u.utt_id, u.speaker, bo.ali[a:b], bo.words[a: a + int(bo.n_words[k])], float(bo.like[k]), b - a)
             if make_ctm:
-                # per utterance, as the reference's extraction loop: an exception concerns this utterance only
-                # (MFA/alignment/multiprocessing.py:1739-1770 catches, logs and continues)
-                try:
-                    ur.ctm = self._make_ctm(u, r, ur.per_frame_likelihood)
-                except Exception as e:  # noqa: BLE001
-                    self.failure_reasons[u.utt_id] = f"interval extraction failed: {e}"
-                    self.ctm_failed.append(u.utt_id)
+                end = u.begin + len(u.pcm) / sr
+                if bo.intervals.err[k] == 0:
+                    ur._lazy = (bo.intervals, k, u.text, u.begin, end)
+                else:
+                    try:                    # the Python specification on this utterance: it raises the specific error
+                        ur.ctm = bo.intervals.ctm(k, text=u.text, begin=u.begin, end=end, likelihood=ur.per_frame_likelihood)
+                    except Exception as e:  # noqa: BLE001
+                        self.failure_reasons[u.utt_id] = f"interval extraction failed: {e}"
+                        self.ctm_failed.append(u.utt_id)
             out.append(ur)
         return out
 
-    def _make_ctm(self, u: CorpusUtterance, r: dict, per_frame_likelihood: float) -> _ctm.HierarchicalCtm:
-        """generate_ctm → phones_to_pronunciations → update_utterance_boundaries → fix_unk_words
-        (MFA/alignment/multiprocessing.py:1733-1751)."""
-        ivs = _ctm.generate_ctm(r["ali"], self.tm, self.lexicon.phone_table, self.frame_shift)
-        ctm = _ctm.phones_to_pronunciations(self.lexicon, r["words"], ivs, text=u.text)
-        ctm.likelihood = per_frame_likelihood
-        ctm.update_utterance_boundaries(u.begin, u.begin + len(u.pcm) / float(self.mfcc_options.get("sample_frequency", 16000.0)))
-        if u.text is not None:   # <unk> intervals get their transcript spelling (MFA/alignment/multiprocessing.py:1749-1751)
-            ctm.word_intervals = _ctm.fix_unk_words(u.text.split(), ctm.word_intervals, self.lexicon)
-        return ctm
-
     def export_textgrids(self, utterances: Sequence[CorpusUtterance], results: Sequence[Optional[UtteranceResult]], output_directory,
                          output_format: str = "long_textgrid", cleanup_silence: bool = True) -> List[Path]:
-        """One file per sound file, one (words, phones) tier pair per speaker (export_textgrid, MFA/textgrid.py:463-572)."""
+        """One file per sound file, one (words, phones) tier pair per speaker (export_textgrid, MFA/textgrid.py:463-572).
+
+        Files whose utterances still carry their interval arrays (the results of ``align``) are written from those arrays
+        by the native writer — byte for byte what ``ctm.export_textgrid`` writes (tests/test_intervals_native_cpu.py);
+        anything else (results whose ``ctm`` a caller set or changed, a file the native writer declines) goes through the
+        Python objects."""
         out_dir = Path(output_directory)
         out_dir.mkdir(parents=True, exist_ok=True)
-        sil = self.lexicon.silence_word
+        sr = float(self.mfcc_options.get("sample_frequency", 16000.0))
+        ext = {"long_textgrid": ".TextGrid", "short_textgrid": ".TextGrid", "json": ".json", "csv": ".csv"}[output_format]
         per_file: Dict[str, dict] = {}
-        for u, r in zip(utterances, results):
-            if r is None or r.ctm is None:
+        for n, (u, r) in enumerate(zip(utterances, results)):
+            if r is None or not r.has_intervals:
                 continue
             name = u.file_name or u.utt_id
-            f = per_file.setdefault(name, dict(duration=0.0, speakers={}))
-            end = u.begin + len(u.pcm) / float(self.mfcc_options.get("sample_frequency", 16000.0))
+            f = per_file.get(name)
+            if f is None:
+                f = per_file[name] = dict(name=name, duration=0.0, speakers={}, native=True)
+            end = u.begin + len(u.pcm) / sr
             f["duration"] = max(f["duration"], u.file_duration or end)
-            tiers = f["speakers"].setdefault(u.speaker, {"words": [], "phones": []})
-            for w in r.ctm.word_intervals:
-                if cleanup_silence and w.label == sil:
-                    continue
-                tiers["words"].append(_ctm.CtmInterval(w.begin, w.end, w.label))
-                tiers["phones"].extend(w.phones)
-        ext = {"long_textgrid": ".TextGrid", "short_textgrid": ".TextGrid", "json": ".json", "csv": ".csv"}[output_format]
-        written = []
-        for name, f in per_file.items():
-            for tiers in f["speakers"].values():
+            f["speakers"].setdefault(u.speaker, []).append(n)
+            if r._lazy is None:
+                f["native"] = False
+        written: List[Path] = []
+        slow = [f for f in per_file.values() if not f["native"]]
+        fast = [f for f in per_file.values() if f["native"]]
+        if fast:
+            from . import intervals_native
+            # the interval arrays of the batches involved, laid end to end: utterance (batch, k) becomes base[batch] + k
+            batches, base = {}, {}
+            for f in fast:
+                for ns in f["speakers"].values():
+                    for n in ns:
+                        b = results[n]._lazy[0]
+                        if id(b) not in batches:
+                            base[id(b)] = sum(x.n_utt for x in batches.values())
+                            batches[id(b)] = b
+            merged = intervals_native.IntervalBatch.concat(list(batches.values()))
+            total = merged.n_utt
+            ub, ue = np.zeros(total), np.zeros(total)
+            texts: List[Optional[str]] = [None] * total
+            files = []
+            for f in fast:
+                spk = []
+                for name, ns in f["speakers"].items():
+                    ids = []
+                    for n in ns:
+                        b, k, text, begin, end = results[n]._lazy
+                        m = base[id(b)] + k
+                        ub[m], ue[m], texts[m] = begin, end, text
+                        ids.append(m)
+                    spk.append((name, ids))
+                files.append(dict(duration=f["duration"], speakers=spk))
+            blobs, codes = self._extractor().write_files(merged, files, ub, ue, merged.relabels(texts), output_format, cleanup_silence)
+            todo = []
+            for f, blob, code in zip(fast, blobs, codes):
+                if code == 0:
+                    todo.append((out_dir / (f["name"] + ext), blob))
+                elif code == 1:
+                    slow.append(f)          # the Python writer raises the reference's error for this file
+            if len(todo) > 64:
+                from concurrent.futures import ThreadPoolExecutor
+                with ThreadPoolExecutor(8) as tp:
+                    list(tp.map(lambda pb: pb[0].write_bytes(pb[1]), todo))
+            else:
+                for path, blob in todo:
+                    path.write_bytes(blob)
+            written += [p_ for p_, _ in todo]
+        sil = self.lexicon.silence_word
+        for f in slow:
+            speakers = {}
+            for name, ns in f["speakers"].items():
+                tiers = speakers.setdefault(name, {"words": [], "phones": []})
+                for n in ns:
+                    for w in results[n].ctm.word_intervals:
+                        if cleanup_silence and w.label == sil:
+                            continue
+                        tiers["words"].append(_ctm.CtmInterval(w.begin, w.end, w.label))
+                        tiers["phones"].extend(w.phones)
                 tiers["words"].sort(); tiers["phones"].sort()
-            path = out_dir / (name + ext)
-            _ctm.export_textgrid(f["speakers"], path, f["duration"], self.frame_shift, output_format)
-            written.append(path)
+            path = out_dir / (f["name"] + ext)
+            _ctm.export_textgrid(speakers, path, f["duration"], self.frame_shift, output_format)
+            if path.exists():
+                written.append(path)
+        order = {name: k for k, name in enumerate(per_file)}
+        written.sort(key=lambda p_: order.get(p_.name[: -len(ext)], 0))
         return written
 
 

@@ -1,6 +1,11 @@
 // Context management, memory helpers and timing for libmfa_hip.so.
 #include "ctx.hpp"
 
+#include <atomic>
+#include <cstring>
+#include <thread>
+#include <vector>
+
 extern "C" {
 
 MFA_API int mfa_version(void) { return 1; }
@@ -102,6 +107,30 @@ MFA_API int mfa_kernel_time_ms(mfa_ctx *c, int which, float *ms, int *launches) 
 MFA_API int mfa_kernel_time_reset(mfa_ctx *c) {
   if (mfa_resolve_timers(c) != 0) return -1;
   for (int i = 0; i < MFA_K_COUNT; i++) { c->k_ms[i] = 0; c->k_n[i] = 0; }
+  return 0;
+}
+
+// Host helper: the PCM of a batch — one array per utterance on the host — copied back to back into one staging buffer
+// (pinned memory, so that a single asynchronous H2D copy follows) by n_threads host threads.  1.3 GB per 4 096 ten-second
+// utterances: a single-threaded gather is slower than the device aligns them.
+MFA_API int mfa_gather_pcm(int32_t n_utt, const int16_t *const *h_src, const int64_t *h_sample_off, int16_t *h_dst, int32_t n_threads) {
+  if (n_utt < 0 || (n_utt > 0 && (!h_src || !h_sample_off || !h_dst))) return -1;
+  int t = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+  if (t < 1) t = 1;
+  if (t > n_utt) t = n_utt > 0 ? n_utt : 1;
+  std::atomic<int32_t> next{0};
+  auto work = [&]() {
+    for (;;) {
+      int32_t u = next.fetch_add(1);
+      if (u >= n_utt) break;
+      const int64_t n = h_sample_off[u + 1] - h_sample_off[u];
+      if (n > 0) memcpy(h_dst + h_sample_off[u], h_src[u], (size_t)n * sizeof(int16_t));
+    }
+  };
+  if (t == 1) { work(); return 0; }
+  std::vector<std::thread> th;
+  for (int k = 0; k < t; k++) th.emplace_back(work);
+  for (auto &x : th) x.join();
   return 0;
 }
 

@@ -183,6 +183,45 @@ struct mfa_gc {
   int n_tids = 0, n_tstates = 0;
   std::vector<int32_t> id2state, self_loop_of;
   std::unordered_map<uint64_t, Hmm> hmm;
+  // tree + topology + transition-state table (mfa_gc_set_model): windows are resolved natively when present
+  struct Model {
+    bool set = false;
+    int32_t root = 0;
+    std::vector<int32_t> kind, key, answer, a, b, yes_off, table, yes_vals;
+    std::vector<int32_t> phone2entry, entry_state_off, fwd_class, slf_class, trans_off, trans_dst, state2id;
+    struct TupleKey {
+      int32_t p, hs, f, s;
+      bool operator==(const TupleKey &o) const { return p == o.p && hs == o.hs && f == o.f && s == o.s; }
+    };
+    struct TupleHash {
+      size_t operator()(const TupleKey &k) const {
+        uint64_t h = (uint64_t)(uint32_t)k.p * 0x9E3779B97F4A7C15ull;
+        h ^= (uint64_t)(uint32_t)k.hs + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+        h ^= (uint64_t)(uint32_t)k.f + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+        h ^= (uint64_t)(uint32_t)k.s + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+        return (size_t)h;
+      }
+    };
+    std::unordered_map<TupleKey, int32_t, TupleHash> tuple2ts;
+    // EventMap::Map for the event {0..width-1: window, -1: pdf_class}; -1 when the tree has no answer
+    int32_t compute(const int32_t *win, int width, int32_t pdf_class) const {
+      int32_t node = root;
+      while (node >= 0) {
+        if (kind[node] == 0) return answer[node];
+        const int32_t k = key[node];
+        int32_t v;
+        if (k == -1) v = pdf_class;
+        else if (k >= 0 && k < width) v = win[k];
+        else return -1;
+        if (kind[node] == 1) node = (v >= 0 && v < b[node]) ? table[a[node] + v] : -1;
+        else {
+          const int32_t *lo = yes_vals.data() + yes_off[node], *hi = yes_vals.data() + yes_off[node + 1];
+          node = std::binary_search(lo, hi, v) ? a[node] : b[node];
+        }
+      }
+      return -1;
+    }
+  } model;
   // batch state
   std::vector<CtxGraph> ctx;
   std::vector<int32_t> missing;       // flat windows
@@ -492,6 +531,78 @@ int64_t mfa_gc_prepare(mfa_gc *gc, int32_t n_utt, const int64_t *word_off, const
   return (int64_t)(gc->missing.size() / gc->width);
 }
 
+int mfa_gc_set_model(mfa_gc *gc, const mfa_gc_model *m) {
+  if (!gc || !m) return -1;
+  mfa_gc::Model &d = gc->model;
+  d = mfa_gc::Model();
+  if (m->n_nodes <= 0 || m->root < 0 || m->root >= m->n_nodes) return gc->fail("tree without nodes");
+  const int n = m->n_nodes;
+  d.root = m->root;
+  d.kind.assign(m->kind, m->kind + n); d.key.assign(m->key, m->key + n); d.answer.assign(m->answer, m->answer + n);
+  d.a.assign(m->a, m->a + n); d.b.assign(m->b, m->b + n); d.yes_off.assign(m->yes_off, m->yes_off + n + 1);
+  size_t n_table = 0;
+  for (int i = 0; i < n; i++) {
+    if (d.kind[i] == 1) { if (d.a[i] < 0 || d.b[i] < 0) return gc->fail("tree node %d: bad table", i); n_table = std::max(n_table, (size_t)d.a[i] + (size_t)d.b[i]); }
+    else if (d.kind[i] == 2) { if (d.a[i] < 0 || d.a[i] >= n || d.b[i] < 0 || d.b[i] >= n) return gc->fail("tree node %d: bad child", i); }
+    else if (d.kind[i] != 0) return gc->fail("tree node %d: unknown kind", i);
+  }
+  d.table.assign(m->table, m->table + n_table);
+  for (int32_t c : d.table) if (c < -1 || c >= n) return gc->fail("tree table entry outside the node array");
+  d.yes_vals.assign(m->yes_vals, m->yes_vals + d.yes_off[n]);
+  d.phone2entry.assign(m->phone2entry, m->phone2entry + m->max_phone + 1);
+  d.entry_state_off.assign(m->entry_state_off, m->entry_state_off + m->n_entries + 1);
+  const int ns = d.entry_state_off[m->n_entries];
+  d.fwd_class.assign(m->fwd_class, m->fwd_class + ns); d.slf_class.assign(m->slf_class, m->slf_class + ns);
+  d.trans_off.assign(m->trans_off, m->trans_off + ns + 1);
+  d.trans_dst.assign(m->trans_dst, m->trans_dst + d.trans_off[ns]);
+  d.state2id.assign(m->state2id, m->state2id + m->n_tuples + 2);
+  d.tuple2ts.reserve((size_t)m->n_tuples * 2);
+  for (int i = 0; i < m->n_tuples; i++)
+    d.tuple2ts[mfa_gc::Model::TupleKey{m->tuples[4 * i], m->tuples[4 * i + 1], m->tuples[4 * i + 2], m->tuples[4 * i + 3]}] = i + 1;
+  d.set = true;
+  return 0;
+}
+
+// graph.py TrainingGraphCompiler._hmm for every missing window the model answers; the rest stay missing
+int64_t mfa_gc_resolve_windows(mfa_gc *gc) {
+  if (!gc) return -1;
+  const mfa_gc::Model &d = gc->model;
+  const int width = gc->width, central = width / 2;
+  if (!d.set) return (int64_t)(gc->missing.size() / width);
+  std::vector<int32_t> left;
+  for (size_t i = 0; i + width <= gc->missing.size(); i += width) {
+    const int32_t *win = gc->missing.data() + i;
+    const int32_t phone = win[central];
+    bool ok = phone >= 0 && phone < (int32_t)d.phone2entry.size() && d.phone2entry[phone] >= 0;
+    Hmm h;
+    if (ok) {
+      const int e = d.phone2entry[phone], s0 = d.entry_state_off[e], s1 = d.entry_state_off[e + 1];
+      h.n_final = s1 - s0 - 1;
+      for (int s = s0; s < s1 && ok; s++) {
+        const int hs = s - s0;
+        if (d.trans_off[s + 1] == d.trans_off[s]) continue;
+        const int32_t fwd = d.compute(win, width, d.fwd_class[s]), slf = d.compute(win, width, d.slf_class[s]);
+        if (fwd < 0 || slf < 0) { ok = false; break; }
+        auto it = d.tuple2ts.find(mfa_gc::Model::TupleKey{phone, hs, fwd, slf});
+        if (it == d.tuple2ts.end()) { ok = false; break; }
+        const int32_t first = d.state2id[it->second];
+        for (int t = d.trans_off[s]; t < d.trans_off[s + 1]; t++) {
+          const int dst = d.trans_dst[t];
+          if (dst == hs) continue;
+          if (dst == 0) { ok = false; break; }          // topologies that re-enter HMM state 0: graph.py raises
+          const int32_t tid = first + (t - d.trans_off[s]);
+          if (tid <= 0 || tid > gc->n_tids) { ok = false; break; }
+          h.trans.push_back(hs); h.trans.push_back(dst); h.trans.push_back(tid);
+        }
+      }
+    }
+    if (ok) gc->hmm[win_key(win, width)] = std::move(h);
+    else left.insert(left.end(), win, win + width);
+  }
+  gc->missing.swap(left);
+  return (int64_t)(gc->missing.size() / width);
+}
+
 int mfa_gc_missing_windows(mfa_gc *gc, int32_t *windows) {
   if (!gc) return -1;
   if (!gc->missing.empty()) memcpy(windows, gc->missing.data(), gc->missing.size() * sizeof(int32_t));
@@ -530,6 +641,40 @@ int mfa_gc_fetch(mfa_gc *gc, int64_t *state_off, int64_t *arc_base, int64_t *arc
     S += (int64_t)r.fin.size(); A += (int64_t)r.arcs.size(); O += (int64_t)r.offs.size();
   }
   state_off[n] = S; arc_base[n] = A;
+  return 0;
+}
+
+/* The batch copied out by n_threads threads, together with the columns the score-plan builder and the device layout read:
+ * arc_off32 (int32 copy of the per-utterance arc offsets), arc_next (next state) and arc_pdf (id2pdf[ilabel]; id2pdf may be
+ * NULL, then arc_pdf is not written).  Any output pointer may be NULL. */
+int mfa_gc_fetch_columns(mfa_gc *gc, const int32_t *id2pdf, int32_t n_threads, int64_t *state_off, int64_t *arc_base,
+                         int64_t *arc_off, int32_t *arc_off32, void *arcs, float *final_w, int32_t *arc_next, int32_t *arc_pdf) {
+  if (!gc) return -1;
+  const int n = (int)gc->res.size();
+  std::vector<int64_t> so((size_t)n + 1, 0), ab((size_t)n + 1, 0);
+  for (int u = 0; u < n; u++) {
+    so[u + 1] = so[u] + (int64_t)gc->res[u].fin.size();
+    ab[u + 1] = ab[u] + (int64_t)gc->res[u].arcs.size();
+  }
+  if (state_off) memcpy(state_off, so.data(), sizeof(int64_t) * (n + 1));
+  if (arc_base) memcpy(arc_base, ab.data(), sizeof(int64_t) * (n + 1));
+  OutArc *out = (OutArc *)arcs;
+  std::atomic<int> bad(0);
+  parallel_for(n, n_threads, [&](int u) {
+    const UttResult &r = gc->res[u];
+    const int64_t S = so[u], A = ab[u], O = so[u] + u;
+    if (arc_off) memcpy(arc_off + O, r.offs.data(), r.offs.size() * sizeof(int64_t));
+    if (arc_off32) for (size_t i = 0; i < r.offs.size(); i++) arc_off32[O + i] = (int32_t)r.offs[i];
+    if (out && !r.arcs.empty()) memcpy(out + A, r.arcs.data(), r.arcs.size() * sizeof(OutArc));
+    if (final_w && !r.fin.empty()) memcpy(final_w + S, r.fin.data(), r.fin.size() * sizeof(float));
+    if (arc_next) for (size_t i = 0; i < r.arcs.size(); i++) arc_next[A + i] = r.arcs[i].nx;
+    if (arc_pdf && id2pdf)
+      for (size_t i = 0; i < r.arcs.size(); i++) {
+        const int32_t il = r.arcs[i].il;
+        if (il < 0 || il > gc->n_tids) { bad.store(1); arc_pdf[A + i] = -1; } else arc_pdf[A + i] = id2pdf[il];
+      }
+  });
+  if (bad.load()) return gc->fail("an arc carries an input label outside the model's transition-ids");
   return 0;
 }
 

@@ -32,6 +32,74 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+def _host_threads() -> int:
+    try:
+        return max(1, min(32, len(os.sched_getaffinity(0))))
+    except AttributeError:
+        return max(1, min(32, os.cpu_count() or 1))
+
+
+class RaggedView:
+    """``np.split(flat, offsets[1:-1])`` without making the pieces up front: piece u is ``flat[offsets[u]: offsets[u + 1]]``."""
+
+    def __init__(self, flat: np.ndarray, offsets: np.ndarray):
+        self.flat, self.offsets = flat, offsets
+
+    def __len__(self) -> int:
+        return len(self.offsets) - 1
+
+    def __getitem__(self, u):
+        if isinstance(u, slice):
+            return [self[k] for k in range(*u.indices(len(self)))]
+        if u < 0:
+            u += len(self)
+        return self.flat[int(self.offsets[u]): int(self.offsets[u + 1])]
+
+    def __iter__(self):
+        for u in range(len(self)):
+            yield self[u]
+
+
+class StagingPool:
+    """Named host staging buffers in pinned memory, reused from batch to batch (a fresh 200 MB numpy array costs more in page
+    faults than the copy it is for).  ``get`` hands out a numpy view; ``to_device`` starts an asynchronous H2D copy of a view
+    and remembers it: ``wait`` blocks until every copy started since the last ``wait`` has left the buffers — call it before
+    writing into them again."""
+
+    def __init__(self, device: torch.device, pinned: bool = True):
+        self.device = device
+        self.pinned = pinned
+        self._buf: Dict[str, torch.Tensor] = {}
+        self._event: Optional[torch.cuda.Event] = None
+
+    def get(self, name: str, count: int, dtype) -> np.ndarray:
+        dtype = np.dtype(dtype)
+        need = max(1, int(count)) * dtype.itemsize
+        t = self._buf.get(name)
+        if t is None or t.numel() < need:
+            t = torch.empty(int(need * 1.25) + 64, dtype=torch.uint8)
+            if self.pinned:
+                try:
+                    t = t.pin_memory()
+                except RuntimeError:      # pinned allocation refused (constrained container): pageable still works
+                    self.pinned = False
+            self._buf[name] = t
+        return t.numpy()[: int(count) * dtype.itemsize].view(dtype)
+
+    def to_device(self, view: np.ndarray, stream: Optional[torch.cuda.Stream] = None) -> torch.Tensor:
+        src = torch.from_numpy(view)
+        with torch.cuda.device(self.device):
+            out = src.to(self.device, non_blocking=True)
+            self._event = torch.cuda.Event()
+            self._event.record(torch.cuda.current_stream(self.device) if stream is None else stream)
+        return out
+
+    def wait(self) -> None:
+        if self._event is not None:
+            self._event.synchronize()
+            self._event = None
+
+
 @dataclass
 class PackedGraphs:
     """Graphs of a batch in the device layout mfa_align_batch consumes (see mfa_graph_batch)."""
@@ -45,7 +113,7 @@ class PackedGraphs:
     pdf_off: torch.Tensor       # int64 [n_utt+1]
     class_counts: torch.Tensor  # int32 [n_utt,6]
     pdf_off_host: np.ndarray
-    pdf_lists_host: List[np.ndarray]
+    pdf_lists_host: Sequence[np.ndarray]                  # per-utterance views of the host copy of pdf_list
     pdf_first_frame: Optional[torch.Tensor] = None        # int32 [ΣP_u]: first frame a pdf can be asked for
     pdf_first_frame_host: Optional[List[np.ndarray]] = None
     # lazy (windowed) scoring keys — mfa_score_plan: running max inside each class of the longest-path depth of a pdf's
@@ -89,6 +157,36 @@ class AlignmentEngine:
         self.num_ceps = 13
         self.gmm: Optional[DiagGmmModel] = None
         self.slot_class: Optional[np.ndarray] = None
+        # two sets of pinned staging buffers: the host fills one while the copies out of the other are still in flight
+        self._staging = [StagingPool(self.device), StagingPool(self.device)]
+        self._staging_turn = 0
+
+    def next_staging(self) -> StagingPool:
+        """The staging pool to fill next (alternating; waits until the copies last started from it are done)."""
+        self._staging_turn ^= 1
+        pool = self._staging[self._staging_turn]
+        pool.wait()
+        return pool
+
+    def gather_pcm(self, arrays: Sequence[np.ndarray], pool: Optional[StagingPool] = None):
+        """int16 arrays (one per utterance, host) → one device tensor + sample offsets: threaded gather into pinned staging
+        memory (mfa_gather_pcm), one asynchronous H2D copy."""
+        n = len(arrays)
+        lens = np.fromiter((a.shape[0] for a in arrays), dtype=np.int64, count=n)
+        so = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(lens, out=so[1:])
+        pool = pool or self.next_staging()
+        stage = pool.get("pcm", int(so[-1]), np.int16)
+        ptrs = (C.c_void_p * max(n, 1))()
+        keep = []
+        for k, a in enumerate(arrays):
+            if a.dtype != np.int16 or not a.flags.c_contiguous:
+                a = np.ascontiguousarray(a, dtype=np.int16)
+                keep.append(a)
+            ptrs[k] = a.ctypes.data
+        if self.lib.mfa_gather_pcm(n, ptrs, so.ctypes.data, stage.ctypes.data, _host_threads()) != 0:
+            raise _lib.MfaHipError("mfa_gather_pcm: bad arguments")
+        return pool.to_device(stage, self.stream), so
 
     def close(self) -> None:
         if self.ctx:
@@ -321,7 +419,7 @@ class AlignmentEngine:
         return bool(fst.num_arcs and (np.any(fst.arcs["ilabel"] == 0) or int(np.diff(fst.arc_offsets).max()) > 64))
 
     def pack_graphs(self, fsts: Sequence[Fst], tm: TransitionModel, cluster_gap: Optional[int] = 32,
-                    groups: Optional[int] = None) -> PackedGraphs:
+                    groups: Optional[int] = None, pool: Optional[StagingPool] = None) -> PackedGraphs:
         """Concatenate per-utterance graphs (with transition probabilities already applied) into the device layout.
 
         Score columns: one per (pdf, depth cluster) of the utterance.  A pdf whose arcs leave states far apart in the graph
@@ -336,11 +434,14 @@ class AlignmentEngine:
         if groups is None:
             groups = int(os.environ.get("MFA_PLAN_GROUPS", "8"))
         n = len(fsts)
-        if getattr(fsts, "arcs", None) is not None and len(getattr(fsts, "state_off", ())) == n + 1:
+        whole = getattr(fsts, "arcs", None) is not None and len(getattr(fsts, "state_off", ())) == n + 1
+        columns = whole and getattr(fsts, "arc_pdf", None) is not None and getattr(fsts, "arc_next", None) is not None \
+            and getattr(fsts, "arc_off32", None) is not None
+        if whole:
             # a batch from the native compiler (graph_native.FstBatch): its elements are views of these arrays
             state_off, arc_base = np.ascontiguousarray(fsts.state_off, dtype=np.int64), np.ascontiguousarray(fsts.arc_base, dtype=np.int64)
             S, A = np.diff(state_off), np.diff(arc_base)
-            arc_off = fsts.arc_off.astype(np.int32)
+            arc_off = fsts.arc_off32 if columns else fsts.arc_off.astype(np.int32)
             final, arcs = np.ascontiguousarray(fsts.final, dtype=np.float32), fsts.arcs
         else:
             S = np.array([f.num_states for f in fsts], dtype=np.int64)
@@ -350,37 +451,44 @@ class AlignmentEngine:
             arc_off = np.concatenate([f.arc_offsets.astype(np.int32) for f in fsts]) if n else np.zeros(0, np.int32)
             final = np.concatenate([f.final for f in fsts]).astype(np.float32)
             arcs = np.concatenate([f.arcs for f in fsts])
-        if np.any(arcs["ilabel"] <= 0):
-            raise _lib.MfaHipError("graphs with epsilon input arcs are not supported by the device decoder")
+        if self.slot_class is None:
+            raise _lib.MfaHipError("pack_graphs needs the acoustic model's slot classes: call load_gmm first")
+        if columns:
+            # (the compiler produced next-state and pdf columns; an input label outside the model was refused there)
+            nxt, pdf_of_arc = fsts.arc_next, fsts.arc_pdf
+            if arcs.shape[0] and int(pdf_of_arc.min()) < 0:
+                raise _lib.MfaHipError("graphs with epsilon input arcs are not supported by the device decoder")
+        else:
+            if np.any(arcs["ilabel"] <= 0):
+                raise _lib.MfaHipError("graphs with epsilon input arcs are not supported by the device decoder")
+            pdf_of_arc = np.ascontiguousarray(tm.id2pdf[arcs["ilabel"]], dtype=np.int32)
+            nxt = np.ascontiguousarray(arcs["nextstate"], dtype=np.int32)
         # (the concatenated offsets restart at every utterance: those steps are <= 0 and do not disturb the maximum)
         max_deg = int(np.diff(arc_off).max()) if arc_off.shape[0] > 1 else 0
         if max_deg > 64:
             raise _lib.MfaHipError(f"a graph state has {max_deg} arcs; the device decoder supports at most 64")
-        pdf_of_arc = np.ascontiguousarray(tm.id2pdf[arcs["ilabel"]], dtype=np.int32)
         span = 0 if cluster_gap is None else int(cluster_gap)
-        if self.slot_class is None:
-            raise _lib.MfaHipError("pack_graphs needs the acoustic model's slot classes: call load_gmm first")
         pdf_class = np.ascontiguousarray(self.slot_class, dtype=np.int32)
         # columns (pdf, depth cluster) in kernel order, their depth keys, and every arc's column: one host call for the batch,
-        # utterances spread over the host's threads (mfa_build_score_plans_batch)
+        # utterances spread over the host's threads (mfa_build_score_plans_batch); outputs land in reused pinned staging
+        # buffers and travel to the device asynchronously
         total_s, total_a = int(state_off[-1]), int(arc_base[-1])
-        nxt = np.ascontiguousarray(arcs["nextstate"], dtype=np.int32)
-        starts = np.array([f.start for f in fsts], dtype=np.int32)
-        sd_all = np.empty((max(total_s, 1), 2), dtype=np.int32)
-        cols = np.empty(max(total_a, 1), dtype=np.int32)
-        cp, cf, cl = (np.empty(max(total_a, 1), dtype=np.int32) for _ in range(3))
+        starts = np.zeros(n, dtype=np.int32) if whole else np.array([f.start for f in fsts], dtype=np.int32)
+        # ``pool``: the staging buffers of this batch (the ones a native-compiled batch already lives in, when the caller
+        # compiled it with ``alloc=pool.get``); default: the engine's next pair
+        in_pool = pool is not None and getattr(fsts, "staging", None) is pool
+        pool = pool or self.next_staging()
+        sd_all = pool.get("sd", max(total_s, 1) * 2, np.int32).reshape(-1, 2)
+        cols = pool.get("cols", max(total_a, 1), np.int32)
+        cp, cf, cl = (pool.get(k, max(total_a, 1), np.int32) for k in ("cp", "cf", "cl"))
         cc_all = np.zeros((max(n, 1), 6), dtype=np.int32)
         gc_all = np.zeros((max(n, 1), max(groups, 1)), dtype=np.int32)
         n_cols = np.zeros(max(n, 1), dtype=np.int32)
         bad = C.c_int32(-1)
-        try:
-            threads = len(os.sched_getaffinity(0))
-        except AttributeError:
-            threads = os.cpu_count() or 1
         rc = self.lib.mfa_build_score_plans_batch(n, state_off.ctypes.data, arc_base.ctypes.data, arc_off.ctypes.data,
                                                   nxt.ctypes.data, pdf_of_arc.ctypes.data, starts.ctypes.data,
                                                   int(pdf_class.shape[0]), pdf_class.ctypes.data, span, groups,
-                                                  max(1, min(32, threads)), sd_all.ctypes.data, cols.ctypes.data, cp.ctypes.data,
+                                                  _host_threads(), sd_all.ctypes.data, cols.ctypes.data, cp.ctypes.data,
                                                   cf.ctypes.data, cl.ctypes.data, cc_all.ctypes.data, gc_all.ctypes.data,
                                                   n_cols.ctypes.data, C.byref(bad)) if n else 0
         if rc != 0:
@@ -393,22 +501,39 @@ class AlignmentEngine:
         # utterance u's columns sit at [arc_base[u], arc_base[u] + n_cols[u]) of the column arrays: compact them
         take = np.repeat(arc_base[:-1] - pdf_off[:-1], n_cols) + np.arange(int(pdf_off[-1]), dtype=np.int64)
         pdf_all, first_all, last_all = cp[take], cf[take], cl[take]
-        cuts = pdf_off[1:-1]
-        pdf_lists = np.split(pdf_all, cuts) if n else []
-        first_frames = np.split(first_all, cuts) if n else []
+        pdf_lists = RaggedView(pdf_all, pdf_off)
+        first_frames = RaggedView(first_all, pdf_off)
         counts, group_counts = cc_all[:n], gc_all[:n]
-        t = dict(
-            state_off=self._dev(state_off), arc_base=self._dev(arc_base),
-            start=self._dev(np.array([f.start for f in fsts], dtype=np.int32)),
-            arc_off=self._dev(arc_off), final=self._dev(final),
-            arc_next=self._dev(arcs["nextstate"].astype(np.int32)), arc_weight=self._dev(arcs["weight"].astype(np.float32)),
-            arc_col=self._dev(cols), arc_ilabel=self._dev(arcs["ilabel"].astype(np.int32)),
-            arc_olabel=self._dev(arcs["olabel"].astype(np.int32)),
-        )
+        up = lambda a: pool.to_device(a, self.stream)       # noqa: E731  (pinned staging → device, asynchronous)
+        if columns:
+            # the 16-byte arc records travel once; their four columns are split on the device (strided device copies)
+            flat = arcs.view(np.int32).reshape(-1)
+            if not in_pool:
+                stage = pool.get("arcs_copy", max(total_a, 1) * 4, np.int32)[: total_a * 4]
+                stage[:] = flat
+                flat = stage
+            rec = up(flat).view(-1, 4)
+            t = dict(
+                state_off=self._dev(state_off), arc_base=self._dev(arc_base), start=self._dev(starts),
+                arc_off=up(arc_off) if in_pool else self._dev(arc_off), final=up(final) if in_pool else self._dev(final),
+                arc_next=rec[:, 3].contiguous(), arc_weight=rec[:, 2].contiguous().view(torch.float32),
+                arc_col=up(cols), arc_ilabel=rec[:, 0].contiguous(), arc_olabel=rec[:, 1].contiguous(),
+            )
+            del rec
+        else:
+            t = dict(
+                state_off=self._dev(state_off), arc_base=self._dev(arc_base),
+                start=self._dev(starts),
+                arc_off=self._dev(arc_off), final=self._dev(final),
+                arc_next=self._dev(arcs["nextstate"].astype(np.int32)), arc_weight=self._dev(arcs["weight"].astype(np.float32)),
+                arc_col=up(cols), arc_ilabel=self._dev(arcs["ilabel"].astype(np.int32)),
+                arc_olabel=self._dev(arcs["olabel"].astype(np.int32)),
+            )
+        sd_dev = up(sd_all[:total_s].reshape(-1)).view(-1, 2)
         return PackedGraphs(n, int(S.max()) if n else 0, int(A.max()) if n else 0, int(A.sum()), t, self._dev(pdf_all),
                             self._dev(pdf_off), self._dev(counts), pdf_off, pdf_lists,
                             self._dev(first_all), first_frames, self._dev(last_all),
-                            self._dev(sd_all[:total_s]), groups,
+                            sd_dev, groups,
                             self._dev(group_counts) if groups > 1 else None)
 
     def align(self, graphs: PackedGraphs, loglikes: torch.Tensor, ll_off: np.ndarray, ll_cols: torch.Tensor,

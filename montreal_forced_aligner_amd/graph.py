@@ -497,7 +497,7 @@ class TrainingGraphCompiler:
         return self._expand_hmm(cg)
 
     def compile_fsts(self, texts: Sequence[str], scaled_log_probs: Optional[np.ndarray] = None,
-                     n_threads: Optional[int] = None) -> List[Fst]:
+                     n_threads: Optional[int] = None, columns: bool = False, alloc=None) -> List[Fst]:
         """``[compile_fst(t) for t in texts]`` (with ``scaled_log_probs``: ``add_transition_probs`` applied) for a whole
         batch through the native compiler — csrc/graph_compile.cpp, one utterance per worker thread, the same graphs bit
         for bit (tests/test_graph_native_cpu.py).  What kalpy's C++ ``export_graphs`` is to the reference
@@ -509,7 +509,7 @@ class TrainingGraphCompiler:
             nat = self._native = graph_native.NativeGraphCompiler(self, n_threads)
         elif n_threads is not None:
             nat.n_threads = max(1, int(n_threads))
-        return nat.compile_batch(list(texts), scaled_log_probs)
+        return nat.compile_batch(list(texts), scaled_log_probs, columns=columns, alloc=alloc)
 
     def compile_phone_graph(self, pg: PhoneGraph) -> Fst:
         return self._expand_hmm(_expand_context(pg, self.tree.context_width))

@@ -53,6 +53,14 @@ class _Config(C.Structure):
                 ("n_tstates", C.c_int32), ("self_loop_of", C.c_void_p)]
 
 
+class _Model(C.Structure):
+    _fields_ = [("n_nodes", C.c_int32), ("root", C.c_int32), ("kind", C.c_void_p), ("key", C.c_void_p), ("answer", C.c_void_p),
+                ("a", C.c_void_p), ("b", C.c_void_p), ("yes_off", C.c_void_p), ("table", C.c_void_p), ("yes_vals", C.c_void_p),
+                ("max_phone", C.c_int32), ("phone2entry", C.c_void_p), ("n_entries", C.c_int32), ("entry_state_off", C.c_void_p),
+                ("fwd_class", C.c_void_p), ("slf_class", C.c_void_p), ("trans_off", C.c_void_p), ("trans_dst", C.c_void_p),
+                ("n_tuples", C.c_int32), ("tuples", C.c_void_p), ("state2id", C.c_void_p)]
+
+
 _vp, _i32, _i64 = C.c_void_p, C.c_int32, C.c_int64
 SIGNATURES = {
     "mfa_gc_create": (_vp, [C.POINTER(_Config)]),
@@ -61,8 +69,11 @@ SIGNATURES = {
     "mfa_gc_add_windows": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp]),
     "mfa_gc_prepare": (_i64, [_vp, _i32, _vp, _vp, _i32]),
     "mfa_gc_missing_windows": (C.c_int, [_vp, _vp]),
+    "mfa_gc_set_model": (C.c_int, [_vp, C.POINTER(_Model)]),
+    "mfa_gc_resolve_windows": (_i64, [_vp]),
     "mfa_gc_finish": (C.c_int, [_vp, _vp, _i32, C.POINTER(_i64), C.POINTER(_i64)]),
     "mfa_gc_fetch": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "mfa_gc_fetch_columns": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 _lib = None
 
@@ -97,6 +108,11 @@ class FstBatch(list):
     arc_off: np.ndarray       # int64 [total states + n]: utterance u's S_u + 1 offsets at state_off[u] + u
     arcs: np.ndarray          # ARC_DTYPE [total arcs]
     final: np.ndarray         # float32 [total states]
+    # columns for the score-plan builder and the device layout (mfa_gc_fetch_columns); None when not asked for
+    arc_off32: Optional[np.ndarray] = None    # int32 copy of arc_off
+    arc_next: Optional[np.ndarray] = None     # int32 [total arcs]
+    arc_pdf: Optional[np.ndarray] = None      # int32 [total arcs] pdf of the arc's transition-id
+    staging = None                            # the object whose ``get`` allocated these arrays (engine.StagingPool), if any
 
 
 class NativeGraphCompiler:
@@ -172,6 +188,72 @@ class NativeGraphCompiler:
         self._h = self.lib.mfa_gc_create(C.byref(cfg))
         if not self._h:
             raise GraphCompileError("mfa_gc_create refused the configuration")
+        self._set_model()
+
+    def _set_model(self) -> None:
+        """Tree, topology and transition-state table, flattened once (include/mfa_graph.h mfa_gc_model): context windows are
+        then resolved inside the library; whatever it cannot answer still comes back through ``_hmm`` (which raises)."""
+        tree, tm = self.compiler.tree, self.compiler.tm
+        kind, key, answer, a, b, table, nodes = [], [], [], [], [], [], []
+        index = {}
+
+        def flat(node) -> int:          # EventMap objects may be shared between parents: one flat node per object
+            if node is None:
+                return -1
+            got = index.get(id(node))
+            if got is not None:
+                return got
+            i = len(kind)
+            index[id(node)] = i
+            nodes.append(node)
+            kind.append({"CE": 0, "TE": 1, "SE": 2}[node.kind]); key.append(int(node.key)); answer.append(int(node.answer))
+            a.append(0); b.append(0)
+            if node.kind == "TE":
+                kids = [flat(c) for c in node.table]
+                a[i], b[i] = len(table), len(kids)
+                table.extend(kids)
+            elif node.kind == "SE":
+                a[i], b[i] = flat(node.yes), flat(node.no)
+                if a[i] < 0 or b[i] < 0:
+                    raise GraphCompileError("SE node with a NULL child")
+            return i
+
+        import sys
+        limit = sys.getrecursionlimit()
+        sys.setrecursionlimit(max(limit, 10000))
+        try:
+            root = flat(tree.to_pdf)
+        except (GraphCompileError, RecursionError):
+            return                      # unusual tree: windows keep going through the Python callback
+        finally:
+            sys.setrecursionlimit(limit)
+        yes_off, yes_vals = [0], []
+        for node in nodes:
+            if node.kind == "SE":
+                yes_vals.extend(sorted(int(x) for x in node.yes_set))
+            yes_off.append(len(yes_vals))
+        topo = tm.topo
+        p2e = np.asarray(topo.phone2idx, dtype=np.int32)
+        eso, fwd, slf, toff, tdst = [0], [], [], [0], []
+        for entry in topo.entries:
+            for st in entry:
+                fwd.append(int(st.forward_pdf_class)); slf.append(int(st.self_loop_pdf_class))
+                tdst.extend(int(d) for d, _p in st.transitions)
+                toff.append(len(tdst))
+            eso.append(len(fwd))
+        i32 = lambda x: np.ascontiguousarray(np.asarray(x if len(x) else [0], dtype=np.int32))   # noqa: E731
+        self._model_keep = dict(kind=i32(kind), key=i32(key), answer=i32(answer), a=i32(a), b=i32(b), yes_off=i32(yes_off),
+                                table=i32(table), yes_vals=i32(yes_vals), p2e=i32(p2e), eso=i32(eso), fwd=i32(fwd), slf=i32(slf),
+                                toff=i32(toff), tdst=i32(tdst), tuples=np.ascontiguousarray(tm.tuples, dtype=np.int32),
+                                s2i=np.ascontiguousarray(tm.state2id, dtype=np.int32))
+        k = self._model_keep
+        if k["s2i"].shape[0] < k["tuples"].shape[0] + 2:
+            return
+        m = _Model(len(kind), root, _ptr(k["kind"]), _ptr(k["key"]), _ptr(k["answer"]), _ptr(k["a"]), _ptr(k["b"]), _ptr(k["yes_off"]),
+                   _ptr(k["table"]), _ptr(k["yes_vals"]), int(p2e.shape[0] - 1), _ptr(k["p2e"]), len(topo.entries), _ptr(k["eso"]),
+                   _ptr(k["fwd"]), _ptr(k["slf"]), _ptr(k["toff"]), _ptr(k["tdst"]), int(k["tuples"].shape[0]), _ptr(k["tuples"]),
+                   _ptr(k["s2i"]))
+        self._check(self.lib.mfa_gc_set_model(self._h, C.byref(m)), "mfa_gc_set_model")
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -187,20 +269,27 @@ class NativeGraphCompiler:
     def _entries(self, text: str) -> Optional[List[int]]:
         """Lexicon entries of a transcript, or None when graph.py has to take it (a word id the tables do not hold)."""
         lex = self.compiler.lexicon
-        out = []
-        for word in text.split():
-            w = word.lower() if lex.ignore_case else word
-            e = self._entry_of.get(w)
-            if e is None:
-                if lex.to_int(word) != self._oov_wid:
-                    return None
-                e = self._oov_entry
-            if e in self._bad_entries:
+        get = self._entry_of.get
+        words = (text.lower() if lex.ignore_case else text).split()
+        out = [get(w) for w in words]
+        if None in out:
+            raw = text.split()
+            if len(raw) != len(words):          # (a case mapping that changes the token count: leave it to graph.py)
                 return None
-            out.append(e)
+            for k, e in enumerate(out):
+                if e is None:
+                    if lex.to_int(raw[k]) != self._oov_wid:
+                        return None
+                    out[k] = self._oov_entry
+        if self._bad_entries and not self._bad_entries.isdisjoint(out):
+            return None
         return out
 
-    def compile_batch(self, texts: Sequence[str], scaled_log_probs: Optional[np.ndarray] = None) -> List[Fst]:
+    def compile_batch(self, texts: Sequence[str], scaled_log_probs: Optional[np.ndarray] = None, columns: bool = False,
+                      alloc=None) -> List[Fst]:
+        """``columns``: also fill ``FstBatch.arc_off32 / arc_next / arc_pdf`` (what ``engine.pack_graphs`` would otherwise
+        derive with passes over the arcs).  ``alloc(name, n, dtype) -> np.ndarray``: where the batch's arrays live (e.g.
+        reused pinned buffers); default fresh numpy arrays."""
         ent = [self._entries(t) for t in texts]
         native = [k for k, e in enumerate(ent) if e is not None]
         out: List[Optional[Fst]] = [None] * len(texts)
@@ -216,6 +305,8 @@ class NativeGraphCompiler:
         entries = np.asarray([e for k in native for e in ent[k]] or [0], dtype=np.int32)
         missing = self._check(self.lib.mfa_gc_prepare(self._h, len(native), _ptr(word_off), _ptr(entries), self.n_threads),
                               "mfa_gc_prepare")
+        if missing:
+            missing = self._check(self.lib.mfa_gc_resolve_windows(self._h), "mfa_gc_resolve_windows")    # tree walked natively
         if missing:
             wins = np.zeros((missing, self._width), dtype=np.int32)
             self._check(self.lib.mfa_gc_missing_windows(self._h, _ptr(wins)), "mfa_gc_missing_windows")
@@ -238,12 +329,22 @@ class NativeGraphCompiler:
         n_states, n_arcs = C.c_int64(0), C.c_int64(0)
         self._check(self.lib.mfa_gc_finish(self._h, _ptr(neg), self.n_threads, C.byref(n_states), C.byref(n_arcs)), "mfa_gc_finish")
         S, A, n = int(n_states.value), int(n_arcs.value), len(native)
+        staging = getattr(alloc, "__self__", None)
+        if alloc is None:
+            alloc = lambda name, count, dtype: np.empty(count, dtype=dtype)   # noqa: E731
         state_off = np.zeros(n + 1, dtype=np.int64)
         arc_base = np.zeros(n + 1, dtype=np.int64)
-        arc_off = np.zeros(S + n, dtype=np.int64)
-        arcs = np.zeros(A, dtype=ARC_DTYPE)
-        final = np.zeros(S, dtype=np.float32)
-        self._check(self.lib.mfa_gc_fetch(self._h, _ptr(state_off), _ptr(arc_base), _ptr(arc_off), _ptr(arcs), _ptr(final)), "mfa_gc_fetch")
+        arc_off = alloc("arc_off", S + n, np.int64)
+        arcs = alloc("arcs", A, ARC_DTYPE)
+        final = alloc("final", S, np.float32)
+        arc_off32 = arc_next = arc_pdf = None
+        id2pdf = None
+        if columns:
+            arc_off32, arc_next, arc_pdf = alloc("arc_off32", S + n, np.int32), alloc("arc_next", A, np.int32), alloc("arc_pdf", A, np.int32)
+            id2pdf = np.ascontiguousarray(self.compiler.tm.id2pdf, dtype=np.int32)
+        self._check(self.lib.mfa_gc_fetch_columns(self._h, _ptr(id2pdf), self.n_threads, _ptr(state_off), _ptr(arc_base), _ptr(arc_off),
+                                                  _ptr(arc_off32), _ptr(arcs), _ptr(final), _ptr(arc_next), _ptr(arc_pdf)),
+                    "mfa_gc_fetch_columns")
         for j, k in enumerate(native):
             s0, s1, a0, a1 = int(state_off[j]), int(state_off[j + 1]), int(arc_base[j]), int(arc_base[j + 1])
             out[k] = Fst(0, arc_off[s0 + j: s1 + j + 1], arcs[a0:a1], final[s0:s1])
@@ -251,4 +352,6 @@ class NativeGraphCompiler:
             return out  # type: ignore[return-value]
         batch = FstBatch(out)
         batch.state_off, batch.arc_base, batch.arc_off, batch.arcs, batch.final = state_off, arc_base, arc_off, arcs, final
+        batch.arc_off32, batch.arc_next, batch.arc_pdf = arc_off32, arc_next, arc_pdf
+        batch.staging = staging
         return batch

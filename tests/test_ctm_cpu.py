@@ -204,11 +204,17 @@ def test_interval_stage_failure_concerns_one_utterance_only(fx, monkeypatch):
     pdfs = np.arange(tm.num_pdfs, dtype=np.int32)
     ll = np.random.default_rng(3).normal(-60.0, 10.0, size=(200, tm.num_pdfs)).astype(np.float32)
     r = helpers.oracle_align(tm, f, ll, pdfs, beam=1e4, retry_beam=0.0)
-    good = dict(ali=r["ali"], words=r["words"], like=r["like"], frames=200)
-    bad = dict(good, words=r["words"][::-1].copy())                   # same phones, word ids that do not spell them
+    from montreal_forced_aligner_amd.aligner import _BatchOut
+
+    T, nw = 200, len(r["words"])
+    words = np.zeros(3 * T, dtype=np.int32)
+    for k, w in enumerate((r["words"], r["words"][::-1], r["words"])):     # the middle one: word ids that do not spell the phones
+        words[k * T: k * T + nw] = w
+    bo = _BatchOut([0, 1, 2], np.array([0, T, 2 * T, 3 * T]), np.tile(r["ali"], 3).astype(np.int32), words,
+                   np.full(3, nw, dtype=np.int32), np.full(3, r["like"], dtype=np.float32), np.zeros(3, dtype=np.int32))
     al = CorpusAligner(tm, fx.mono_am, fx.mono_tree, fx.mono_lex, engine=StubEngine())
     monkeypatch.setattr(al, "speaker_cmvn", lambda utts: ({"s": 0}, None))
-    monkeypatch.setattr(al, "_pass", lambda utts, spk_ids, cmvn, fmllr, want_feats=False: ([good, bad, good], []))
+    monkeypatch.setattr(al, "_pass", lambda utts, spk_ids, cmvn, fmllr, want_feats=False: ([(bo, 0), (bo, 1), (bo, 2)], []))
     pcm = np.zeros(32000, dtype=np.int16)
     res = al.align([CorpusUtterance(f"s-{k}", "s", pcm, text) for k in range(3)])
     assert [x is not None for x in res] == [True, True, True] and al.failed == []

@@ -1,6 +1,7 @@
 """End-to-end rate of CorpusAligner on configs[2]-shaped utterances: int16 PCM + transcripts in host memory → alignments
 (and, with --ctm, phone/word intervals) on the host; stage times of the host loop printed beside it.
-GPU box:  python tools/corpus_rate.py [n_utt] [--ctm]"""
+GPU box:  python tools/corpus_rate.py [n_utt] [--ctm] [--full] [--textgrid]
+--full: the bench's model (4 960 pdfs x 32 Gaussians) and DISTINCT utterances, as bench.py's value_end_to_end loop."""
 import cProfile
 import pstats
 import sys
@@ -16,7 +17,8 @@ from montreal_forced_aligner_amd.engine import AlignmentEngine              # no
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 2048
-    want_ctm = "--ctm" in sys.argv
+    want_ctm = "--ctm" in sys.argv or "--textgrid" in sys.argv
+    full = "--full" in sys.argv
     import torch
 
     world = synth.SynthWorld.build()
@@ -31,8 +33,8 @@ def main():
         own = np.zeros(1, dtype=np.int32)
         return eng.features(mfcc, fo, own, eng.cmvn_stats(mfcc, fo, own, 1), lda=d_lda).cpu().numpy()
 
-    model = synth.train_triphone(world, feats_of, n_train=60, n_gauss=32, n_classes=2)
-    pool = 128
+    model = synth.train_triphone(world, feats_of, n_train=60, n_gauss=32, n_classes=5 if full else 2)
+    pool = n if full else 128
     base = [world.utterance(20000 + i, n_words=30) for i in range(pool)]
     utts = [CorpusUtterance(f"{base[i % pool][3]}-{i}", str(base[i % pool][3]), base[i % pool][0], base[i % pool][1]) for i in range(n)]
     al = CorpusAligner(model.tm, model.am, model.tree, world.lexicon, lda=lda, engine=eng,
@@ -49,7 +51,22 @@ def main():
     ok = sum(r is not None for r in res)
     print(f"CorpusAligner.align(make_ctm={want_ctm}): {n} utterances in {dt:.2f} s = {n / dt:.0f} utterances/s; {ok} aligned", flush=True)
     st = pstats.Stats(pr)
-    st.sort_stats("cumulative").print_stats(22)
+    st.sort_stats("cumulative").print_stats(45)
+    if "--textgrid" in sys.argv:
+        import shutil
+        import tempfile
+        d = tempfile.mkdtemp()
+        for u in utts:
+            u.file_name = u.utt_id
+        pr = cProfile.Profile()
+        t0 = time.time()
+        pr.enable()
+        files = al.export_textgrids(utts, res, d)
+        pr.disable()
+        dt2 = time.time() - t0
+        print(f"export_textgrids: {len(files)} files in {dt2:.2f} s = {n / dt2:.0f} utterances/s; with align {n / (dt + dt2):.0f}/s", flush=True)
+        pstats.Stats(pr).sort_stats("cumulative").print_stats(15)
+        shutil.rmtree(d, ignore_errors=True)
 
 
 if __name__ == "__main__":
