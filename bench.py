@@ -494,7 +494,7 @@ def main():
                            options=AlignOptions(beam=args.beam, retry_beam=args.retry_beam, max_tokens=args.max_tokens,
                                                 bp_tokens_per_frame=args.bp_tokens, batch_frames=B * 1001),
                            silence_phones=[pt.find("sil"), pt.find("spn")])
-        ca.align(utts_e2e[: min(B, 256)], make_ctm=False, previous_transforms=prev_tf)       # warm-up (allocations, tables)
+        ca.align(utts_e2e, make_ctm=False, previous_transforms=prev_tf)       # warm-up at full size (pinned staging buffers, tables)
         e2e = {}
         holder = {}
         dt_a = timed_loop(lambda: holder.__setitem__("res", ca.align(utts_e2e, make_ctm=False, previous_transforms=prev_tf)), 1)

@@ -1199,15 +1199,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     WSYNC();
   }
   if (overflow) { hand_over(); return; }
-  if (spec_fail) {   // the narrow band did not hold: the list pass decodes the utterance again from frame 0 with proven bands
-    if (lane == 0) {
-      VitState vs; vs.n = 0; vs.cur = 0; vs.done = 1; vs.pad0 = 0; vs.H = H; vs.pad1 = 0; vs.bp_used = bp_used;
-      p.w_vstate[utt] = vs;
-      p.w_hash[utt] = H;
-      p.status[utt] = ST_GROW; p.n_words[utt] = 0; p.like[utt] = 0.0f;
-    }
-    return;
-  }
+  // the narrow band did not hold: nothing parked has been touched, so the window is scored again with the proven band and
+  // redone from its parked state by the large tier — the same hand-over as a capacity overflow
+  if (spec_fail) { hand_over(); return; }
   __threadfence_block();
   u32 *c_state = l_state0 + cur * N;
   double *c_costp = l_cost0 + cur * N;
@@ -1269,6 +1263,11 @@ __global__ __launch_bounds__(64) void viterbi_finish_kernel(VitParams p) {
 __global__ void collect_pending_kernel(const int32_t *status, int n_utt, int code, int32_t *list, int32_t *count) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n_utt && status[i] == code) list[atomicAdd(count, 1)] = i;
+}
+// utterances a first-tier launch flagged for the large tier (w_redo != 0), as a list for the scoring kernels
+__global__ void collect_flagged_kernel(const u32 *flags, int n_utt, int32_t *list, int32_t *count) {
+  int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u < n_utt && flags[u] != 0u) list[atomicAdd(count, 1)] = u;
 }
 __global__ void finalize_pending_kernel(int32_t *status, int n_utt) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1409,14 +1408,15 @@ int align_impl(mfa_ctx *c, const mfa_graph_batch *g, const float *d_loglikes, co
   { const char *e = getenv("MFA_VIT_TIER"); if (e && atoi(e) >= 64) kSmallTokens = (atoi(e) + 63) & ~63; }
   // Speculative look-ahead of the windowed first-beam pass.  The proven band lets a token advance one arc per frame, K − 1
   // arcs by the window's last frame; speech advances a third of that (synthetic 10 s utterances: 21 states per 64 frames on
-  // average, 34 at the 99th percentile, 38 at most).  The window is scored for a look-ahead of 3/4 K arcs instead (48 for
-  // K = 64: 16 % fewer cells, no utterance of the bench workload exceeds it; 40: 25 % fewer cells, 2 % of the utterances
-  // fail somewhere), the decoder checks every score it reads against what was scored, and an utterance that asks for more
-  // is decoded again from frame 0 by the list pass below with the proven bands — results cannot differ.
+  // average, 34 at the 99th percentile, 38 at most).  The window is scored for a look-ahead of K / 2 arcs instead (32 for
+  // K = 64: a fifth fewer model blocks gathered than with 48, tools/band_study.py), the decoder checks every score it reads
+  // against what was scored, and a window in which it asks for more (about 1 % of them) is scored again with the proven band
+  // and redone from the state parked at its start by the large tier — the hand-over capacity overflows already use; results
+  // cannot differ.  (Round 2 re-decoded such an utterance from frame 0, which made anything below 48 arcs a loss.)
   // MFA_LAZY_LOOKAHEAD=n overrides (n >= K − 1: off).
   int spec_slack = 0;
   if (lazy) {
-    int look = lazy->window * 3 / 4;
+    int look = lazy->window / 2;
     { const char *e = getenv("MFA_LAZY_LOOKAHEAD"); if (e && atoi(e) > 0) look = atoi(e); }
     spec_slack = std::max(0, lazy->window - 1 - look);
     if (lazy->plan.max_cols > 32 * kBmWords) spec_slack = 0;   // (the decoder's bitmap of scored columns holds 2 048)
@@ -1427,7 +1427,8 @@ int align_impl(mfa_ctx *c, const mfa_graph_batch *g, const float *d_loglikes, co
     // so at most 1 024 tokens; beyond that a from-scratch pass with HBM-resident lists follows, as in the dense path)
     const int nb = std::min(N[0], 1024);
     const int cb = std::min(C[0], 4 * nb);
-    const bool second = nb < N[0] || spec_slack > 0;   // a from-scratch list pass: table growth, failed speculation
+    const bool second = nb < N[0];   // a from-scratch list pass: table growth beyond the large tier (a failed speculation is
+                                     // redone window by window, below)
     Launch a{0, kSmallTokens, std::min(C[0], 4 * kSmallTokens), 0, second ? 1 : 0};
     a.N2 = nb; a.C2 = cb;
     plan.push_back(a);
@@ -1542,6 +1543,18 @@ int align_impl(mfa_ctx *c, const mfa_graph_batch *g, const float *d_loglikes, co
           p2.windowed = 1; p2.next_window = K; p2.state_depth = p.state_depth; p2.band = p.band;
           p2.t_begin = t0; p2.t_end = t0 + K; p2.redo_mode = 2; p2.npark = p.npark; p2.grow = L.grow;
           p2.utt_list = p.utt_list; p2.n_list = p.n_list;
+          if (spec) {
+            // Window-level redo of a failed speculation: the utterances the first tier handed over (token overflow or a
+            // score asked for outside the narrow band) get THIS window scored again with the proven band, then the large
+            // tier redoes it from the parked state without the check.  Mostly empty launches: a fraction of a percent of
+            // the (utterance, window) pairs are flagged.
+            MFA_HIP_CHECK(c, hipMemsetAsync(d_count, 0, sizeof(int32_t), c->stream));
+            hipLaunchKernelGGL(collect_flagged_kernel, dim3((n_utt + 255) / 256), dim3(256), 0, c->stream, p.w_redo, n_utt, d_list, d_count);
+            MfaWindowScore ws2 = ws;
+            ws2.hi_slack = 0; ws2.utt_list = d_list; ws2.n_list = d_count; ws2.cols_per_wave = 0;
+            if (mfa_gmm_score_window(c, lazy, &ws2, d_frame_off, n_utt, d_ll_off, (float *)d_loglikes) != 0) return -1;
+            p2.spec = 0;
+          }
           {
             KernelTimer kt2(c, MFA_K_VITERBI);
             hipLaunchKernelGGL(viterbi_kernel<true>, dim3(n_utt), dim3(64), lds2, c->stream, p2);

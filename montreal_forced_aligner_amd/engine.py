@@ -77,12 +77,15 @@ class StagingPool:
         need = max(1, int(count)) * dtype.itemsize
         t = self._buf.get(name)
         if t is None or t.numel() < need:
-            t = torch.empty(int(need * 1.25) + 64, dtype=torch.uint8)
+            size = int(need * 1.25) + 64
+            t = None
             if self.pinned:
                 try:
-                    t = t.pin_memory()
+                    t = torch.empty(size, dtype=torch.uint8, pin_memory=True)
                 except RuntimeError:      # pinned allocation refused (constrained container): pageable still works
                     self.pinned = False
+            if t is None:
+                t = torch.empty(size, dtype=torch.uint8)
             self._buf[name] = t
         return t.numpy()[: int(count) * dtype.itemsize].view(dtype)
 
@@ -183,7 +186,7 @@ class AlignmentEngine:
             if a.dtype != np.int16 or not a.flags.c_contiguous:
                 a = np.ascontiguousarray(a, dtype=np.int16)
                 keep.append(a)
-            ptrs[k] = a.ctypes.data
+            ptrs[k] = a.__array_interface__["data"][0]
         if self.lib.mfa_gather_pcm(n, ptrs, so.ctypes.data, stage.ctypes.data, _host_threads()) != 0:
             raise _lib.MfaHipError("mfa_gather_pcm: bad arguments")
         return pool.to_device(stage, self.stream), so
@@ -433,6 +436,8 @@ class AlignmentEngine:
         mod groups — so that the lazy scoring kernel can give each run to one XCD (mfa_build_score_plan_grouped)."""
         if groups is None:
             groups = int(os.environ.get("MFA_PLAN_GROUPS", "8"))
+        if cluster_gap == 32 and os.environ.get("MFA_PLAN_SPAN"):          # (diagnostics: tools/band_study.py)
+            cluster_gap = int(os.environ["MFA_PLAN_SPAN"])
         n = len(fsts)
         whole = getattr(fsts, "arcs", None) is not None and len(getattr(fsts, "state_off", ())) == n + 1
         columns = whole and getattr(fsts, "arc_pdf", None) is not None and getattr(fsts, "arc_next", None) is not None \

@@ -533,6 +533,9 @@ struct FasterDecoder {
   HashList toks; std::vector<Token> pool; std::vector<int> queue; std::vector<double> tmp; int num_frames_decoded = -1;
   // statistics for tests / design (max tokens alive, total candidates)
   int64_t stat_max_toks = 0, stat_sum_toks = 0;
+  // optional (design studies of the device's lazy-scoring bands): per frame, over the tokens ENTERING the frame,
+  // {min of depth[s][1], max of depth[s][0], number of tokens, depth[.][0] of the best token}
+  const int32_t *stat_depth = nullptr; int32_t *stat_band = nullptr;
 
   FasterDecoder(const Graph &gr, float bm, int32_t maxa, int32_t mina, float bd, float hr)
       : g(gr), beam(bm), max_active(maxa), min_active(mina), beam_delta(bd), hash_ratio(hr) { toks.SetSize(1000); }
@@ -592,6 +595,15 @@ struct FasterDecoder {
     int last_toks = toks.Clear();
     size_t tok_cnt; float adaptive_beam; int best_elem = -1;
     double weight_cutoff = GetCutoff(last_toks, &tok_cnt, &adaptive_beam, &best_elem);
+    if (stat_depth && stat_band) {
+      int32_t lo = std::numeric_limits<int32_t>::max(), hi = -1;
+      for (int e = last_toks; e != -1; e = toks.elems[e].tail) {
+        int32_t st = toks.elems[e].key;
+        lo = std::min(lo, stat_depth[2 * st + 1]); hi = std::max(hi, stat_depth[2 * st]);
+      }
+      stat_band[4 * frame] = lo; stat_band[4 * frame + 1] = hi; stat_band[4 * frame + 2] = (int32_t)tok_cnt;
+      stat_band[4 * frame + 3] = best_elem >= 0 ? stat_depth[2 * toks.elems[best_elem].key] : -1;
+    }
     stat_max_toks = std::max<int64_t>(stat_max_toks, (int64_t)tok_cnt); stat_sum_toks += (int64_t)tok_cnt;
     size_t new_sz = (size_t)((float)tok_cnt * hash_ratio);  // PossiblyResizeHash
     if (new_sz > toks.Size()) toks.SetSize(new_sz);
@@ -704,8 +716,10 @@ struct FasterDecoder {
 // status: 0 ok first beam, 1 ok after retry, 2 failed.  like = -(graph+ac)/acoustic_scale.
 static int32_t align_with(const Graph &g, const Decodable &dec, int32_t T, float acoustic_scale, float beam, float retry_beam,
                           int32_t *ali, int32_t *words, int32_t cap_words, int32_t *n_words, float *like,
-                          float *per_frame_loglike, int64_t *stats) {
+                          float *per_frame_loglike, int64_t *stats, const int32_t *stat_depth = nullptr,
+                          int32_t *stat_band = nullptr) {
   FasterDecoder d(g, beam, std::numeric_limits<int32_t>::max(), 20, 0.5f, 2.0f);
+  d.stat_depth = stat_depth; d.stat_band = stat_band;
   d.Decode(dec);
   bool ans = d.ReachedFinal(); int status = 0;
   if (!ans && retry_beam != 0.0f) { status = 1; d.beam = retry_beam; d.Decode(dec); ans = d.ReachedFinal(); }
@@ -741,13 +755,15 @@ ORC_API int32_t orc_align_feats(int32_t num_states, int32_t start, const int64_t
                                 const float *means_invvars, const float *inv_vars, const int32_t *pdf_offsets, int32_t num_pdfs,
                                 const int32_t *tid2pdf, float acoustic_scale, float beam, float retry_beam, int32_t *ali,
                                 int32_t *words, int32_t cap_words, int32_t *n_words, float *like, float *per_frame_loglike,
-                                int64_t *stats /*[3] or NULL*/) {
+                                int64_t *stats /*[3] or NULL*/, const int32_t *state_depth /*[S][2] or NULL*/,
+                                int32_t *frame_band /*[T][4] or NULL: see FasterDecoder::stat_band (first beam's pass)*/) {
   if (start < 0 || num_states == 0) return 2;
   Graph g{num_states, start, arc_off, arcs, final_w};
   Decodable dec{nullptr, T, 0, tid2pdf, acoustic_scale};
   dec.feats = feats; dec.D = D; dec.gconsts = gconsts; dec.means_invvars = means_invvars; dec.inv_vars = inv_vars;
   dec.pdf_offsets = pdf_offsets; dec.InitLazy(num_pdfs);
-  int32_t st = align_with(g, dec, T, acoustic_scale, beam, retry_beam, ali, words, cap_words, n_words, like, per_frame_loglike, stats);
+  int32_t st = align_with(g, dec, T, acoustic_scale, beam, retry_beam, ali, words, cap_words, n_words, like, per_frame_loglike, stats,
+                          state_depth, frame_band);
   if (stats) stats[2] = dec.evals;
   return st;
 }

@@ -213,7 +213,7 @@ def align(num_states, start, arc_offsets, arcs, final, loglikes, tid2col, acoust
 
 
 def align_feats(num_states, start, arc_offsets, arcs, final, feats, gconsts, means_invvars, inv_vars, pdf_offsets, tid2pdf,
-                acoustic_scale, beam, retry_beam):
+                acoustic_scale, beam, retry_beam, state_depth=None):
     """The alignment with Kaldi's LAZY decodable (orc_align_feats): features + acoustic model in; a (frame, pdf) score is
     computed when a live token's arc first asks for it.  Same results as gmm_loglikes + align; also returns ``cells`` = the
     number of (frame, pdf) scores evaluated.  ``tid2pdf``: pdf id per transition-id (entry 0 unused)."""
@@ -236,12 +236,17 @@ def align_feats(num_states, start, arc_offsets, arcs, final, feats, gconsts, mea
     stats = np.zeros(3, np.int64)
     fn = lib().orc_align_feats
     fn.restype = C.c_int32
+    sd = None if state_depth is None else np.ascontiguousarray(state_depth, np.int32)
+    band = None if sd is None else np.zeros((T, 4), np.int32)
     st = fn(C.c_int32(num_states), C.c_int32(start), _p(arc_offsets), _p(arcs), _p(final), _p(feats), C.c_int32(T), C.c_int32(D),
             _p(gconsts), _p(means_invvars), _p(inv_vars), _p(pdf_offsets), C.c_int32(pdf_offsets.shape[0] - 1), _p(tid2pdf),
             C.c_float(acoustic_scale), C.c_float(beam), C.c_float(retry_beam), _p(ali), _p(words), C.c_int32(cap_words),
-            C.byref(n_words), C.byref(like), _p(pf), _p(stats))
-    return dict(status=int(st), ali=ali, words=words[: n_words.value].copy(), like=float(like.value), per_frame=pf,
-                max_toks=int(stats[0]), sum_toks=int(stats[1]), cells=int(stats[2]))
+            C.byref(n_words), C.byref(like), _p(pf), _p(stats), None if sd is None else _p(sd), None if band is None else _p(band))
+    out = dict(status=int(st), ali=ali, words=words[: n_words.value].copy(), like=float(like.value), per_frame=pf,
+               max_toks=int(stats[0]), sum_toks=int(stats[1]), cells=int(stats[2]))
+    if band is not None:
+        out["frame_band"] = band      # per frame: min longest-reach depth, max BFS depth, tokens, BFS depth of the best token
+    return out
 
 
 def split_to_phones(ali, id2state, is_self_loop, is_final, tuples):

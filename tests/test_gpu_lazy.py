@@ -325,9 +325,10 @@ def test_lazy_window_edges_and_empty_transcript(engine, tri):
 
 @pytest.mark.parametrize("lookahead", [6, 24])
 def test_speculative_lookahead_failures_fall_back_to_the_proven_band(engine, tri, lookahead, monkeypatch):
-    """The first-beam windows are scored for a look-ahead of 40 arcs instead of the proven 63; a decoder that reads a score
-    outside what was scored gives the utterance up and the list pass decodes it again with proven bands.  Forced here with
-    look-aheads far too short (almost every utterance fails its first windows): every output still equals the dense path's."""
+    """The first-beam windows are scored for a look-ahead of 32 arcs instead of the proven 63; a decoder that reads a score
+    outside what was scored hands the WINDOW over: it is scored again with the proven band and redone from the state parked
+    at its start by the large tier.  Forced here with look-aheads far too short (6: nearly every window fails; 24: a good
+    part of them): every output still equals the dense path's (``_both`` compares them)."""
     world, model, lda, fm, feats_of = tri
     engine.load_gmm(model.am)
     utts = [world.utterance(7500 + i, n_words=nw, samples=ns) for i, (nw, ns) in enumerate([(30, 160000), (10, 60000), (2, 9000), (35, 200000)])]
@@ -344,4 +345,7 @@ def test_speculative_lookahead_failures_fall_back_to_the_proven_band(engine, tri
     _, _, fill_proven = _both(engine, graphs, feats, fo, **kw)
     assert set(dense["status"].cpu().tolist()) <= {0, 1}
     assert fill_default < fill_proven                         # the default look-ahead scores fewer cells than the proven band
-    assert fill_forced > fill_default                         # and the forced failures really went through the list pass
+    if lookahead == 6:      # nearly every window was redone with the proven band: about as many cells as without speculation
+        assert fill_forced > fill_default and fill_forced > 0.8 * fill_proven
+    else:                   # some windows held: fewer cells than the proven band, more than the look-ahead alone would write
+        assert fill_forced < fill_proven

@@ -39,7 +39,7 @@ def main():
     utts = [CorpusUtterance(f"{base[i % pool][3]}-{i}", str(base[i % pool][3]), base[i % pool][0], base[i % pool][1]) for i in range(n)]
     al = CorpusAligner(model.tm, model.am, model.tree, world.lexicon, lda=lda, engine=eng,
                        options=AlignOptions(batch_frames=4_096_000))
-    al.align(utts[:256], make_ctm=want_ctm)                                 # warm-up: context windows, allocations
+    al.align(utts, make_ctm=want_ctm)                                       # warm-up at full size: context windows, pinned staging buffers
     torch.cuda.synchronize()
     pr = cProfile.Profile()
     t0 = time.time()
