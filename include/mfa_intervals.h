@@ -107,6 +107,13 @@ MFA_IV_API int mfa_iv_write_files(mfa_iv *iv, int32_t format, int32_t cleanup_si
                                   const int64_t *relabel_off, const char *relabel_text, int32_t n_threads, char *out,
                                   int64_t out_cap, int64_t *out_off, int32_t *file_err, int64_t *needed);
 
+/* Those bytes to disk, one file per entry, by n_threads host threads: file f = out[out_off[f] .. out_off[f + 1]) written to
+ * the path paths[path_off[f] .. path_off[f + 1]) (UTF-8); entries with file_err[f] != 0 are skipped.  io_err[f] = errno of a
+ * failed open / write / close, 0 otherwise.  Returns the number of files that failed.  (ExportTextGridProcessWorker,
+ * MFA/alignment/multiprocessing.py:1865-1960, writes its files from worker processes for the same reason.) */
+MFA_IV_API int mfa_iv_save_files(int32_t n_files, const int64_t *path_off, const char *paths, const char *out, const int64_t *out_off,
+                                 const int32_t *file_err, int32_t n_threads, int32_t *io_err);
+
 #ifdef __cplusplus
 }
 #endif

@@ -154,6 +154,7 @@ class CorpusAligner:
         self._mfcc_cache_bytes = 0
         self._mfcc_cache_on = False
         self._intervals = None          # intervals_native.IntervalExtractor, built on first use
+        self._worker = None             # one worker thread: the next batch's graphs compile under the current batch
 
     def _boosted(self, am: DiagGmmModel) -> DiagGmmModel:
         import copy
@@ -173,18 +174,25 @@ class CorpusAligner:
 
     # ------------------------------------------------------------------ helpers
     def _batches(self, utts: Sequence[CorpusUtterance]) -> List[List[int]]:
-        """Length-bucketed batches (BASELINE configs[4]): sort by duration, cut at ``batch_frames``."""
-        order = np.argsort([len(u.pcm) for u in utts], kind="stable")
-        out, cur, frames = [], [], 0
-        for i in order:
-            t = self.engine.num_frames(len(utts[i].pcm))
-            if cur and frames + t > self.opt.batch_frames:
+        """Length-bucketed batches (BASELINE configs[4]): sort by duration, cut at ``batch_frames``.  Computed once per run
+        (``align`` asks three times: graph compilation ahead, the CMVN pass, the alignment passes)."""
+        key = (id(utts), len(utts))
+        if getattr(self, "_batches_key", None) == key:
+            return self._batches_val
+        lens = np.fromiter((len(u.pcm) for u in utts), dtype=np.int64, count=len(utts))
+        order = np.argsort(lens, kind="stable")
+        frames = self.engine.num_frames_array(lens) if hasattr(self.engine, "num_frames_array") else \
+            np.array([self.engine.num_frames(int(n)) for n in lens], dtype=np.int64)
+        out, cur, total = [], [], 0
+        for i, t in zip(order.tolist(), frames[order].tolist()):
+            if cur and total + t > self.opt.batch_frames:
                 out.append(cur)
-                cur, frames = [], 0
-            cur.append(int(i))
-            frames += t
+                cur, total = [], 0
+            cur.append(i)
+            total += t
         if cur:
             out.append(cur)
+        self._batches_key, self._batches_val = key, out
         return out
 
     def _mfcc(self, utts: Sequence[CorpusUtterance], idx: Sequence[int]):
@@ -259,13 +267,26 @@ class CorpusAligner:
                          max_tokens=max_tokens, bp_tokens_per_frame=bp_tokens)
 
     # ------------------------------------------------------------------ one alignment pass, batch by batch
-    def _prepare(self, utts, idx_all):
-        """Host side of a batch, no device results needed: transcripts → training graphs (native, threaded, straight into the
-        batch's pinned staging buffers) → device layout + score plan.  Called for batch b + 1 while the device works on b."""
-        eng = self.engine
-        pool = eng.next_staging()
+    def _compile(self, utts, idx_all, pool):
+        """Pure host work of a batch, safe on a worker thread (no device call): transcripts → training graphs by the native
+        compiler's threads, straight into the batch's pinned staging buffers.  Runs for batch b + 1 while the main thread packs,
+        launches and collects batch b (and, for the first batch, while the CMVN pass gathers PCM)."""
         fsts_all = self.compiler.compile_fsts([utts[i].text for i in idx_all], self.scaled, columns=True, alloc=pool.get)
-        prep = dict(idx_all=list(idx_all), idx=[], fsts=[], gidx=[], gfsts=[], graphs=None)
+        return dict(idx_all=list(idx_all), fsts_all=fsts_all, pool=pool)
+
+    def _submit_compile(self, utts, idx_all):
+        from concurrent.futures import ThreadPoolExecutor
+
+        if self._worker is None:
+            self._worker = ThreadPoolExecutor(1, thread_name_prefix="mfa-graphs")
+        pool = self.engine.next_staging()          # (main thread: waits for the copies last started from this pool)
+        return self._worker.submit(self._compile, utts, idx_all, pool)
+
+    def _prepare(self, utts, comp):
+        """Device layout + score plan of a compiled batch (main thread: starts the batch's H2D copies)."""
+        eng = self.engine
+        idx_all, fsts_all, pool = comp["idx_all"], comp["fsts_all"], comp["pool"]
+        prep = dict(idx_all=idx_all, idx=[], fsts=[], gidx=[], gfsts=[], graphs=None)
         pdf = getattr(fsts_all, "arc_pdf", None)
         if pdf is not None and len(fsts_all) and pdf.shape[0] and int(pdf.min()) >= 0 \
                 and int(np.diff(fsts_all.arc_off32).max()) <= 64 and int(np.diff(fsts_all.arc_base).min()) > 0:
@@ -370,14 +391,15 @@ class CorpusAligner:
                 res["ali"] = ali_dev
             kept.append((idx, feats, res["ali"], fo, rows))
 
-    def _pass(self, utts, spk_ids, cmvn, fmllr, want_feats=False):
+    def _pass(self, utts, spk_ids, cmvn, fmllr, want_feats=False, first_compile=None):
         """One alignment pass over all batches.  Returns per utterance ``(batch output, index)`` (None where alignment
         failed) and, when asked, what fMLLR estimation needs (features, alignments, frame offsets per batch).  Nothing an
         individual utterance does aborts the pass: unsupported graphs and decoder statuses beyond "failed" are recorded in
         ``failure_reasons`` (the reference logs and continues, MFA/alignment/mixins.py:308-314).
 
-        Software pipeline over batches: launch b (asynchronous), prepare b + 1 on the host while the device works, then
-        collect b."""
+        Software pipeline over batches: the graphs of batch b + 1 compile on a worker thread while the main thread packs,
+        launches and collects batch b.  ``first_compile``: the future of batch 0's compilation when the caller started it
+        earlier (``_align`` does, under the CMVN pass)."""
         import torch
 
         eng = self.engine
@@ -385,15 +407,18 @@ class CorpusAligner:
         results: List[Optional[tuple]] = [None] * len(utts)
         kept: List[tuple] = []
         batches = self._batches(utts)
-        prep = self._prepare(utts, batches[0]) if batches else None
+        fut = first_compile if first_compile is not None else (self._submit_compile(utts, batches[0]) if batches else None)
         for b in range(len(batches)):
+            comp = fut.result()
+            # the next batch's graphs compile on the worker thread from here on — under this batch's packing, launch and
+            # collection (its staging pool was last read by batch b − 1, whose results have been collected)
+            fut = self._submit_compile(utts, batches[b + 1]) if b + 1 < len(batches) else None
+            prep = self._prepare(utts, comp)
             launched = self._launch(utts, prep, spk_ids, cmvn, d_lda, fmllr)
-            nxt = self._prepare(utts, batches[b + 1]) if b + 1 < len(batches) else None
             if prep["gidx"]:
                 self._general(utts, prep, spk_ids, cmvn, d_lda, fmllr, results, kept, want_feats)
             if launched is not None:
                 self._collect(utts, prep, launched, results, kept, want_feats)
-            prep = nxt
         return results, kept
 
     # ------------------------------------------------------------------ public
@@ -413,15 +438,18 @@ class CorpusAligner:
             return self._align(utts, speaker_adapted, make_ctm, previous_transforms)
         finally:
             self._mfcc_cache, self._mfcc_cache_bytes, self._mfcc_cache_on = {}, 0, False
+            self._batches_key = None
 
     def _align(self, utts, speaker_adapted, make_ctm, previous_transforms):
         import torch
 
+        batches = self._batches(utts)
+        first_compile = self._submit_compile(utts, batches[0]) if batches else None     # graphs compile under the CMVN pass
         spk_ids, cmvn = self.speaker_cmvn(utts)
         first_model = self.ali_am if self.ali_am is not None else self.am
         self._load(first_model)
         prev = None if previous_transforms is None else torch.from_numpy(np.asarray(previous_transforms, dtype=np.float32)).to(self.engine.device)
-        results, kept = self._pass(utts, spk_ids, cmvn, prev, want_feats=speaker_adapted)
+        results, kept = self._pass(utts, spk_ids, cmvn, prev, want_feats=speaker_adapted, first_compile=first_compile)
         self.transforms = None if previous_transforms is None else np.asarray(previous_transforms, dtype=np.float32)
         if speaker_adapted:
             if self.lda is None:
@@ -535,7 +563,7 @@ class CorpusAligner:
                             batches[id(b)] = b
             merged = intervals_native.IntervalBatch.concat(list(batches.values()))
             total = merged.n_utt
-            ub, ue = np.zeros(total), np.zeros(total)
+            ub_l, ue_l = [0.0] * total, [0.0] * total          # (plain lists: per-element numpy stores cost more than the loop)
             texts: List[Optional[str]] = [None] * total
             files = []
             for f in fast:
@@ -545,25 +573,19 @@ class CorpusAligner:
                     for n in ns:
                         b, k, text, begin, end = results[n]._lazy
                         m = base[id(b)] + k
-                        ub[m], ue[m], texts[m] = begin, end, text
+                        ub_l[m] = begin; ue_l[m] = end; texts[m] = text
                         ids.append(m)
                     spk.append((name, ids))
                 files.append(dict(duration=f["duration"], speakers=spk))
-            blobs, codes = self._extractor().write_files(merged, files, ub, ue, merged.relabels(texts), output_format, cleanup_silence)
-            todo = []
-            for f, blob, code in zip(fast, blobs, codes):
+            ub, ue = np.asarray(ub_l, dtype=np.float64), np.asarray(ue_l, dtype=np.float64)
+            paths = [str(out_dir / (f["name"] + ext)) for f in fast]
+            _none, codes = self._extractor().write_files(merged, files, ub, ue, merged.relabels(texts), output_format, cleanup_silence,
+                                                          paths=paths)          # text AND files by the library's threads
+            for f, path, code in zip(fast, paths, codes):
                 if code == 0:
-                    todo.append((out_dir / (f["name"] + ext), blob))
+                    written.append(Path(path))
                 elif code == 1:
                     slow.append(f)          # the Python writer raises the reference's error for this file
-            if len(todo) > 64:
-                from concurrent.futures import ThreadPoolExecutor
-                with ThreadPoolExecutor(8) as tp:
-                    list(tp.map(lambda pb: pb[0].write_bytes(pb[1]), todo))
-            else:
-                for path, blob in todo:
-                    path.write_bytes(blob)
-            written += [p_ for p_, _ in todo]
         sil = self.lexicon.silence_word
         for f in slow:
             speakers = {}

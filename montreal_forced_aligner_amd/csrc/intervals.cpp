@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <atomic>
 #include <charconv>
+#include <cerrno>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -556,6 +557,26 @@ MFA_IV_API int mfa_iv_write_files(mfa_iv *iv, int32_t format, int32_t cleanup_si
     if (jobs[f].err == 0 && !jobs[f].text.empty()) memcpy(out + out_off[f], jobs[f].text.data(), jobs[f].text.size());
   });
   return 0;
+}
+
+// The files themselves, written by n_threads threads: file f = out[out_off[f] .. out_off[f + 1]) to the path
+// paths[path_off[f] .. path_off[f + 1]) (UTF-8), skipped when file_err[f] != 0.  io_err[f] receives errno of a failed
+// open / write / close (0 = written or skipped).  Returns the number of files that failed.
+MFA_IV_API int mfa_iv_save_files(int32_t n_files, const int64_t *path_off, const char *paths, const char *out, const int64_t *out_off,
+                                 const int32_t *file_err, int32_t n_threads, int32_t *io_err) {
+  std::atomic<int> failed{0};
+  parallel_for(n_files, n_threads, [&](int64_t f) {
+    io_err[f] = 0;
+    if (file_err && file_err[f] != 0) return;
+    std::string path(paths + path_off[f], paths + path_off[f + 1]);
+    FILE *fp = fopen(path.c_str(), "wb");
+    if (!fp) { io_err[f] = errno ? errno : -1; failed.fetch_add(1); return; }
+    const size_t n = (size_t)(out_off[f + 1] - out_off[f]);
+    bool ok = n == 0 || fwrite(out + out_off[f], 1, n, fp) == n;
+    if (fclose(fp) != 0) ok = false;
+    if (!ok) { io_err[f] = errno ? errno : -1; failed.fetch_add(1); }
+  });
+  return failed.load();
 }
 
 }  // extern "C"

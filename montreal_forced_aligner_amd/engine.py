@@ -163,6 +163,8 @@ class AlignmentEngine:
         # two sets of pinned staging buffers: the host fills one while the copies out of the other are still in flight
         self._staging = [StagingPool(self.device), StagingPool(self.device)]
         self._staging_turn = 0
+        self._pcm_staging = [StagingPool(self.device), StagingPool(self.device)]   # PCM has its own pair: gathered while graphs compile
+        self._pcm_turn = 0
 
     def next_staging(self) -> StagingPool:
         """The staging pool to fill next (alternating; waits until the copies last started from it are done)."""
@@ -178,7 +180,10 @@ class AlignmentEngine:
         lens = np.fromiter((a.shape[0] for a in arrays), dtype=np.int64, count=n)
         so = np.zeros(n + 1, dtype=np.int64)
         np.cumsum(lens, out=so[1:])
-        pool = pool or self.next_staging()
+        if pool is None:
+            self._pcm_turn ^= 1
+            pool = self._pcm_staging[self._pcm_turn]
+            pool.wait()
         stage = pool.get("pcm", int(so[-1]), np.int16)
         ptrs = (C.c_void_p * max(n, 1))()
         keep = []
@@ -239,13 +244,33 @@ class AlignmentEngine:
     def num_frames(self, num_samples: int) -> int:
         return int(self.lib.mfa_mfcc_num_frames(self.ctx, num_samples))
 
+    def num_frames_array(self, num_samples: np.ndarray) -> np.ndarray:
+        """``num_frames`` for a whole batch (Kaldi NumFrames, both snip_edges settings), with the window and shift computed as
+        the library computes them (float32 arithmetic, mfa_mfcc_configure); checked against the library on first use."""
+        n = np.asarray(num_samples, dtype=np.int64)
+        if self.mfcc_opts is None:
+            self.configure_mfcc()
+        o = self.mfcc_opts
+        f32 = np.float32
+        win = int(f32(f32(o.sample_frequency) * f32(0.001)) * f32(o.frame_length_ms))
+        shift = int(f32(f32(o.sample_frequency) * f32(0.001)) * f32(o.frame_shift_ms))
+        snip = int(o.snip_edges)
+        out = np.where(n < win, 0, 1 + (n - win) // shift) if snip else (n + shift // 2) // shift
+        key = (win, shift, snip)
+        if getattr(self, "_nf_checked", None) != key:
+            for probe in (0, 1, win - 1, win, win + shift - 1, win + shift, 159999, 160000, 160001, 1 << 20):
+                ref = (0 if probe < win else 1 + (probe - win) // shift) if snip else (probe + shift // 2) // shift
+                if self.num_frames(probe) != ref:
+                    raise _lib.MfaHipError("num_frames_array disagrees with mfa_mfcc_num_frames")
+            self._nf_checked = key
+        return out.astype(np.int64)
+
     # ------------------------------------------------------------------ stages
     def _dev(self, a: np.ndarray) -> torch.Tensor:
         return torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
 
     def frame_offsets(self, sample_off: np.ndarray) -> np.ndarray:
-        lens = np.diff(sample_off)
-        frames = np.array([self.num_frames(int(n)) for n in lens], dtype=np.int64)
+        frames = self.num_frames_array(np.diff(sample_off))
         return np.concatenate([[0], np.cumsum(frames)]).astype(np.int64)
 
     def mfcc(self, pcm: torch.Tensor, sample_off: np.ndarray, frame_off: Optional[np.ndarray] = None):

@@ -57,6 +57,7 @@ SIGNATURES = {
     "mfa_iv_version": (C.c_int, []),
     "mfa_iv_extract_batch": (C.c_int, [_vp, _i32] + [_vp] * 5 + [_i32] + [_vp] * 3),
     "mfa_iv_fetch": (C.c_int, [_vp] * 9),
+    "mfa_iv_save_files": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "mfa_iv_write_files": (C.c_int, [_vp, _i32, _i32, _i32] + [_vp] * 18 + [_i32] + [_vp] * 4 + [_i32, _vp, _i64, _vp, _vp, _vp]),
 }
 _lib = None
@@ -291,7 +292,7 @@ class IntervalExtractor:
 
     def write_files(self, batch: IntervalBatch, files: Sequence[dict], utt_begin: np.ndarray, utt_end: np.ndarray,
                     relabel: Sequence[tuple] = (), output_format: str = "long_textgrid", cleanup_silence: bool = True,
-                    n_threads: Optional[int] = None):
+                    n_threads: Optional[int] = None, paths: Optional[Sequence[str]] = None):
         """``files``: one dict per output file — ``duration`` and ``speakers`` = [(speaker name, [utterance indices of the
         batch, corpus order])] in first-appearance order.  ``relabel``: (utterance index, transcript position, spelling) for
         out-of-vocabulary items.  Returns (list of bytes or None per file, list of codes: 0 ok, 1 needs the Python writer, 2 no
@@ -335,6 +336,15 @@ class IntervalExtractor:
             if rc != 0:
                 raise IntervalError((self.lib.mfa_iv_last_error(self.h) or b"error").decode())
             break
+        if paths is not None:
+            p_off, p_blob = _strings([str(p) for p in paths])
+            io_err = np.zeros(max(nf, 1), dtype=np.int32)
+            bad = self.lib.mfa_iv_save_files(nf, _ptr(p_off), _ptr(p_blob), _ptr(out), _ptr(out_off), _ptr(ferr),
+                                             _threads() if n_threads is None else int(n_threads), _ptr(io_err))
+            if bad:
+                k = int(np.flatnonzero(io_err[:nf])[0])
+                raise OSError(int(io_err[k]), os.strerror(int(io_err[k])) if io_err[k] > 0 else "write failed", str(paths[k]))
+            return None, ferr[:nf].tolist()
         mv = memoryview(out)
         texts = [bytes(mv[int(out_off[f]): int(out_off[f + 1])]) if ferr[f] == 0 else None for f in range(nf)]
         return texts, ferr[:nf].tolist()

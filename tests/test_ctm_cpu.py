@@ -198,6 +198,9 @@ def test_interval_stage_failure_concerns_one_utterance_only(fx, monkeypatch):
         def load_gmm(self, am):
             pass
 
+        def num_frames(self, n_samples):
+            return n_samples // 160
+
     tm = fx.mono_tm
     text = "this is the acoustic corpus"
     f = fx.mono_graph(text)
@@ -214,7 +217,8 @@ def test_interval_stage_failure_concerns_one_utterance_only(fx, monkeypatch):
                    np.full(3, nw, dtype=np.int32), np.full(3, r["like"], dtype=np.float32), np.zeros(3, dtype=np.int32))
     al = CorpusAligner(tm, fx.mono_am, fx.mono_tree, fx.mono_lex, engine=StubEngine())
     monkeypatch.setattr(al, "speaker_cmvn", lambda utts: ({"s": 0}, None))
-    monkeypatch.setattr(al, "_pass", lambda utts, spk_ids, cmvn, fmllr, want_feats=False: ([(bo, 0), (bo, 1), (bo, 2)], []))
+    monkeypatch.setattr(al, "_submit_compile", lambda utts, idx: None)
+    monkeypatch.setattr(al, "_pass", lambda utts, spk_ids, cmvn, fmllr, **kw: ([(bo, 0), (bo, 1), (bo, 2)], []))
     pcm = np.zeros(32000, dtype=np.int16)
     res = al.align([CorpusUtterance(f"s-{k}", "s", pcm, text) for k in range(3)])
     assert [x is not None for x in res] == [True, True, True] and al.failed == []
