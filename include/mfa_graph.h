@@ -55,6 +55,9 @@ typedef struct {
   const int32_t *id2state;          /* [n_tids + 1] transition-id → transition-state */
   int32_t n_tstates;
   const int32_t *self_loop_of;      /* [n_tstates + 1] transition-state → its self-loop transition-id, 0 = none */
+  int32_t determinize;              /* != 0: DeterminizeStarInLog + MinimizeEncoded between the HMM expansion and the self-loops,
+                                       as Kaldi's TrainingGraphCompiler::CompileGraph runs them (graph.py determinize_star_log,
+                                       minimize_encoded) */
 } mfa_gc_config;
 
 MFA_GC_API mfa_gc *mfa_gc_create(const mfa_gc_config *cfg);

@@ -8,6 +8,7 @@
 #include "../../include/mfa_graph.h"
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <cmath>
 #include <cstdarg>
@@ -17,6 +18,7 @@
 #include <memory_resource>
 #include <string>
 #include <thread>
+#include <tuple>
 #include <unordered_map>
 #include <vector>
 
@@ -176,7 +178,7 @@ struct UttResult {
 }  // namespace
 
 struct mfa_gc {
-  int width = 1, share = 1, sil = 0;
+  int width = 1, share = 1, sil = 0, determinize = 0;
   std::vector<int32_t> entry_word, entry_pron_off, phones;
   std::vector<mfa_gc_pron> prons;
   double cost_init_sil = 0, cost_init_eps = 0, final_ns = 0, final_s = 0;
@@ -364,6 +366,324 @@ void expand_context(const PhoneGraph &pg, int width, CtxGraph &cg, std::pmr::mem
   if (pg.has_fin[pg.start]) { cg.fin[0] = pg.fin[pg.start]; cg.has_fin[0] = 1; }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// graph.py determinize_star_log / minimize_encoded (Kaldi DeterminizeStarInLog + MinimizeEncoded between the HMM expansion
+// and AddSelfLoops), statement for statement where floating point is involved: ⊕ folds in the same order.
+constexpr double kKaldiDelta = 1.0 / 1024.0;
+struct DArc { int dst, tid, ol; double w; };
+
+inline double log_add(double a, double b) {
+  const double inf = std::numeric_limits<double>::infinity();
+  if (a == inf) return b;
+  if (b == inf) return a;
+  return (a < b ? a : b) - std::log1p(std::exp(-std::fabs(a - b)));
+}
+
+struct DElem {
+  int q; int slen; int s[2]; double w;
+};
+inline bool key_less(const DElem &a, const DElem &b) {      // Python: sorted((state, string tuple))
+  if (a.q != b.q) return a.q < b.q;
+  const int n = std::min(a.slen, b.slen);
+  for (int i = 0; i < n; i++) if (a.s[i] != b.s[i]) return a.s[i] < b.s[i];
+  return a.slen < b.slen;
+}
+inline bool key_equal(const DElem &a, const DElem &b) {
+  if (a.q != b.q || a.slen != b.slen) return false;
+  for (int i = 0; i < a.slen; i++) if (a.s[i] != b.s[i]) return false;
+  return true;
+}
+
+// in: G0 as (head, pool) chains + finals; out: deterministic graph, start 0.  false: unsupported (caller keeps G0).
+// Most subsets are single states with nothing pending (the graph is deterministic already except where pronunciation
+// variants share a prefix and where a word's last phone goes two ways): those take a path without any subset machinery —
+// the same result, 0.0 + w and ⊕ with the neutral element being exact.
+template <class Pool>
+bool determinize_star_log(const Pool &pool, const std::vector<int> &head, const std::vector<double> &fin, const std::vector<char> &has_fin,
+                          int start, std::vector<DArc> &out_arcs, std::vector<int> &out_off, std::vector<double> &out_fin,
+                          std::vector<char> &out_has) {
+  const double inf = std::numeric_limits<double>::infinity();
+  out_off.assign(1, 0);
+  std::vector<DElem> store;                                  // all subsets' elements, back to back
+  struct Sub { int first, n; };
+  std::vector<Sub> subsets;
+  std::vector<int> single_id(head.size(), -1);               // id of the subset {(q, "", 0)}
+  std::unordered_map<uint64_t, std::vector<int>> ids;        // other subsets: hash of the (state, string) signature → ids, creation order
+  auto sig_hash = [](const DElem *v, int n) {
+    uint64_t h = 0x9E3779B97F4A7C15ull;
+    for (int k = 0; k < n; k++) {
+      const DElem &e = v[k];
+      h = (h ^ (uint64_t)(uint32_t)e.q) * 0x100000001B3ull;
+      h = (h ^ (uint64_t)(uint32_t)e.slen) * 0x100000001B3ull;
+      for (int i = 0; i < e.slen; i++) h = (h ^ (uint64_t)(uint32_t)e.s[i]) * 0x100000001B3ull;
+    }
+    return h;
+  };
+  auto is_plain = [](const DElem *v, int n) { return n == 1 && v[0].slen == 0 && v[0].w == 0.0; };
+  auto lookup_or_add = [&](const DElem *v, int n) -> int {
+    if (is_plain(v, n)) {
+      int &id = single_id[v[0].q];
+      if (id < 0) { id = (int)subsets.size(); subsets.push_back(Sub{(int)store.size(), 1}); store.push_back(v[0]); }
+      return id;
+    }
+    const uint64_t h = sig_hash(v, n);
+    auto it = ids.find(h);
+    if (it != ids.end())
+      for (int cid : it->second) {
+        const Sub &c = subsets[cid];
+        if (c.n != n) continue;
+        bool ok = true;
+        for (int k = 0; k < n && ok; k++) ok = key_equal(store[c.first + k], v[k]) && std::fabs(store[c.first + k].w - v[k].w) <= kKaldiDelta;
+        if (ok) return cid;
+      }
+    const int id = (int)subsets.size();
+    subsets.push_back(Sub{(int)store.size(), n});
+    store.insert(store.end(), v, v + n);
+    ids[h].push_back(id);
+    return id;
+  };
+  {
+    DElem s0{start, 0, {0, 0}, 0.0};
+    lookup_or_add(&s0, 1);
+  }
+  struct Tr { int tid; DElem e; };
+  std::vector<Tr> trs;
+  std::vector<DElem> grp, sub, P;
+  std::vector<DArc> row;
+  for (size_t qi = 0; qi < subsets.size(); qi++) {
+    P.assign(store.begin() + subsets[qi].first, store.begin() + subsets[qi].first + subsets[qi].n);   // (copy: `store` grows below)
+    if (is_plain(P.data(), (int)P.size())) {
+      const int q = P[0].q;
+      const bool f_ok = (size_t)q < has_fin.size() && has_fin[q] && fin[q] != inf;
+      out_fin.push_back(f_ok ? 0.0 + fin[q] : inf); out_has.push_back(f_ok);
+      row.clear();
+      bool distinct = true;
+      for (int a = head[q]; a >= 0; a = pool[a].next) {
+        for (const DArc &r : row) if (r.tid == pool[a].tid) { distinct = false; break; }
+        if (!distinct) break;
+        row.push_back(DArc{pool[a].dst, pool[a].tid, pool[a].ol, 0.0 + pool[a].w});
+      }
+      if (distinct) {
+        std::stable_sort(row.begin(), row.end(), [](const DArc &x, const DArc &y) { return x.tid < y.tid; });
+        for (DArc &r : row) {
+          DElem ne{r.dst, 0, {0, 0}, 0.0};
+          r.dst = lookup_or_add(&ne, 1);
+        }
+        out_arcs.insert(out_arcs.end(), row.begin(), row.end());
+        out_off.push_back((int)out_arcs.size());
+        continue;
+      }
+      out_fin.pop_back(); out_has.pop_back();
+    }
+    double f = inf;
+    trs.clear();
+    for (const DElem &el : P) {
+      if ((size_t)el.q < has_fin.size() && has_fin[el.q] && fin[el.q] != inf) {
+        if (el.slen) return false;
+        f = log_add(f, el.w + fin[el.q]);
+      }
+      for (int a = head[el.q]; a >= 0; a = pool[a].next) {
+        DElem ne = el;
+        ne.q = pool[a].dst;
+        if (pool[a].ol) {
+          if (ne.slen >= 2) return false;
+          ne.s[ne.slen++] = pool[a].ol;
+        }
+        ne.w = el.w + pool[a].w;
+        trs.push_back(Tr{pool[a].tid, ne});
+      }
+    }
+    out_fin.push_back(f); out_has.push_back(f != inf);
+    std::stable_sort(trs.begin(), trs.end(), [](const Tr &x, const Tr &y) { return x.tid < y.tid; });
+    for (size_t i = 0; i < trs.size();) {
+      size_t j = i;
+      while (j < trs.size() && trs[j].tid == trs[i].tid) j++;
+      grp.clear();
+      for (size_t k = i; k < j; k++) grp.push_back(trs[k].e);
+      std::stable_sort(grp.begin(), grp.end(), key_less);       // equal keys stay in encounter order: ⊕ folds left to right
+      sub.clear();
+      for (size_t k = 0; k < grp.size(); k++) {
+        if (!sub.empty() && key_equal(sub.back(), grp[k])) sub.back().w = log_add(sub.back().w, grp[k].w);
+        else sub.push_back(grp[k]);
+      }
+      double tot = inf;
+      for (const DElem &e : sub) tot = log_add(tot, e.w);
+      int n_common = sub[0].slen;
+      for (const DElem &e : sub) n_common = std::min(n_common, e.slen);
+      for (int c = 0; c < n_common; c++) {
+        bool same = true;
+        for (const DElem &e : sub) if (e.s[c] != sub[0].s[c]) { same = false; break; }
+        if (!same) { n_common = c; break; }
+      }
+      if (n_common > 1) return false;
+      const int ol = n_common == 1 ? sub[0].s[0] : 0;
+      for (DElem &e : sub) {
+        if (n_common == 1) { e.s[0] = e.s[1]; e.s[1] = 0; e.slen--; }
+        e.w = e.w - tot;
+      }
+      const int found = lookup_or_add(sub.data(), (int)sub.size());
+      out_arcs.push_back(DArc{found, trs[i].tid, ol, tot});
+      i = j;
+    }
+    out_off.push_back((int)out_arcs.size());
+  }
+  return true;
+}
+
+// strongly connected components, successors before predecessors (Tarjan, iterative); comp_off / comp_nodes: CSR
+void tarjan_sccs(const std::vector<DArc> &arcs, const std::vector<int> &off, std::vector<int> &comp_off, std::vector<int> &comp_nodes) {
+  const int n = (int)off.size() - 1;
+  std::vector<int> index(n, -1), low(n, 0), stack;
+  std::vector<char> on(n, 0);
+  std::vector<std::pair<int, int>> work;
+  int counter = 0;
+  comp_off.assign(1, 0);
+  for (int root = 0; root < n; root++) {
+    if (index[root] != -1) continue;
+    work.push_back({root, off[root]});
+    index[root] = low[root] = counter++;
+    stack.push_back(root); on[root] = 1;
+    while (!work.empty()) {
+      const int u = work.back().first, k = work.back().second;
+      if (k < off[u + 1]) {
+        work.back().second = k + 1;
+        const int v = arcs[k].dst;
+        if (index[v] == -1) {
+          index[v] = low[v] = counter++;
+          stack.push_back(v); on[v] = 1;
+          work.push_back({v, off[v]});
+        } else if (on[v]) low[u] = std::min(low[u], index[v]);
+      } else {
+        work.pop_back();
+        if (!work.empty()) { const int p = work.back().first; low[p] = std::min(low[p], low[u]); }
+        if (low[u] == index[u]) {
+          for (;;) {
+            const int v = stack.back(); stack.pop_back(); on[v] = 0;
+            comp_nodes.push_back(v);
+            if (v == u) break;
+          }
+          comp_off.push_back((int)comp_nodes.size());
+        }
+      }
+    }
+  }
+}
+
+// graph.py minimize_encoded on the CSR graph (rows are sorted by transition-id and hold every transition-id once — the
+// output of determinize_star_log — so "the same set of arcs" is "the same row").
+void minimize_encoded(std::vector<DArc> &arcs, std::vector<int> &off, std::vector<double> &fin, std::vector<char> &has) {
+  auto quant = [](double w) { return std::floor(w / kKaldiDelta + 0.5) * kKaldiDelta; };
+  const int n = (int)off.size() - 1;
+  for (DArc &a : arcs) a.w = quant(a.w);
+  for (int u = 0; u < n; u++) if (has[u]) fin[u] = quant(fin[u]);
+  std::vector<int> rep(n);
+  for (int u = 0; u < n; u++) rep[u] = u;
+  auto bits = [](double w) { uint64_t b; memcpy(&b, &w, 8); return b; };
+  auto mix = [](uint64_t h, uint64_t x) { return (h ^ x) * 1099511628211ull; };
+  // open-addressing table: hash → first state with that signature (collisions: next slot)
+  size_t cap = 64;
+  while (cap < (size_t)n * 2 + 16) cap <<= 1;
+  std::vector<int> table(cap, -1);
+  std::vector<uint64_t> hashes(n, 0);
+  auto row_hash = [&](int u) {
+    uint64_t h = mix(1469598103934665603ull, has[u] ? 1 + bits(fin[u]) : 0);
+    for (int k = off[u]; k < off[u + 1]; k++) {
+      h = mix(h, ((uint64_t)(uint32_t)arcs[k].dst << 32) | (uint32_t)arcs[k].tid);
+      h = mix(h, (uint64_t)(uint32_t)arcs[k].ol);
+      h = mix(h, bits(arcs[k].w));
+    }
+    return h;
+  };
+  auto same_row = [&](int x, int y) {
+    if (has[x] != has[y] || (has[x] && bits(fin[x]) != bits(fin[y]))) return false;
+    if (off[x + 1] - off[x] != off[y + 1] - off[y]) return false;
+    for (int k = off[x], j = off[y]; k < off[x + 1]; k++, j++)
+      if (arcs[k].dst != arcs[j].dst || arcs[k].tid != arcs[j].tid || arcs[k].ol != arcs[j].ol || bits(arcs[k].w) != bits(arcs[j].w)) return false;
+    return true;
+  };
+  std::vector<int> comp_off, comp_nodes;
+  tarjan_sccs(arcs, off, comp_off, comp_nodes);
+  std::vector<int> pos(n, -1);
+  struct CompSig { std::vector<uint64_t> v; bool operator==(const CompSig &o) const { return v == o.v; } };
+  struct CompHash { size_t operator()(const CompSig &s) const { uint64_t h = 1469598103934665603ull; for (uint64_t x : s.v) h = (h ^ x) * 1099511628211ull; return (size_t)h; } };
+  std::unordered_map<CompSig, std::vector<int>, CompHash> seen_comp;   // cyclic components (a few per utterance)
+  for (size_t c = 0; c + 1 < comp_off.size(); c++) {
+    const int *comp = comp_nodes.data() + comp_off[c];
+    const int cn = comp_off[c + 1] - comp_off[c];
+    bool trivial = cn == 1;
+    if (trivial) for (int k = off[comp[0]]; k < off[comp[0] + 1]; k++) if (arcs[k].dst == comp[0]) { trivial = false; break; }
+    if (trivial) {
+      const int u = comp[0];
+      for (int k = off[u]; k < off[u + 1]; k++) arcs[k].dst = rep[arcs[k].dst];
+      const uint64_t h = row_hash(u);
+      size_t slot = (size_t)(h >> 11) & (cap - 1);
+      for (;;) {
+        const int t = table[slot];
+        if (t < 0) { table[slot] = u; hashes[u] = h; break; }
+        if (hashes[t] == h && same_row(t, u)) { rep[u] = t; break; }
+        slot = (slot + 1) & (cap - 1);
+      }
+      continue;
+    }
+    // a cyclic component (the inner states of a silence model): canonical order by the states' own (symbol) sets
+    for (int i = 0; i < cn; i++) pos[comp[i]] = -2;                  // "inside", position assigned below
+    auto own_less = [&](int x, int y) {                              // tuple(sorted((tid, ol, w))): rows are sorted by tid already
+      int k = off[x], j = off[y];
+      for (; k < off[x + 1] && j < off[y + 1]; k++, j++) {
+        if (arcs[k].tid != arcs[j].tid) return arcs[k].tid < arcs[j].tid;
+        if (arcs[k].ol != arcs[j].ol) return arcs[k].ol < arcs[j].ol;
+        if (arcs[k].w != arcs[j].w) return arcs[k].w < arcs[j].w;
+      }
+      return (off[x + 1] - off[x]) < (off[y + 1] - off[y]);
+    };
+    std::vector<int> ordered(comp, comp + cn);
+    std::sort(ordered.begin(), ordered.end(), own_less);
+    bool distinct = true;
+    for (size_t i = 1; i < ordered.size(); i++) if (!own_less(ordered[i - 1], ordered[i])) { distinct = false; break; }
+    for (int i = 0; i < cn; i++)
+      for (int k = off[comp[i]]; k < off[comp[i] + 1]; k++) if (pos[arcs[k].dst] != -2 && pos[arcs[k].dst] < 0) arcs[k].dst = rep[arcs[k].dst];
+    if (distinct) {
+      for (size_t i = 0; i < ordered.size(); i++) pos[ordered[i]] = (int)i;
+      CompSig sg;
+      std::vector<std::array<uint64_t, 4>> row;
+      for (int u : ordered) {
+        row.clear();
+        for (int k = off[u]; k < off[u + 1]; k++) {
+          const DArc &a = arcs[k];
+          const bool in = pos[a.dst] >= 0;
+          // the Python tuple ((0, position) | (1, state), tid, ol, w): inside arcs first
+          row.push_back({((uint64_t)(in ? 0 : 1) << 32) | (uint32_t)(in ? pos[a.dst] : a.dst), (uint64_t)(uint32_t)a.tid, (uint64_t)(uint32_t)a.ol, bits(a.w)});
+        }
+        std::sort(row.begin(), row.end());
+        sg.v.push_back(has[u] ? 1 : 0); sg.v.push_back(has[u] ? bits(fin[u]) : 0); sg.v.push_back((uint64_t)row.size());
+        for (const auto &r : row) for (uint64_t x : r) sg.v.push_back(x);
+      }
+      auto ins = seen_comp.emplace(std::move(sg), ordered);
+      if (!ins.second) { const std::vector<int> &first = ins.first->second; for (size_t i = 0; i < ordered.size(); i++) rep[ordered[i]] = first[i]; }
+    }
+    for (int i = 0; i < cn; i++) pos[comp[i]] = -1;
+  }
+  // renumber breadth first from the start state's class, arc order kept
+  std::vector<int> new_id(n, -1), order;
+  new_id[rep[0]] = 0; order.push_back(rep[0]);
+  for (size_t qi = 0; qi < order.size(); qi++)
+    for (int k = off[order[qi]]; k < off[order[qi] + 1]; k++) {
+      const int v = rep[arcs[k].dst];
+      if (new_id[v] < 0) { new_id[v] = (int)order.size(); order.push_back(v); }
+    }
+  std::vector<DArc> out;
+  std::vector<int> out_off(1, 0);
+  out.reserve(arcs.size());
+  std::vector<double> of(order.size(), 0.0); std::vector<char> oh(order.size(), 0);
+  for (size_t i = 0; i < order.size(); i++) {
+    const int u = order[i];
+    for (int k = off[u]; k < off[u + 1]; k++) out.push_back(DArc{new_id[rep[arcs[k].dst]], arcs[k].tid, arcs[k].ol, arcs[k].w});
+    out_off.push_back((int)out.size());
+    of[i] = fin[u]; oh[i] = has[u];
+  }
+  arcs.swap(out); off.swap(out_off); fin.swap(of); has.swap(oh);
+}
+
 // graph.py TrainingGraphCompiler._expand_hmm (+ add_transition_probs)
 bool expand_hmm(const mfa_gc &gc, const CtxGraph &cg, const float *neg_scaled, UttResult &r, std::string &err) {
   // "G0" (forward transitions only) as one arc pool with a per-node chain in insertion order — nodes are created on the fly
@@ -406,6 +726,24 @@ bool expand_hmm(const mfa_gc &gc, const CtxGraph &cg, const float *neg_scaled, U
       }
     }
   }
+  // finals of G0 (junction nodes only); then DeterminizeStarInLog + MinimizeEncoded when asked for
+  std::vector<double> g_fin(head.size(), 0.0);
+  std::vector<char> g_has(head.size(), 0);
+  for (int u = 0; u < J; u++) if (cg.has_fin[u]) { g_fin[u] = cg.fin[u]; g_has[u] = 1; }
+  int g_start = cg.start;
+  if (gc.determinize) {
+    std::vector<DArc> d_arcs;
+    std::vector<int> d_off;
+    std::vector<double> d_fin; std::vector<char> d_has;
+    if (determinize_star_log(pool, head, g_fin, g_has, cg.start, d_arcs, d_off, d_fin, d_has)) {
+      minimize_encoded(d_arcs, d_off, d_fin, d_has);
+      const size_t dn = d_off.size() - 1;
+      pool.clear(); head.assign(dn, -1); tail.assign(dn, -1);
+      for (size_t u = 0; u < dn; u++) for (int k = d_off[u]; k < d_off[u + 1]; k++) add_arc((int)u, d_arcs[k].dst, d_arcs[k].tid, d_arcs[k].ol, d_arcs[k].w);
+      g_fin.swap(d_fin); g_has.swap(d_has);
+      g_start = 0;
+    }
+  }
   // (node, incoming transition-state) → output state: open addressing, keys in first-seen order in `order`
   size_t cap = 64;
   while (cap < pool.size() * 4 + 16) cap <<= 1;
@@ -423,7 +761,7 @@ bool expand_hmm(const mfa_gc &gc, const CtxGraph &cg, const float *neg_scaled, U
       h = (h + 1) & (cap - 1);
     }
   };
-  find_or_add(cg.start, 0);
+  find_or_add(g_start, 0);
   r.offs.clear(); r.arcs.clear(); r.fin.clear();
   r.arcs.reserve(pool.size() * 2 + 16); r.offs.reserve(pool.size() + 16); r.fin.reserve(pool.size() + 16);
   r.offs.push_back(0);
@@ -441,7 +779,7 @@ bool expand_hmm(const mfa_gc &gc, const CtxGraph &cg, const float *neg_scaled, U
       if (sl != 0) r.arcs.push_back({sl, 0, 0.0f, (int32_t)qi});
     }
     r.offs.push_back((int64_t)r.arcs.size());
-    r.fin.push_back(node < J ? (cg.has_fin[node] ? (float)cg.fin[node] : inf) : inf);
+    r.fin.push_back(g_has[node] ? (float)g_fin[node] : inf);
   }
   if (neg_scaled)
     for (OutArc &a : r.arcs) if (a.il > 0) a.w = a.w + neg_scaled[a.il];
@@ -466,7 +804,7 @@ extern "C" {
 mfa_gc *mfa_gc_create(const mfa_gc_config *c) {
   if (!c || (c->context_width != 1 && c->context_width != 3) || c->n_entries < 0) return nullptr;
   mfa_gc *g = new mfa_gc();
-  g->width = c->context_width; g->share = c->share_suffixes; g->sil = c->sil_phone;
+  g->width = c->context_width; g->determinize = c->determinize; g->share = c->share_suffixes; g->sil = c->sil_phone;
   g->entry_word.assign(c->entry_word, c->entry_word + c->n_entries);
   g->entry_pron_off.assign(c->entry_pron_off, c->entry_pron_off + c->n_entries + 1);
   const int np_ = g->entry_pron_off.empty() ? 0 : g->entry_pron_off.back();

@@ -446,7 +446,11 @@ class TrainingGraphCompiler:
     """
 
     def __init__(self, transition_model: TransitionModel, tree: ContextDependency, lexicon_compiler: LexiconCompiler,
-                 use_g2p: bool = False, batch_size: int = 500):
+                 use_g2p: bool = False, batch_size: int = 500, determinize: bool = True):
+        # determinize: DeterminizeStarInLog + MinimizeEncoded between the HMM expansion and AddSelfLoops, as Kaldi's
+        # TrainingGraphCompiler::CompileGraph runs them (determinize_star_log / minimize_encoded below); False keeps the
+        # round-2 graphs (phone-level suffix sharing only).
+        self.determinize = bool(determinize)
         if use_g2p:
             raise NotImplementedError("use_g2p (character transcripts through a G2P lexicon) is outside the alignment path built here")
         self.tm = transition_model
@@ -539,10 +543,16 @@ class TrainingGraphCompiler:
                 for (hs, dst, tid) in trans:
                     first = hs == 0
                     g0_arcs[node_of[hs]].append((node_of[dst], tid, ol if first else 0, w if first else 0.0))
+        g0_final = {u: w for u, w in cg.final.items() if u < J}
+        g0_start = cg.start
+        if self.determinize:
+            det = determinize_star_log(g0_arcs, g0_final, g0_start)
+            if det is not None:                 # (None: an output string longer than one label would be needed — kept as it was)
+                g0_arcs, g0_final = minimize_encoded(*det)
+                g0_start = 0
         # phase 2: split states by incoming transition-state (MakePrecedingInputSymbolsSameClass) and add self loops.
-        n0 = len(g0_arcs)
-        key2id: Dict[Tuple[int, int], int] = {(cg.start, 0): 0}
-        order: List[Tuple[int, int]] = [(cg.start, 0)]
+        key2id: Dict[Tuple[int, int], int] = {(g0_start, 0): 0}
+        order: List[Tuple[int, int]] = [(g0_start, 0)]
         out_arcs: List[List[Tuple[int, int, float, int]]] = []
         finals: List[float] = []
         qi = 0
@@ -561,7 +571,7 @@ class TrainingGraphCompiler:
                 if sl != 0:
                     arcs.append((sl, 0, 0.0, key2id[(node, ts_in)]))
             out_arcs.append(arcs)
-            finals.append(cg.final.get(node, float("inf")) if node < J else float("inf"))
+            finals.append(g0_final.get(node, float("inf")))
         S = len(out_arcs)
         offs = np.zeros(S + 1, dtype=np.int64)
         for s in range(S):
@@ -573,6 +583,199 @@ class TrainingGraphCompiler:
                 arcs_np[k] = (il, ol, w, nx)
                 k += 1
         return Fst(0, offs, arcs_np, np.asarray(finals, dtype=np.float32))
+
+
+KALDI_DELTA = 1.0 / 1024.0          # fst::kDelta: weight equality in DeterminizeStar, quantum of MinimizeEncoded
+
+
+def _log_add(a: float, b: float) -> float:
+    """⊕ of the log semiring: −ln(e^−a + e^−b)."""
+    if a == float("inf"):
+        return b
+    if b == float("inf"):
+        return a
+    return (a if a < b else b) - math.log1p(math.exp(-abs(a - b)))
+
+
+def determinize_star_log(arcs, final, start, delta: float = KALDI_DELTA):
+    """Kaldi DeterminizeStarInLog on the forward-transition graph (fstext/determinize-star-inl.h, called from
+    TrainingGraphCompiler::CompileGraph — reached through kalpy's TrainingGraphCompiler, MFA/alignment/multiprocessing.py:
+    537-571): weighted subset construction over the input labels (transition-ids) in the LOG semiring.  A subset is a list of
+    (state, residual output string, residual weight); an input label's arc carries ⊕ of its elements' weights and the
+    longest common prefix of their output strings, the elements keep the remainders; elements that meet in the same state
+    with the same string are ⊕-added; subsets are identified up to ``delta`` on their weights.  The input here has no
+    ε input labels, so the "star" (ε-closure) part of the algorithm has nothing to do.
+
+    arcs: per node a list of (dst, transition-id, output label or 0, weight); final: {node: weight}.  Returns
+    (arcs, final) of the deterministic graph, start state 0, states numbered in order of discovery (breadth first), arcs of a
+    state by ascending transition-id — or None when an arc would have to emit more than one output label (then ε-input arcs
+    would be needed, as DeterminizeStar creates them) or a residual string grows beyond two labels; transcripts through a
+    lexicon never get there (a word's label sits on its first phone and is agreed on at once)."""
+    inf = float("inf")
+    first = ((start, (), 0.0),)
+    ids = {((start, ()),): [(first, 0)]}          # (state, string) signature → [(subset, id)] (weights compared up to delta)
+    subsets = [first]
+    out_arcs: List[List[Tuple[int, int, int, float]]] = []
+    out_final: Dict[int, float] = {}
+    qi = 0
+    while qi < len(subsets):
+        P = subsets[qi]
+        qi += 1
+        fin = inf
+        by_label: Dict[int, List[Tuple[int, tuple, float]]] = {}
+        for (q, s, w) in P:
+            fq = final.get(q)
+            if fq is not None and fq != inf:
+                if s:
+                    return None
+                fin = _log_add(fin, w + fq)
+            for (dst, tid, ol, aw) in arcs[q]:
+                s2 = s + (ol,) if ol else s
+                if len(s2) > 2:
+                    return None
+                by_label.setdefault(tid, []).append((dst, s2, w + aw))
+        if fin != inf:
+            out_final[qi - 1] = fin
+        row = []
+        for tid in sorted(by_label):
+            elems: Dict[Tuple[int, tuple], float] = {}
+            for (dst, s2, w2) in by_label[tid]:          # same state, same string: ⊕
+                k = (dst, s2)
+                elems[k] = _log_add(elems[k], w2) if k in elems else w2
+            keys = sorted(elems)
+            tot = inf
+            for k in keys:
+                tot = _log_add(tot, elems[k])
+            strings = [k[1] for k in keys]
+            n_common = min(len(x) for x in strings)
+            for j in range(n_common):
+                if any(x[j] != strings[0][j] for x in strings):
+                    n_common = j
+                    break
+            if n_common > 1:
+                return None
+            subset = tuple((k[0], k[1][n_common:], elems[k] - tot) for k in keys)
+            sig = tuple((q, x) for (q, x, _w) in subset)
+            found = None
+            for cand, cid in ids.get(sig, ()):
+                if all(abs(a[2] - b[2]) <= delta for a, b in zip(cand, subset)):
+                    found = cid
+                    break
+            if found is None:
+                found = len(subsets)
+                subsets.append(subset)
+                ids.setdefault(sig, []).append((subset, found))
+            row.append((found, tid, strings[0][0] if n_common == 1 else 0, tot))
+        out_arcs.append(row)
+    return out_arcs, out_final
+
+
+def _sccs(arcs) -> List[List[int]]:
+    """Strongly connected components, successors before predecessors (Tarjan, iterative)."""
+    n = len(arcs)
+    index = [-1] * n
+    low = [0] * n
+    on = [False] * n
+    stack: List[int] = []
+    out: List[List[int]] = []
+    counter = 0
+    for root in range(n):
+        if index[root] != -1:
+            continue
+        work = [(root, 0)]
+        index[root] = low[root] = counter
+        counter += 1
+        stack.append(root)
+        on[root] = True
+        while work:
+            u, k = work[-1]
+            if k < len(arcs[u]):
+                work[-1] = (u, k + 1)
+                v = arcs[u][k][0]
+                if index[v] == -1:
+                    index[v] = low[v] = counter
+                    counter += 1
+                    stack.append(v)
+                    on[v] = True
+                    work.append((v, 0))
+                elif on[v]:
+                    low[u] = min(low[u], index[v])
+            else:
+                work.pop()
+                if work:
+                    p = work[-1][0]
+                    low[p] = min(low[p], low[u])
+                if low[u] == index[u]:
+                    comp = []
+                    while True:
+                        v = stack.pop()
+                        on[v] = False
+                        comp.append(v)
+                        if v == u:
+                            break
+                    out.append(comp)
+    return out
+
+
+def minimize_encoded(arcs, final, delta: float = KALDI_DELTA):
+    """Kaldi MinimizeEncoded (fstext/fstext-utils-inl.h): weights quantised to multiples of ``delta`` (QuantizeMapper:
+    floor(w / delta + 0.5) · delta), every (input label, output label, weight) triple read as one symbol, and the resulting
+    unweighted acceptor minimised — states with the same final weight and the same set of (symbol, successor class) are one
+    state.  The graph is acyclic except inside silence models (MFA's 5-state silence topology moves back and forth between
+    its inner states), so the classes are found bottom-up over the strongly connected components: a single state by its
+    (final, arcs) signature; a cyclic component as a whole — its states ordered by their own (symbol) sets, arcs that stay
+    inside written as positions — and two components with the same signature are merged state by state.  (Never merges
+    states that differ; a component whose states cannot be told apart by their symbols is left alone.)
+    Start state 0; states renumbered breadth first, arc order kept."""
+    def quant(w: float) -> float:
+        return math.floor(w / delta + 0.5) * delta
+
+    n = len(arcs)
+    arcs = [[(dst, tid, ol, quant(w)) for (dst, tid, ol, w) in row] for row in arcs]
+    final = {u: quant(w) for u, w in final.items()}
+    rep = list(range(n))
+    seen: Dict[tuple, int] = {}
+    seen_comp: Dict[tuple, List[int]] = {}
+    for comp in _sccs(arcs):
+        if len(comp) == 1 and all(v != comp[0] for (v, *_r) in arcs[comp[0]]):
+            u = comp[0]
+            row = []
+            for (v, tid, ol, w) in arcs[u]:
+                a = (rep[v], tid, ol, w)
+                if a not in row:
+                    row.append(a)
+            arcs[u] = row
+            sig = (final.get(u), tuple(sorted(row)))
+            rep[u] = seen.setdefault(sig, u)
+            continue
+        inside = set(comp)
+        own = {u: tuple(sorted((tid, ol, w) for (_v, tid, ol, w) in arcs[u])) for u in comp}
+        ordered = sorted(comp, key=lambda u: own[u])
+        pos = {u: i for i, u in enumerate(ordered)}
+        for u in comp:
+            arcs[u] = [(v if v in inside else rep[v], tid, ol, w) for (v, tid, ol, w) in arcs[u]]
+        if len(set(own.values())) != len(comp):
+            continue
+        sig = tuple((final.get(u), tuple(sorted(((0, pos[v]) if v in inside else (1, v), tid, ol, w) for (v, tid, ol, w) in arcs[u])))
+                    for u in ordered)
+        first = seen_comp.setdefault(sig, ordered)
+        if first is not ordered:
+            for u, r in zip(ordered, first):
+                rep[u] = r
+    # renumber breadth first from the start state's class
+    new_id = {rep[0]: 0}
+    order = [rep[0]]
+    qi = 0
+    while qi < len(order):
+        u = order[qi]
+        qi += 1
+        for (v, *_r) in arcs[u]:
+            v = rep[v]
+            if v not in new_id:
+                new_id[v] = len(order)
+                order.append(v)
+    out = [[(new_id[rep[v]], tid, ol, w) for (v, tid, ol, w) in arcs[u]] for u in order]
+    return out, {new_id[u]: w for u, w in final.items() if u in new_id}
 
 
 @dataclass

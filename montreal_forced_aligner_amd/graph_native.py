@@ -50,7 +50,7 @@ class _Config(C.Structure):
                 ("n_entries", C.c_int32), ("entry_word", C.c_void_p), ("entry_pron_off", C.c_void_p), ("prons", C.c_void_p),
                 ("phones", C.c_void_p), ("cost_init_sil", C.c_double), ("cost_init_eps", C.c_double),
                 ("final_ns", C.c_double), ("final_s", C.c_double), ("n_tids", C.c_int32), ("id2state", C.c_void_p),
-                ("n_tstates", C.c_int32), ("self_loop_of", C.c_void_p)]
+                ("n_tstates", C.c_int32), ("self_loop_of", C.c_void_p), ("determinize", C.c_int32)]
 
 
 class _Model(C.Structure):
@@ -185,6 +185,7 @@ class NativeGraphCompiler:
         cfg.id2state = _ptr(self._id2state)
         cfg.n_tstates = int(self._self_loop_of.shape[0] - 1)
         cfg.self_loop_of = _ptr(self._self_loop_of)
+        cfg.determinize = 1 if getattr(compiler, "determinize", False) else 0
         self._h = self.lib.mfa_gc_create(C.byref(cfg))
         if not self._h:
             raise GraphCompileError("mfa_gc_create refused the configuration")

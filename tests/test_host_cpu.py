@@ -242,9 +242,10 @@ def test_suffix_sharing_keeps_every_path_of_the_phone_graph(fx):
     text = " ".join(fx.text.split()[:12])
     tm = fx.mono_tm
     scaled = tm.scaled_log_probs(1.0, 0.1)
-    gc_plain = G.TrainingGraphCompiler(tm, fx.mono_tree, plain)
+    # (determinize=False: the phone-level sharing on its own — DeterminizeStar + MinimizeEncoded would find the copies too)
+    gc_plain = G.TrainingGraphCompiler(tm, fx.mono_tree, plain, determinize=False)
     f_a = G.add_transition_probs(gc_plain.compile_fst(text), scaled)
-    f_b = fx.mono_graph(text)
+    f_b = G.add_transition_probs(G.TrainingGraphCompiler(tm, fx.mono_tree, lex, determinize=False).compile_fst(text), scaled)
     assert f_b.num_states < 0.7 * f_a.num_states
     x = fx.mono_feats(fx.pcm[: 16000 * 5])
     am = fx.mono_am
@@ -286,3 +287,79 @@ def test_export_graphs_takes_the_references_utterance_records(fx, tmp_path):
         gc.export_graphs(tmp_path / "c.ark", recs, interjection_words={"uh": 1.0})
     with pytest.raises(NotImplementedError):
         KA.TrainingGraphCompiler(fx.mono_tm, fx.mono_tree, fx.mono_lex, use_g2p=True)
+
+
+def test_determinize_star_log_and_minimize_encoded(fx):
+    """Kaldi's TrainingGraphCompiler determinises (DeterminizeStarInLog) and minimises (MinimizeEncoded, weights quantised to
+    1/1024) the HMM-level graph before the self-loops go in; graph.determinize_star_log / minimize_encoded restate the two.
+    Checked here on what makes them what they are: (a) a toy graph — shared input prefixes merge, the shared arc carries the
+    log-semiring sum of the alternatives, the alternatives the remainders, paths with identical labels are ⊕-added; (b) the
+    compiled graphs of the reference's dictionary — deterministic, smaller, every (transition-id sequence, word sequence)
+    of the undeterminised graph still there with its cost up to the quantum per arc; (c) alignment through both graphs: same
+    transition-ids, likelihood equal up to the quantisation."""
+    import math
+
+    from montreal_forced_aligner_amd import graph as G
+    from oracle import oracle as O
+    from tests import helpers
+
+    # (a) 0 -a/1-> 1 -b/0.5-> 3(final) ; 0 -a/2-> 2 -c/0-> 3 ; and a duplicate of the first path with other weights
+    arcs = [[(1, 7, 5, 1.0), (2, 7, 5, 2.0), (4, 7, 5, 3.0)], [(3, 8, 0, 0.5)], [(3, 9, 0, 0.0)], [], [(3, 8, 0, 0.25)]]
+    det = G.determinize_star_log(arcs, {3: 0.0}, 0)
+    assert det is not None
+    d_arcs, d_final = det
+    ladd = lambda a, b: -math.log(math.exp(-a) + math.exp(-b))          # noqa: E731
+    assert len(d_arcs[0]) == 1 and d_arcs[0][0][1:3] == (7, 5)           # one arc for label 7, the word label agreed at once
+    assert abs(d_arcs[0][0][3] - ladd(ladd(1.0, 2.0), 3.0)) < 1e-12
+    nxt = d_arcs[d_arcs[0][0][0]]
+    assert [a[1] for a in nxt] == [8, 9]                                  # by ascending input label
+    total_b = ladd(1.0 + 0.5, 3.0 + 0.25)                                 # the two paths spelling (7, 8) are one path now
+    assert abs(d_arcs[0][0][3] + nxt[0][3] + d_final[nxt[0][0]] - total_b) < 1e-12
+    assert abs(d_arcs[0][0][3] + nxt[1][3] + d_final[nxt[1][0]] - 2.0) < 1e-12
+    m_arcs, m_final = G.minimize_encoded(d_arcs, d_final)
+    assert len(m_arcs) == 3 and all(abs(w * 1024 - round(w * 1024)) < 1e-9 for row in m_arcs for (_d, _t, _o, w) in row)
+
+    # (b) compiled graphs
+    tm = fx.mono_tm
+    plain = G.TrainingGraphCompiler(tm, fx.mono_tree, fx.mono_lex, determinize=False)
+    det_c = G.TrainingGraphCompiler(tm, fx.mono_tree, fx.mono_lex, determinize=True)
+
+    def paths(f, max_arcs):
+        """(transition-ids without self-loops, words) → cost of every accepted path of at most ``max_arcs`` forward arcs
+        (the silence model's inner states form cycles, so the language is infinite: compared up to a length)."""
+        out = {}
+
+        def walk(s, tids, words, cost):
+            if len(tids) > max_arcs:
+                return
+            if np.isfinite(f.final[s]):
+                key = (tuple(tids), tuple(words))
+                c = cost + float(f.final[s])
+                out[key] = min(out.get(key, np.inf), c)
+            for a in f.arcs[f.arc_offsets[s]: f.arc_offsets[s + 1]]:
+                if tm.is_self_loop[a["ilabel"]]:
+                    continue
+                walk(int(a["nextstate"]), tids + [int(a["ilabel"])], words + ([int(a["olabel"])] if a["olabel"] else []), cost + float(a["weight"]))
+
+        walk(f.start, [], [], 0.0)
+        return out
+
+    for text, max_arcs in (("the", 13), ("this is", 18), ("i'm", 13)):
+        a, b = plain.compile_fst(text), det_c.compile_fst(text)
+        assert b.num_states < a.num_states
+        for s in range(b.num_states):                                     # deterministic on the input side
+            il = b.arcs["ilabel"][b.arc_offsets[s]: b.arc_offsets[s + 1]]
+            assert len(set(il.tolist())) == len(il)
+        pa, pb = paths(a, max_arcs), paths(b, max_arcs)
+        assert len(pa) > 3 and set(pa) == set(pb)
+        for k in pa:
+            assert abs(pa[k] - pb[k]) <= (len(k[0]) + 1) / 2048 + 1e-6, (text, k)
+    # (c) the same alignment through both
+    scaled = tm.scaled_log_probs(1.0, 0.1)
+    text = " ".join(fx.text.split()[:12])
+    x = fx.mono_feats(fx.pcm[: 16000 * 5])
+    ra = helpers.oracle_align_feats(tm, G.add_transition_probs(plain.compile_fst(text), scaled), x, fx.mono_am, beam=1e9, retry_beam=0.0)
+    rb = helpers.oracle_align_feats(tm, G.add_transition_probs(det_c.compile_fst(text), scaled), x, fx.mono_am, beam=1e9, retry_beam=0.0)
+    assert ra["status"] == 0 and rb["status"] == 0
+    assert np.array_equal(ra["ali"], rb["ali"]) and np.array_equal(ra["words"], rb["words"])
+    assert abs(ra["like"] - rb["like"]) < 10 * len(ra["ali"]) / 2048
