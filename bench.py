@@ -492,9 +492,10 @@ def main():
         prev_tf = None if mono else fm_np[np.array([int(s_[1:]) for s_ in spk_order]) % n_spk_total]
         ca = CorpusAligner(model.tm, model.am, model.tree, world_.lexicon, lda=lda_np, engine=eng,
                            options=AlignOptions(beam=args.beam, retry_beam=args.retry_beam, max_tokens=args.max_tokens,
-                                                bp_tokens_per_frame=args.bp_tokens, batch_frames=B * 1001),
+                                                bp_tokens_per_frame=args.bp_tokens, batch_frames=max(1024, B // 4) * 1001),
                            silence_phones=[pt.find("sil"), pt.find("spn")])
-        ca.align(utts_e2e, make_ctm=False, previous_transforms=prev_tf)       # warm-up at full size (pinned staging buffers, tables)
+        for _ in range(3):    # warm-up at full size: the pinned staging buffers come in rotating sets of two and three
+            ca.align(utts_e2e, make_ctm=False, previous_transforms=prev_tf)
         e2e = {}
         holder = {}
         dt_a = timed_loop(lambda: holder.__setitem__("res", ca.align(utts_e2e, make_ctm=False, previous_transforms=prev_tf)), 1)

@@ -155,6 +155,8 @@ class CorpusAligner:
         self._mfcc_cache_on = False
         self._intervals = None          # intervals_native.IntervalExtractor, built on first use
         self._worker = None             # one worker thread: the next batch's graphs compile under the current batch
+        self._out_pools = None          # pinned staging for the batches' outputs on their way back (two sets)
+        self._out_turn = 0
 
     def _boosted(self, am: DiagGmmModel) -> DiagGmmModel:
         import copy
@@ -314,7 +316,21 @@ class CorpusAligner:
         rows = np.array([spk_ids[utts[i].speaker] for i in idx], dtype=np.int32)
         feats = self._final_features(mfcc, fo, rows, cmvn, d_lda, fmllr)
         res = self._decode(prep["graphs"], feats, fo, self.opt.max_tokens, self.opt.bp_tokens_per_frame)
-        return dict(res=res, feats=feats, fo=fo, rows=rows)
+        # outputs start their way back right behind the kernels (asynchronous copies into pinned staging memory, one event):
+        # _collect waits for THIS batch only, while the next batch's kernels are already queued behind it
+        import torch
+        pool = self._out_pools[self._out_turn]
+        self._out_turn = (self._out_turn + 1) % len(self._out_pools)
+        host = {}
+        with torch.cuda.device(self.engine.device):
+            for k in ("status", "ali", "words", "n_words", "like"):
+                t = res[k]
+                view = pool.get("out_" + k, t.numel(), {torch.int32: np.int32, torch.float32: np.float32}[t.dtype])
+                torch.from_numpy(view).copy_(t, non_blocking=True)
+                host[k] = view
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.engine.device))
+        return dict(res=res, feats=feats, fo=fo, rows=rows, host=host, event=ev)
 
     def _general(self, utts, prep, spk_ids, cmvn, d_lda, fmllr, results, kept, want_feats):
         """FasterDecoder as Kaldi runs it, ProcessNonemitting included (mfa_align_general_batch): the slow, exact path for
@@ -350,9 +366,10 @@ class CorpusAligner:
         eng, o = self.engine, self.opt
         idx, fsts = prep["idx"], prep["fsts"]
         res, feats, fo, rows = launched["res"], launched["feats"], launched["fo"], launched["rows"]
-        status = res["status"].cpu().numpy()
-        ali, words = res["ali"].cpu().numpy(), res["words"].cpu().numpy()
-        n_words, like = res["n_words"].cpu().numpy(), res["like"].cpu().numpy()
+        launched["event"].synchronize()
+        h = launched["host"]          # (pinned staging views: copied out, the buffers are reused two batches later)
+        status, ali, words = h["status"].copy(), h["ali"].copy(), h["words"].copy()
+        n_words, like = h["n_words"].copy(), h["like"].copy()
         # Capacity overflows (status 3 tokens / 4 back-pointers) are not alignment failures: those utterances are decoded
         # again on their own with the hard upper bounds (one token per graph state), which cannot overflow.
         over = np.flatnonzero((status == 3) | (status == 4)).tolist()
@@ -403,22 +420,31 @@ class CorpusAligner:
         import torch
 
         eng = self.engine
+        if self._out_pools is None:
+            from .engine import StagingPool
+            self._out_pools = [StagingPool(eng.device), StagingPool(eng.device), StagingPool(eng.device)]
         d_lda = None if self.lda is None else torch.from_numpy(self.lda).to(eng.device)
         results: List[Optional[tuple]] = [None] * len(utts)
         kept: List[tuple] = []
         batches = self._batches(utts)
         fut = first_compile if first_compile is not None else (self._submit_compile(utts, batches[0]) if batches else None)
+        in_flight = None                      # (prep, launched) of the batch the device is working on
         for b in range(len(batches)):
             comp = fut.result()
-            # the next batch's graphs compile on the worker thread from here on — under this batch's packing, launch and
-            # collection (its staging pool was last read by batch b − 1, whose results have been collected)
+            # the next batch's graphs compile on the worker thread from here on — under this batch's packing and launch and
+            # the previous batch's collection (its staging pool was last read two batches ago)
             fut = self._submit_compile(utts, batches[b + 1]) if b + 1 < len(batches) else None
             prep = self._prepare(utts, comp)
             launched = self._launch(utts, prep, spk_ids, cmvn, d_lda, fmllr)
+            if in_flight is not None:         # collected while the device runs the batch launched just now
+                self._collect(utts, in_flight[0], in_flight[1], results, kept, want_feats)
+                in_flight = None
             if prep["gidx"]:
                 self._general(utts, prep, spk_ids, cmvn, d_lda, fmllr, results, kept, want_feats)
             if launched is not None:
-                self._collect(utts, prep, launched, results, kept, want_feats)
+                in_flight = (prep, launched)
+        if in_flight is not None:
+            self._collect(utts, in_flight[0], in_flight[1], results, kept, want_feats)
         return results, kept
 
     # ------------------------------------------------------------------ public

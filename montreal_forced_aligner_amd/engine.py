@@ -160,15 +160,16 @@ class AlignmentEngine:
         self.num_ceps = 13
         self.gmm: Optional[DiagGmmModel] = None
         self.slot_class: Optional[np.ndarray] = None
-        # two sets of pinned staging buffers: the host fills one while the copies out of the other are still in flight
-        self._staging = [StagingPool(self.device), StagingPool(self.device)]
+        # three sets of pinned staging buffers: the host fills one (the graphs of batch b + 2 compile into it) while the copies
+        # out of the second are in flight and the third still backs the host-side graphs of the batch being collected
+        self._staging = [StagingPool(self.device), StagingPool(self.device), StagingPool(self.device)]
         self._staging_turn = 0
         self._pcm_staging = [StagingPool(self.device), StagingPool(self.device)]   # PCM has its own pair: gathered while graphs compile
         self._pcm_turn = 0
 
     def next_staging(self) -> StagingPool:
-        """The staging pool to fill next (alternating; waits until the copies last started from it are done)."""
-        self._staging_turn ^= 1
+        """The staging pool to fill next (round robin; waits until the copies last started from it are done)."""
+        self._staging_turn = (self._staging_turn + 1) % len(self._staging)
         pool = self._staging[self._staging_turn]
         pool.wait()
         return pool

@@ -135,8 +135,8 @@ def test_alimdl_first_pass_two_model_transforms_and_fallback(engine, sat):
     al._load(al.am)
 
     class LosesSecondPass(CorpusAligner):
-        def _pass(self, utts_, spk_ids_, cmvn_, fmllr, want_feats=False):
-            res, kept = super()._pass(utts_, spk_ids_, cmvn_, fmllr, want_feats)
+        def _pass(self, utts_, spk_ids_, cmvn_, fmllr, want_feats=False, **kw):
+            res, kept = super()._pass(utts_, spk_ids_, cmvn_, fmllr, want_feats, **kw)
             if fmllr is not None:
                 res[2] = None
                 res[5] = None

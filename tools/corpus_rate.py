@@ -38,8 +38,9 @@ def main():
     base = [world.utterance(20000 + i, n_words=30) for i in range(pool)]
     utts = [CorpusUtterance(f"{base[i % pool][3]}-{i}", str(base[i % pool][3]), base[i % pool][0], base[i % pool][1]) for i in range(n)]
     al = CorpusAligner(model.tm, model.am, model.tree, world.lexicon, lda=lda, engine=eng,
-                       options=AlignOptions(batch_frames=4_096_000))
-    al.align(utts, make_ctm=want_ctm)                                       # warm-up at full size: context windows, pinned staging buffers
+                       options=AlignOptions(batch_frames=1_025_000))
+    for _ in range(3):                                                      # warm-up at full size, twice: context windows, both sets of pinned staging buffers
+        al.align(utts, make_ctm=want_ctm)
     torch.cuda.synchronize()
     pr = cProfile.Profile()
     t0 = time.time()
