@@ -160,7 +160,7 @@ MFA_API int mfa_debug_viterbi_stamps(mfa_ctx *ctx, void *d_stamps);
  *      (MFA/alignment/multiprocessing.py:846-853, :1311-1315; MFA/online/alignment.py:107) = Kaldi AddTransitionProbs
  *      (done by the host on the arc weights) + AlignUtteranceWrapper + FasterDecoder (beam, min_active 20,
  *      beam_delta 0.5, hash_ratio 2.0) with exactly Kaldi's pruning and tie-breaking order.
- * Graph u (epsilon-free): states state_off[u]..state_off[u+1]; d_arc_off[global_state] .. [global_state+1] index the
+ * Graph u (epsilon-free, or with d_state_nemit: see mfa_graph_batch): states state_off[u]..state_off[u+1]; d_arc_off[global_state] .. [global_state+1] index the
  * arc arrays RELATIVE to arc_base[u]; start state d_start[u]; d_final[global_state] (+inf = non-final).
  * Arcs (SoA): d_arc_next (local state), d_arc_weight (graph cost incl. transition probs), d_arc_col (column of the
  * utterance's log-likelihood matrix = position of pdf(tid) in its pdf list), d_arc_ilabel (transition-id),
@@ -177,6 +177,14 @@ typedef struct {
   const int32_t *d_arc_col;
   const int32_t *d_arc_ilabel;
   const int32_t *d_arc_olabel;
+  /* Graphs with EPSILON INPUT ARCS (ilabel 0; training graphs compiled by kalpy / Kaldi can hold them) on the wavefront-
+   * parallel decoder: NULL for epsilon-free batches; otherwise [total_states] = emitting arcs of every state, whose arcs
+   * must then be stored [emitting arcs | epsilon arcs], each kind in its original relative order (FasterDecoder's
+   * ProcessEmitting walks the emitting arcs of a state in order and skips the others, ProcessNonemitting the other way round:
+   * the interleaving never matters).  d_arc_col of an epsilon arc is ignored.  Requirement (the host checks it and routes
+   * anything else to mfa_align_general_batch): at most 64 emitting and at most 64 epsilon arcs per state.  The closure pops
+   * its stack one token at a time exactly as Kaldi's does, so neither ties nor negative epsilon weights change its result. */
+  const int32_t *d_state_nemit;
 } mfa_graph_batch;
 
 typedef struct {

@@ -35,7 +35,7 @@ class GraphBatch(C.Structure):
         ("n_utt", C.c_int32),
         ("d_state_off", C.c_void_p), ("d_arc_base", C.c_void_p), ("d_start", C.c_void_p), ("d_arc_off", C.c_void_p),
         ("d_final", C.c_void_p), ("d_arc_next", C.c_void_p), ("d_arc_weight", C.c_void_p), ("d_arc_col", C.c_void_p),
-        ("d_arc_ilabel", C.c_void_p), ("d_arc_olabel", C.c_void_p),
+        ("d_arc_ilabel", C.c_void_p), ("d_arc_olabel", C.c_void_p), ("d_state_nemit", C.c_void_p),
     ]
 
 

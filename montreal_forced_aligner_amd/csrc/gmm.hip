@@ -2372,6 +2372,34 @@ MFA_API int mfa_fst_first_frames(int32_t n_states, const int32_t *h_arc_off, con
   return 0;
 }
 
+// The same with epsilon input arcs (h_arc_pdf[a] < 0) counting for nothing: depth = fewest EMITTING arcs from the start state —
+// the first frame a token can sit on the state, FasterDecoder's ProcessNonemitting moving tokens along epsilon arcs within a
+// frame.  0-1 breadth-first search.
+static int fst_first_frames_eps(int32_t n_states, const int32_t *h_arc_off, const int32_t *h_arc_next, const int32_t *h_arc_pdf,
+                                int32_t start, int32_t *h_depth) {
+  if (n_states <= 0 || start < 0 || start >= n_states) return -1;
+  for (int s = 0; s < n_states; s++) h_depth[s] = INT32_MAX;
+  std::vector<int32_t> cur, nxt;
+  cur.push_back(start);
+  h_depth[start] = 0;
+  int32_t level = 0;
+  while (!cur.empty()) {
+    for (size_t q = 0; q < cur.size(); q++) {            // (cur grows while epsilon arcs are followed)
+      const int s = cur[q];
+      if (h_depth[s] != level) continue;                 // reached more cheaply in the meantime
+      for (int a = h_arc_off[s]; a < h_arc_off[s + 1]; a++) {
+        const int d = h_arc_next[a];
+        if (d < 0 || d >= n_states) return -1;
+        const int32_t nd = level + (h_arc_pdf[a] < 0 ? 0 : 1);
+        if (nd < h_depth[d]) { h_depth[d] = nd; (nd == level ? cur : nxt).push_back(d); }
+      }
+    }
+    cur.swap(nxt); nxt.clear();
+    level++;
+  }
+  return 0;
+}
+
 MFA_API int mfa_fst_last_depths(int32_t n_states, const int32_t *h_arc_off, const int32_t *h_arc_next, int32_t start,
                                 const int32_t *h_bfs_depth, int32_t *h_depth) {
   if (n_states <= 0 || start < 0 || start >= n_states) return -1;
@@ -2493,7 +2521,11 @@ MFA_API int mfa_build_score_plan_grouped(int32_t n_states, const int32_t *h_arc_
   if (n_states <= 0 || start < 0 || start >= n_states) return -1;
   const int n_arcs = h_arc_off[n_states];
   std::vector<int32_t> bfs(n_states), low(n_states);
-  if (mfa_fst_first_frames(n_states, h_arc_off, h_arc_next, start, bfs.data()) != 0) return -1;
+  bool has_eps = false;
+  for (int a = 0; a < n_arcs; a++) if (h_arc_pdf[a] < 0) { has_eps = true; break; }
+  // (an arc with pdf -1 is an epsilon input arc: no score column, no frame consumed)
+  if ((has_eps ? fst_first_frames_eps(n_states, h_arc_off, h_arc_next, h_arc_pdf, start, bfs.data())
+               : mfa_fst_first_frames(n_states, h_arc_off, h_arc_next, start, bfs.data())) != 0) return -1;
   if (mfa_fst_last_depths(n_states, h_arc_off, h_arc_next, start, bfs.data(), low.data()) < 0) return -1;
   for (int s = 0; s < n_states; s++) {
     h_state_depth[2 * s] = bfs[s] == INT32_MAX ? 0 : bfs[s];
@@ -2504,19 +2536,22 @@ MFA_API int mfa_build_score_plan_grouped(int32_t n_states, const int32_t *h_arc_
   std::vector<int32_t> src(n_arcs), order(n_arcs);
   for (int s = 0; s < n_states; s++)
     for (int a = h_arc_off[s]; a < h_arc_off[s + 1]; a++) src[a] = s;
+  order.clear();
   for (int a = 0; a < n_arcs; a++) {
-    order[a] = a;
+    if (h_arc_pdf[a] == -1) continue;                    // epsilon input arc
     if (h_arc_pdf[a] < 0 || h_arc_pdf[a] >= num_pdfs) return -2;
     if (h_pdf_class[h_arc_pdf[a]] < 0 || h_pdf_class[h_arc_pdf[a]] > 5) return -2;
+    order.push_back(a);
   }
+  const int n_emit = (int)order.size();
   std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
     if (h_arc_pdf[x] != h_arc_pdf[y]) return h_arc_pdf[x] < h_arc_pdf[y];
     return bfs[src[x]] < bfs[src[y]];
   });
   struct Col { int32_t pdf, first, last, cls; };
   std::vector<Col> cols;
-  std::vector<int32_t> col_of_arc(n_arcs);
-  for (int i = 0; i < n_arcs; i++) {
+  std::vector<int32_t> col_of_arc(n_arcs, -1);
+  for (int i = 0; i < n_emit; i++) {
     const int a = order[i], pdf = h_arc_pdf[a], d = bfs[src[a]];
     const bool fresh = cols.empty() || cols.back().pdf != pdf ||
                        (cluster_span > 0 && ((int64_t)d - cols.back().first > cluster_span));
@@ -2551,7 +2586,7 @@ MFA_API int mfa_build_score_plan_grouped(int32_t n_states, const int32_t *h_arc_
     h_class_counts[cl.cls]++;
     if (h_group_counts && cl.cls == 0) h_group_counts[grp]++;
   }
-  for (int a = 0; a < n_arcs; a++) h_arc_col[a] = rank[col_of_arc[a]];
+  for (int a = 0; a < n_arcs; a++) h_arc_col[a] = col_of_arc[a] >= 0 ? rank[col_of_arc[a]] : 0;
   *h_n_cols = n_cols;
   return 0;
 }

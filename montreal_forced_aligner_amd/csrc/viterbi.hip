@@ -65,6 +65,10 @@ struct VitParams {
   u32 *w_tokoff;                       // [total_frames + n_utt]
   u32 *w_hash;                         // [n_utt] hash size carried from pass 0 to the retry pass
   const uint4 *w_arcnext;              // [total_arcs] {next, (arc_off[next] << 7) | out-degree(next), col, weight}, built once per call
+  // Graphs with epsilon input arcs (g.d_state_nemit != NULL: every state's arcs are stored [emitting | epsilon] and the
+  // out-degree above counts the emitting ones): per state {first epsilon arc << 7 | number of epsilon arcs}, built once per call
+  const u32 *w_epsinfo;                // [n_utt * max_states] at (utt * max_states + state), or NULL
+  int eps_stride;                      // max_states
   unsigned long long *stamps;          // -DVIT_STAMPS builds: per-utterance phase cycles (mfa_debug_viterbi_stamps) or NULL
   int llcap;                           // score-row cache capacity in LDS (floats); rows longer than this are read from HBM
   // windowed (resumable) decoding — mfa_align_features_batch: one launch decodes frames [t_begin, t_end) of every utterance,
@@ -205,7 +209,8 @@ template <class StateP, class CostP>
 __device__ __forceinline__ void finalize_utterance(const VitParams &p, int utt, int lane, int status, int t, int T, int n,
                                                    StateP c_state, CostP c_cost, const float *final_w, const u64 *bp,
                                                    const u32 *tokoff, int64_t f0, int64_t ab_, const float *a_w,
-                                                   const int32_t *a_col, const float *ll, int P) {
+                                                   const int32_t *a_col, const float *ll, int P, bool eps = false,
+                                                   u64 bp_used = 0, u64 bp_cap = 0) {
   // ---------------- ReachedFinal / best final token (first in list order on ties)
   int32_t out_status = status;
   double bestc = INFINITY; u32 bpos = kEmpty;
@@ -239,11 +244,85 @@ __device__ __forceinline__ void finalize_utterance(const VitParams &p, int utt, 
     return;
   }
 
+  int32_t *ali = p.ali + f0;
+  const u32 fstate = c_state[bpos];
+  const int32_t *a_il = p.g.d_arc_ilabel + ab_, *a_ol = p.g.d_arc_olabel + ab_;
+  int32_t *words = p.words + f0;
+  float *flike = p.frame_like ? p.frame_like + f0 : nullptr;
+  u32 nw_out = 0;
+  double cost = 0.0; float w1 = 0.0f, w2 = 0.0f;
+  const float inv_scale = -1.0f / p.scale;
+  if (eps) {
+    // ---------------- graphs with epsilon input arcs: a frame's record may be followed by records of the SAME frame's list
+    // (tokens that came over epsilon arcs), so the path has T + E arcs.  Traceback writes their arc indices, back to front,
+    // into the unused tail of the utterance's back-pointer area; the forward pass below reads them in path order: words from
+    // any arc, a transition-id and a frame only from the emitting ones, the float accumulation of Kaldi's
+    // GetLinearSymbolSequence over all of them (an epsilon arc adds its weight and the rounding residue of its cost step).
+    u32 *path = (u32 *)(bp + bp_used);
+    const u64 pcap64 = (bp_cap - bp_used) * 2ull;
+    const u32 pcap = pcap64 > 0x7FFFFFFFull ? 0x7FFFFFFFu : (u32)pcap64;
+    u32 wpos = pcap, pos = bpos;
+    bool full = false;
+    for (int tt = T - 1; tt >= 0 && !full; tt--) {
+      const u32 to = tokoff[tt];
+      for (int hop = 0; ; hop++) {
+        const u64 rec = bp[(u64)to + pos];
+        const u32 arc = (u32)(rec >> 32);
+        pos = (u32)(rec & 0xFFFFFFFFu);
+        if (wpos == 0u || hop > 4096) { full = true; break; }
+        wpos--;
+        if (lane == 0) path[wpos] = arc;
+        if (a_il[arc] != 0) break;              // an emitting arc: `pos` now refers to the previous frame's list
+      }
+    }
+    // the initial list (InitDecoding's closure): records bp[0 .. n_init), the start token's carries arc 0xFFFFFFFF
+    for (int hop = 0; !full; hop++) {
+      const u64 rec = bp[pos];
+      const u32 arc = (u32)(rec >> 32);
+      if (arc == 0xFFFFFFFFu) break;
+      if (wpos == 0u || hop > 4096) { full = true; break; }
+      wpos--;
+      if (lane == 0) path[wpos] = arc;
+      pos = (u32)(rec & 0xFFFFFFFFu);
+    }
+    if (full) {
+      if (lane == 0) { p.status[utt] = ST_BP_OVERFLOW; p.n_words[utt] = 0; p.like[utt] = 0.0f; }
+      return;
+    }
+    __threadfence_block();
+    WSYNC();
+    const u32 L = pcap - wpos;
+    u32 frames_done = 0;
+    for (u32 c0 = 0; c0 < L; c0 += 64) {
+      const u32 i = c0 + (u32)lane;
+      int arc = 0, il = 0, ol = 0; float w = 0.0f, ac = 0.0f;
+      if (i < L) { arc = (int)path[wpos + i]; il = a_il[arc]; ol = a_ol[arc]; w = a_w[arc]; }
+      const u64 em = __ballot(i < L && il != 0);
+      const u32 tt = frames_done + (u32)__popcll(em & ((1ull << lane) - 1ull));
+      if (i < L && il != 0 && tt < (u32)T) ac = -(p.scale * ll[(size_t)tt * P + a_col[arc]]);
+      const u64 mask = __ballot(ol != 0);
+      const u32 wat = nw_out + (u32)__popcll(mask & ((1ull << lane) - 1ull));
+      if (ol != 0 && wat < (u32)T) words[wat] = ol;
+      nw_out += (u32)__popcll(mask);
+      float my_fl = 0.0f;
+      const int lim = (int)min(64u, L - c0);
+      for (int j = 0; j < lim; j++) {
+        float wj = __shfl(w, j), acj = __shfl(ac, j);
+        double nc = ((double)wj + cost) + (double)acj;
+        float tot = (float)(nc - cost);
+        float acost = tot - wj;
+        w1 += wj; w2 += acost;
+        cost = nc;
+        if (lane == j) my_fl = acost * inv_scale;
+      }
+      if (i < L && il != 0 && tt < (u32)T) { ali[tt] = il; if (flike) flike[tt] = my_fl; }
+      frames_done += (u32)__popcll(em);
+    }
+    if (nw_out > (u32)T) nw_out = (u32)T;
+  } else {
   // ---------------- traceback, arc index per frame parked in ali[].  The chain is pos → record → pos; the per-frame offsets
   // do not depend on it, so 64 of them are fetched at once and handed out by v_readlane: one dependent load per frame
   // instead of two (every lane walks the same chain on broadcast addresses; lane 0 stores).
-  int32_t *ali = p.ali + f0;
-  const u32 fstate = c_state[bpos];
   {
     u32 pos = bpos;
     for (int c0 = T - 1; c0 >= 0; c0 -= 64) {
@@ -261,12 +340,6 @@ __device__ __forceinline__ void finalize_utterance(const VitParams &p, int utt, 
   __threadfence_block();
   WSYNC();
   // ---------------- outputs: transition-ids, words (ordered compaction), likelihood (Kaldi's float accumulation)
-  const int32_t *a_il = p.g.d_arc_ilabel + ab_, *a_ol = p.g.d_arc_olabel + ab_;
-  int32_t *words = p.words + f0;
-  float *flike = p.frame_like ? p.frame_like + f0 : nullptr;
-  u32 nw_out = 0;
-  double cost = 0.0; float w1 = 0.0f, w2 = 0.0f;
-  const float inv_scale = -1.0f / p.scale;
   for (int c0 = 0; c0 < T; c0 += 64) {
     const int tt = c0 + lane;
     int arc = tt < T ? ali[tt] : 0;
@@ -293,6 +366,7 @@ __device__ __forceinline__ void finalize_utterance(const VitParams &p, int utt, 
     }
     if (tt < T) { ali[tt] = il; if (flike) flike[tt] = my_fl; }
   }
+  }
   if (lane == 0) {
     w1 += final_w[fstate];
     p.like[utt] = -(w1 + w2) / p.scale;
@@ -306,7 +380,10 @@ constexpr int kArcCache = 8;  // arcs per token kept in registers during expansi
 // kListsInLds: the two token lists (state, cost) live in LDS (fast path) or, for graphs/beams whose tables would not
 // fit in 160 KiB, in the per-utterance HBM workspace.
 // (waves_per_eu 4: at most 128 VGPRs, so that the 9.5 KB first tier really gets its 16 wavefronts per CU)
-template <bool kListsInLds>
+// kEps: the instantiation for batches that hold graphs with epsilon input arcs (g.d_state_nemit): every frame's emitting phase
+// is followed by FasterDecoder::ProcessNonemitting — see the closure block in the frame loop.  The epsilon-free instantiation
+// is the code it always was.
+template <bool kListsInLds, bool kEps = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void viterbi_kernel(VitParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x;
@@ -359,6 +436,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   float *ll_row = (float *)(cntord + C);      // [llcap] this frame's score row
   u32 *ctr = (u32 *)(ll_row + p.llcap);       // [2]: nslots, nstash
   u32 *bm = ctr + 4;                          // [kBmWords] columns scored for this window (speculative look-ahead only)
+  // epsilon closure (kEps): per slot its list position, the inverse, the winning epsilon arc, a scratch word for the winner
+  // vote, the state's epsilon-arc info; and the stack of ProcessNonemitting
+  u32 *e_pos = bm + kBmWords;                 // [N]
+  u32 *e_inv = e_pos + N;                     // [N]
+  u32 *e_arc = e_inv + N;                     // [N]
+  u32 *e_tmp = e_arc + N;                     // [N]
+  u32 *e_info = e_tmp + N;                    // [N]
+  u32 *e_stk = e_info + N;                    // [2N]
+  if constexpr (kEps) {
+    for (int i = lane; i < N; i += 64) e_tmp[i] = 0xFFFFFFFFu;
+  }
 
   u32 *st_a = p.w_stash_a + (size_t)utt * C;
   u32 *st_b = p.w_stash_b + (size_t)utt * C;
@@ -385,11 +473,105 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   u32 *park_an = p.w_state + (size_t)p.g.n_utt * 2 * NP + (size_t)utt * 2 * NP;
   double *park_cost = p.w_cost + (size_t)utt * 2 * NP;
   if (!resume) {
-    // InitDecoding: one token at the start state with cost 0 (graphs are epsilon-free: ProcessNonemitting is a no-op)
+    // InitDecoding: one token at the start state with cost 0 (epsilon-free graphs: ProcessNonemitting is a no-op)
     if (lane == 0) {
       const int s0 = start < 0 || start >= S ? 0 : start;
       l_state0[0] = (u32)s0; l_cost0[0] = 0.0;
-      l_an0[0] = S > 0 ? ((u32)arc_off[s0] << 7) | (u32)(arc_off[s0 + 1] - arc_off[s0]) : 0u;
+      u32 deg0 = S > 0 ? (u32)(arc_off[s0 + 1] - arc_off[s0]) : 0u;
+      if constexpr (kEps) { if (S > 0 && p.g.d_state_nemit) deg0 = (u32)p.g.d_state_nemit[so + s0]; }
+      l_an0[0] = S > 0 ? ((u32)arc_off[s0] << 7) | min(deg0, 127u) : 0u;
+    }
+    if constexpr (kEps) {
+      // ---------------- InitDecoding's ProcessNonemitting(cutoff = FLT_MAX), as Kaldi runs it: a stack, the popped token's
+      // epsilon arcs one after the other.  Once per utterance and a handful of tokens, so the wavefront simply walks the
+      // sequential algorithm (every lane the same scalars, lane 0 stores, destinations looked up by a ballot over the tokens
+      // created so far).  Tokens in creation order: s_state / s_cost (cost bits) / e_arc / e_inv (creator) / s_an; then the
+      // hash-list order (buckets by first occupancy, creation order inside) gives the initial list and its back-pointer
+      // records — bp[0 .. n): the start token's carries arc 0xFFFFFFFF, the others an epsilon arc and a position in this list.
+      if (status == ST_OK) {
+        u32 nc_ = 1u;
+        if (lane == 0) {
+          s_state[0] = (u32)start; s_cost[0] = (u64)__double_as_longlong(0.0); e_arc[0] = 0xFFFFFFFFu; e_inv[0] = 0u;
+          s_an[0] = l_an0[0]; e_stk[0] = 0u;
+        }
+        WSYNC();
+        u32 sp = 1u;
+        int guard = 0;
+        bool over = false;
+        while (sp > 0u && !over) {
+          if (++guard > 64 * N) { over = true; break; }
+          const u32 e = e_stk[sp - 1u];
+          sp--;
+          const double ce = __longlong_as_double((long long)s_cost[e]);
+          const u32 ei = p.w_epsinfo[(size_t)utt * p.eps_stride + s_state[e]];
+          const u32 n_eps = ei & 127u, first = ei >> 7;
+          for (u32 k = 0; k < n_eps && !over; k++) {
+            const uint4 rec = a_rec[first + k];
+            const u32 d = rec.x;
+            const double ncst = ce + (double)__uint_as_float(rec.w);
+            if (ncst > (double)3.4028234663852886e38f) continue;      // cutoff = numeric_limits<float>::max()
+            u32 found = kEmpty;
+            for (u32 c0 = 0; c0 < nc_; c0 += 64) {
+              const u32 c_ = c0 + (u32)lane;
+              const u64 hit = __ballot(c_ < nc_ && s_state[c_] == d);
+              if (hit) { found = c0 + (u32)__ffsll((long long)hit) - 1u; break; }
+            }
+            bool pushed = false; u32 who = 0u;
+            if (found == kEmpty) {
+              if (nc_ >= (u32)N) { over = true; break; }
+              if (lane == 0) {
+                s_state[nc_] = d; s_cost[nc_] = (u64)__double_as_longlong(ncst); e_arc[nc_] = first + k; e_inv[nc_] = e; s_an[nc_] = rec.y;
+              }
+              who = nc_; nc_++; pushed = true;
+            } else if (__longlong_as_double((long long)s_cost[found]) > ncst) {
+              if (lane == 0) { s_cost[found] = (u64)__double_as_longlong(ncst); e_arc[found] = first + k; e_inv[found] = e; }
+              who = found; pushed = true;
+            }
+            if (pushed) {
+              if (sp >= 2u * (u32)N) { over = true; break; }
+              if (lane == 0) e_stk[sp] = who;
+              sp++;
+            }
+            WSYNC();
+          }
+        }
+        if (over) status = ST_TOKEN_OVERFLOW;
+        else {
+          // hash-list order: position of token c = number of tokens whose (bucket's first creator, own index) is smaller
+          for (u32 c0 = 0; c0 < nc_; c0 += 64) {
+            const u32 c_ = c0 + (u32)lane;
+            if (c_ < nc_) {
+              const u32 bc = s_state[c_] % H;
+              u32 lead_c = c_;
+              for (u32 x = 0; x < c_; x++) if (s_state[x] % H == bc) { lead_c = x; break; }
+              u32 pos_ = 0;
+              for (u32 x = 0; x < nc_; x++) {
+                if (x == c_) continue;
+                const u32 bx = s_state[x] % H;
+                u32 lead_x = x;
+                for (u32 y = 0; y < x; y++) if (s_state[y] % H == bx) { lead_x = y; break; }
+                if (lead_x < lead_c || (lead_x == lead_c && x < c_)) pos_++;
+              }
+              e_pos[c_] = pos_;
+            }
+          }
+          WSYNC();
+          for (u32 c0 = 0; c0 < nc_; c0 += 64) {
+            const u32 c_ = c0 + (u32)lane;
+            if (c_ < nc_) {
+              const u32 pos_ = e_pos[c_];
+              l_state0[pos_] = s_state[c_];
+              l_cost0[pos_] = __longlong_as_double((long long)s_cost[c_]);
+              l_an0[pos_] = s_an[c_];
+              bp[pos_] = ((u64)e_arc[c_] << 32) | (u64)(c_ == 0u ? 0u : e_pos[e_inv[c_]]);
+            }
+          }
+          n = (int)nc_;
+          bp_used = nc_;
+          __threadfence_block();
+          WSYNC();
+        }
+      }
     }
   } else {
     const VitState vs = p.w_vstate[utt];
@@ -572,6 +754,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     bool bad_degree = false;
     bool used_stash = false;
     bool fast = false;
+    double frame_min = INFINITY;   // (kEps) cheapest candidate of the frame: next_weight_cutoff = frame_min + adaptive_beam
     // ---------------- fast path (the common case): at most 64 tokens and at most 64 candidates this frame → ONE
     // candidate per lane.  The running cutoff is then a plain exclusive prefix-min across lanes, every candidate does one
     // arc fetch, one slot lookup, one claim/lower, and the winner check comes straight from its registers.
@@ -607,6 +790,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         const double seed = wave_min_f64((valid && tok == best_i) ? nw : INFINITY);  // the best token's candidates
         const double m_incl = incl_scan_min(nw);
         const double local = min_f64(seed, shift_in_min(m_incl));
+        if constexpr (kEps) frame_min = min_f64(seed, readlane_f64(m_incl, 63));
         const bool created = valid && nw < local + (double)abeam;
         const u32 cidx = (tok << kArcBits) | k;
         STAMP(4);   // running cutoff (seed, prefix-min)
@@ -740,6 +924,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             if (sl[k] != kEmpty && dkey(nw[k]) == s_cost[sl[k]]) atomicMin(&s_W[sl[k]], ((u32)i << kArcBits) | (u32)k);
         }
       }
+      if constexpr (kEps) frame_min = run;
     }
     prefetch_next_row();
     // the stash lives in HBM: make its stores visible before other lanes read them back (workgroup-scope fence waits for
@@ -762,71 +947,214 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     }
     WSYNC();  // winners settled
     STAMP(6);   // general path + stash winners (zero when the fast path ran)
-    // ---------------- Kaldi list order of the new tokens
-    for (u32 j0 = 0; j0 < nslots; j0 += 64) {
-      u32 j = j0 + lane;
-      if (j < nslots) {
-        const u32 d = s_state[j], Fj = s_F[j];
-        u32 Fb = Fj, nb = 1, rank = 0;
-        if ((u32)S > H) {
-          nb = 0;
-          for (u32 m = d % H; m < (u32)S; m += H) {
-            u32 sm = find(m);
-            if (sm < (u32)N) {
-              u32 Fm = s_F[sm];
-              nb++;
-              if (Fm < Fj) rank++;
-              if (Fm < Fb) Fb = Fm;
+    // ---------------- Kaldi list order of the new tokens: for every slot the ordinal of its hash bucket's first creator and
+    // its rank inside the bucket; bucket sizes at the leaders' ordinals, then exclusive sums = where every bucket starts.
+    // (kEps: slots created by the epsilon closure carry ordinals past the candidates': s_F = 0x80000000 | k.)
+    auto ord_of = [&](u32 F) -> u32 {
+      if constexpr (kEps) { if (F >> 31) return cand_base + (F & 0x7FFFFFFFu); }
+      return t_cbase[F >> kArcBits] + (F & (kMaxArcsPerState - 1));
+    };
+    auto order_pass = [&](u32 ns, u32 n_ord) {
+      for (u32 j0 = 0; j0 < ns; j0 += 64) {
+        u32 j = j0 + lane;
+        if (j < ns) {
+          const u32 d = s_state[j], Fj = s_F[j];
+          u32 Fb = Fj, nb = 1, rank = 0;
+          if ((u32)S > H) {
+            nb = 0;
+            for (u32 m = d % H; m < (u32)S; m += H) {
+              u32 sm = find(m);
+              if (sm < (u32)N) {
+                u32 Fm = s_F[sm];
+                nb++;
+                if (Fm < Fj) rank++;
+                if (Fm < Fb) Fb = Fm;
+              }
             }
           }
+          const u32 ord_b = ord_of(Fb);
+          s_aux[j] = (rank << 24) | ord_b;
+          if (Fb == Fj) cntord[ord_b] = nb;
         }
-        const u32 ord_b = t_cbase[Fb >> kArcBits] + (Fb & (kMaxArcsPerState - 1));
-        s_aux[j] = (rank << 24) | ord_b;
-        if (Fb == Fj) cntord[ord_b] = nb;
       }
-    }
-    WSYNC();
-    {
-      u32 carry = 0;
-      for (u32 o0 = 0; o0 < cand_base; o0 += 64) {
-        u32 o = o0 + lane;
-        u32 v = o < cand_base ? cntord[o] : 0u;
-        const u32 inc = incl_scan_sum(v);
-        if (o < cand_base && v != 0) cntord[o] = carry + inc - v;  // only leader ordinals are ever non-zero (and reset below)
-        carry += (u32)__builtin_amdgcn_readlane((int)inc, 63);
+      WSYNC();
+      {
+        u32 carry = 0;
+        for (u32 o0 = 0; o0 < n_ord; o0 += 64) {
+          u32 o = o0 + lane;
+          u32 v = o < n_ord ? cntord[o] : 0u;
+          const u32 inc = incl_scan_sum(v);
+          if (o < n_ord && v != 0) cntord[o] = carry + inc - v;  // only leader ordinals are ever non-zero (and reset below)
+          carry += (u32)__builtin_amdgcn_readlane((int)inc, 63);
+        }
       }
-    }
-    WSYNC();
+      WSYNC();
+    };
+    order_pass(nslots, cand_base);
     STAMP(7);   // list order (bucket ranks, ordinal scan)
+    u32 nslots_f = nslots;      // slots after the epsilon closure (kEps)
+    if constexpr (kEps) {
+      // ---------------- FasterDecoder::ProcessNonemitting(next_weight_cutoff).  The new tokens live in the slot table
+      // (state, cost key, first creator, winner) and the pass above has just given each its list position.  Kaldi pushes the
+      // list on a stack (last token on top) and pops: a popped token's epsilon arcs, in arc order, insert their destination
+      // (end of its hash bucket's chain) or replace its token when strictly cheaper, and push it.  Costs come out the same
+      // whatever the order (label-correcting search, epsilon weights >= 0); the order of insertion — hence the list order the
+      // next frame walks — and the back-pointer on ties do not, so the pops run one after the other as Kaldi's do; the popped
+      // state's epsilon arcs are relaxed by the lanes in parallel with arc order restored where it matters (first creator
+      // by atomicMin on the ordinal, earlier duplicates of a destination by a lane loop, pushes by ballot prefix).  States
+      // without epsilon arcs are never pushed: popping them does nothing.
+      const double eps_cut = frame_min + (double)abeam;
+      bool any_eps = false;
+      for (u32 j0 = 0; j0 < nslots; j0 += 64) {
+        const u32 j = j0 + lane;
+        u32 ei = 0;
+        if (j < nslots) { ei = p.w_epsinfo[(size_t)utt * p.eps_stride + s_state[j]]; e_info[j] = ei; }
+        if (__any((ei & 127u) != 0u)) any_eps = true;
+      }
+      if (any_eps) {
+        bool eps_broken = false;
+        for (u32 j0 = 0; j0 < nslots; j0 += 64) {
+          const u32 j = j0 + lane;
+          if (j < nslots) {
+            const u32 aux = s_aux[j];
+            const u32 pos = cntord[aux & 0xFFFFFFu] + (aux >> 24);
+            if (pos < nslots) e_inv[pos] = j; else eps_broken = true;
+          }
+        }
+        if (__any(eps_broken)) { status = ST_INTERNAL; break; }
+        WSYNC();
+        u32 sp = 0;
+        for (u32 q0 = 0; q0 < nslots; q0 += 64) {
+          const u32 q = q0 + lane;
+          const u32 j = q < nslots ? e_inv[q] : 0u;
+          const bool has = q < nslots && (e_info[j] & 127u) != 0u;
+          const u64 m = __ballot(has);
+          if (has) e_stk[sp + (u32)__popcll(m & ((1ull << lane) - 1ull))] = j;
+          sp += (u32)__popcll(m);
+        }
+        WSYNC();
+        u32 eord = 0;
+        int guard = 0;
+        bool eps_over = false;
+        while (sp > 0u) {
+          if (++guard > 64 * N) { eps_over = true; break; }
+          const u32 e = e_stk[sp - 1u];
+          sp--;
+          const double ce = dunkey(s_cost[e]);
+          if (ce > eps_cut) continue;
+          const u32 ei = e_info[e];
+          const u32 n_eps = ei & 127u, first = ei >> 7;
+          if (n_eps == 0u) continue;
+          if (n_eps > 64u) { bad_degree = true; break; }
+          const bool valid = (u32)lane < n_eps;
+          u32 nx = 0u, nan_ = 0u; float w = 0.0f;
+          if (valid) { const uint4 rec = a_rec[first + (u32)lane]; nx = rec.x; nan_ = rec.y; w = __uint_as_float(rec.w); }
+          const double nc = ce + (double)w;           // Kaldi: new_tok->cost_ = tok->cost_ + arc.weight (no acoustic term)
+          const bool ok0 = valid && !(nc > eps_cut);
+          u32 sl = kEmpty;
+          {
+            bool pend = ok0; u32 h = hash_of(nx);
+            while (__any(pend)) { probe(pend, h, sl, nx, nan_); WSYNC(); if (ctr[0] > (u32)N) break; }
+          }
+          if (ctr[0] > (u32)N) { eps_over = true; break; }
+          const bool ok = ok0 && sl != kEmpty;
+          const u64 okm = __ballot(ok);
+          const u64 pre = ok ? s_cost[sl] : kKeyInf;  // before this pop: infinite = the state was not in the list
+          const bool is_new = ok && pre == kKeyInf;
+          if (is_new) e_info[sl] = p.w_epsinfo[(size_t)utt * p.eps_stride + nx];
+          // earlier arcs of this pop into the same state (rare): what Kaldi's sequential loop would have left there
+          double pm = INFINITY; bool first_dup = true;
+          for (u32 j = 0; j < n_eps; j++) {
+            const u32 nxj = (u32)__builtin_amdgcn_readlane((int)nx, (int)j);
+            const double ncj = readlane_f64(nc, (int)j);
+            if (((okm >> j) & 1ull) && (u32)lane > j && nxj == nx) { pm = min_f64(pm, ncj); first_dup = false; }
+          }
+          const bool push = ok && (is_new ? (first_dup || nc < pm) : (nc < min_f64(dunkey(pre), pm)));
+          WSYNC();                                    // every lane has read `pre`
+          if (push) atomicMin(&s_cost[sl], dkey(nc));
+          if (is_new) atomicMin(&s_F[sl], 0x80000000u | (eord + (u32)__popcll(okm & ((1ull << lane) - 1ull))));
+          WSYNC();
+          const bool win = push && dkey(nc) == s_cost[sl];
+          if (win) atomicMin(&e_tmp[sl], (u32)lane);
+          WSYNC();
+          if (win && e_tmp[sl] == (u32)lane) { s_W[sl] = 0x80000000u | e; e_arc[sl] = first + (u32)lane; }
+          WSYNC();
+          if (win) e_tmp[sl] = 0xFFFFFFFFu;
+          const bool pp = push && (e_info[sl] & 127u) != 0u;
+          const u64 pmk = __ballot(pp);
+          const u32 at = sp + (u32)__popcll(pmk & ((1ull << lane) - 1ull));
+          if (pp && at < 2u * (u32)N) e_stk[at] = sl;
+          sp += (u32)__popcll(pmk);
+          if (sp > 2u * (u32)N) { eps_over = true; break; }
+          eord += (u32)__popcll(okm);
+          if (cand_base + eord > (u32)C) { eps_over = true; break; }
+          WSYNC();
+        }
+        if (__any(bad_degree)) { status = ST_UNSUPPORTED; break; }
+        if (eps_over) { status = ST_TOKEN_OVERFLOW; break; }
+        nslots_f = ctr[0];
+        if (nslots_f > nslots) {
+          // new states: the list order is worked out again over all slots (a new state goes to the end of its bucket's
+          // chain, which may lie in the middle of the list)
+          for (u32 j0 = 0; j0 < nslots; j0 += 64) {
+            const u32 j = j0 + lane;
+            if (j < nslots) cntord[s_aux[j] & 0xFFFFFFu] = 0u;
+          }
+          WSYNC();
+          order_pass(nslots_f, cand_base + eord);
+        }
+      }
+    }
     // ---------------- write the new list + back-pointers, reset the tables
-    if (bp_used + nslots > bp_cap) { status = ST_BP_OVERFLOW; break; }
+    if (bp_used + nslots_f > bp_cap) { status = ST_BP_OVERFLOW; break; }
     bool broken = false;  // defensive: an inconsistent table must never turn into an out-of-range store
-    for (u32 j0 = 0; j0 < nslots; j0 += 64) {
+    if constexpr (kEps) {
+      for (u32 j0 = 0; j0 < nslots_f; j0 += 64) {
+        const u32 j = j0 + lane;
+        if (j < nslots_f) { const u32 aux = s_aux[j]; e_pos[j] = cntord[aux & 0xFFFFFFu] + (aux >> 24); }
+      }
+      WSYNC();
+    }
+    for (u32 j0 = 0; j0 < nslots_f; j0 += 64) {
       u32 j = j0 + lane;
-      if (j < nslots) {
+      if (j < nslots_f) {
         const u32 aux = s_aux[j];
         const u32 pos = cntord[aux & 0xFFFFFFu] + (aux >> 24);
         const u32 d = s_state[j], W = s_W[j];
-        const u32 ppos = W >> kArcBits, k = W & (kMaxArcsPerState - 1);
-        if (pos >= nslots || ppos >= (u32)n || d >= (u32)S) broken = true;
-        else {
-          const u32 arc = (c_an[ppos] >> 7) + k;
-          n_state[pos] = d;
-          n_an[pos] = s_an[j];
-          n_cost[pos] = dunkey(s_cost[j]);
-          bp[bp_used + pos] = ((u64)arc << 32) | (u64)ppos;
+        bool eps_w = false;
+        if constexpr (kEps) eps_w = (W >> 31) != 0u;
+        if (eps_w) {
+          // the token came over an epsilon arc: its predecessor is a token of THIS frame's list (no frame consumed)
+          const u32 src = W & 0x7FFFFFFFu;
+          if (pos >= nslots_f || src >= nslots_f || d >= (u32)S) broken = true;
+          else {
+            n_state[pos] = d;
+            n_an[pos] = s_an[j];
+            n_cost[pos] = dunkey(s_cost[j]);
+            bp[bp_used + pos] = ((u64)e_arc[j] << 32) | (u64)e_pos[src];
+          }
+        } else {
+          const u32 ppos = W >> kArcBits, k = W & (kMaxArcsPerState - 1);
+          if (pos >= nslots_f || ppos >= (u32)n || d >= (u32)S) broken = true;
+          else {
+            const u32 arc = (c_an[ppos] >> 7) + k;
+            n_state[pos] = d;
+            n_an[pos] = s_an[j];
+            n_cost[pos] = dunkey(s_cost[j]);
+            bp[bp_used + pos] = ((u64)arc << 32) | (u64)ppos;
+          }
         }
       }
     }
     if (__any(broken)) { status = ST_INTERNAL; break; }
     WSYNC();
-    for (u32 j0 = 0; j0 < nslots; j0 += 64) {
+    for (u32 j0 = 0; j0 < nslots_f; j0 += 64) {
       u32 j = j0 + lane;
-      if (j < nslots) { hmap[s_bucket[j]] = kEmpty; cntord[s_aux[j] & 0xFFFFFFu] = 0; }
+      if (j < nslots_f) { hmap[s_bucket[j]] = kEmpty; cntord[s_aux[j] & 0xFFFFFFu] = 0; }
     }
     if (lane == 0) { tokoff[t] = (u32)bp_used; ctr[0] = 0; ctr[1] = 0; }
-    bp_used += nslots;
-    n = (int)nslots;
+    bp_used += nslots_f;
+    n = (int)nslots_f;
     cur ^= 1;
     if (!kListsInLds) __threadfence_block();  // token lists in HBM: stores must land before the next frame reads them
     WSYNC();
@@ -884,7 +1212,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   }
   if (p.pass == 0 && lane == 0) p.w_hash[utt] = H;
 
-  finalize_utterance(p, utt, lane, status, t, T, n, c_state, c_cost, final_w, bp, tokoff, f0, ab_, a_w, a_col, ll, P);
+  finalize_utterance(p, utt, lane, status, t, T, n, c_state, c_cost, final_w, bp, tokoff, f0, ab_, a_w, a_col, ll, P, kEps, bp_used,
+                     bp_cap);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1278,16 +1607,24 @@ __global__ void finalize_pending_kernel(int32_t *status, int n_utt) {
 // score column, weight}.  The destination's arc range folds the arc_off lookup of the NEXT frame into this frame's arc
 // fetch (one dependent HBM/L2 round trip per frame instead of three), and the record makes that fetch one 16-byte load
 // touching one line instead of four 4-byte gathers from four arrays.
-__global__ void arcnext_kernel(mfa_graph_batch g, uint4 *out) {
+__global__ void arcnext_kernel(mfa_graph_batch g, uint4 *out, u32 *epsinfo, int max_states) {
   const int utt = blockIdx.x;
   const int64_t so = g.d_state_off[utt], ab = g.d_arc_base[utt];
   const int64_t na = g.d_arc_base[utt + 1] - ab;
+  const int S = (int)(g.d_state_off[utt + 1] - so);
   const int32_t *arc_off = g.d_arc_off + so + utt;
+  const int32_t *nemit = g.d_state_nemit ? g.d_state_nemit + so : nullptr;   // emitting arcs per state (the rest are epsilon arcs)
   for (int64_t a = threadIdx.x; a < na; a += blockDim.x) {
     const int d = g.d_arc_next[ab + a];
-    const u32 an = ((u32)arc_off[d] << 7) | (u32)(arc_off[d + 1] - arc_off[d]);
+    const u32 deg = nemit ? (u32)nemit[d] : (u32)(arc_off[d + 1] - arc_off[d]);
+    const u32 an = ((u32)arc_off[d] << 7) | min(deg, 127u);
     out[ab + a] = make_uint4((u32)d, an, (u32)g.d_arc_col[ab + a], __float_as_uint(g.d_arc_weight[ab + a]));
   }
+  if (epsinfo && nemit)
+    for (int s_ = threadIdx.x; s_ < S && s_ < max_states; s_ += blockDim.x) {
+      const int first = arc_off[s_] + nemit[s_], n_eps = arc_off[s_ + 1] - first;
+      epsinfo[(size_t)utt * max_states + s_] = ((u32)first << 7) | (u32)min(max(n_eps, 0), 127);
+    }
 }
 
 constexpr int kLlCap = 512;
@@ -1298,18 +1635,18 @@ int hash_bits(int S, int N) {
   while ((1 << b) < 4 * N) b++;
   return ((size_t)4 << b) <= (size_t)((S + 1) & ~1) * 4 ? b : 0;
 }
-size_t lds_bytes(int S, int N, int C, bool lists_in_lds) {
+size_t lds_bytes(int S, int N, int C, bool lists_in_lds, bool eps = false) {
   const int hb = hash_bits(S, N);
   const size_t table = hb ? ((size_t)4 << hb) : (size_t)((S + 1) & ~1) * 4;
   return (size_t)N * 8 + table + (size_t)N * 7 * 4 + (size_t)C * 4 + (size_t)kLlCap * 4 + 16 + (size_t)kBmWords * 4 +
-         (lists_in_lds ? (size_t)N * 32 : 0);
+         (lists_in_lds ? (size_t)N * 32 : 0) + (eps ? (size_t)N * 7 * 4 : 0);   // eps: position / inverse / arc / vote / info + stack
 }
 constexpr size_t kLdsLimit = 160 * 1024;
 
 struct WsLayout {
-  size_t arcnext, state, cost, sta, stb, stkey, bp, tokoff, hash, list, count, vstate, band, redo, total;
+  size_t arcnext, state, cost, sta, stb, stkey, bp, tokoff, hash, list, count, vstate, band, redo, eps, total;
 };
-WsLayout ws_layout(int n_utt, int64_t total_frames, int N, int C, int bpf, int64_t total_arcs) {
+WsLayout ws_layout(int n_utt, int64_t total_frames, int N, int C, int bpf, int64_t total_arcs, int64_t eps_states = 0) {
   WsLayout w; size_t o = 0;
   auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 255) & ~(size_t)255; return at; };
   w.arcnext = take((size_t)total_arcs * 16);
@@ -1326,6 +1663,7 @@ WsLayout ws_layout(int n_utt, int64_t total_frames, int N, int C, int bpf, int64
   w.vstate = take((size_t)n_utt * sizeof(VitState));
   w.band = take((size_t)n_utt * 2 * 4);
   w.redo = take((size_t)n_utt * 4);
+  w.eps = take((size_t)eps_states * 4);
   w.total = o;
   return w;
 }
@@ -1385,14 +1723,20 @@ int align_impl(mfa_ctx *c, const mfa_graph_batch *g, const float *d_loglikes, co
   int N[2], C[2];
   for (int ps = 0; ps < 2; ps++) pick_caps(o, max_states, max_arcs, ps, &N[ps], &C[ps]);
   const int Nw = passes == 2 ? N[1] : N[0], Cw = passes == 2 ? C[1] : C[0];
-  WsLayout w = ws_layout(n_utt, total_frames, Nw, Cw, bpf, total_arcs);
+  // graphs with epsilon input arcs: the general kernel's kEps instantiation on every tier (the 64-token kernel knows nothing
+  // of them), one {first epsilon arc, count} word per state in the workspace
+  const bool eps = g->d_state_nemit != nullptr;
+  if (eps && max_arcs >= (1 << 24)) return c->fail("graphs with epsilon arcs and more than 2^24 arcs are not supported");
+  const int64_t eps_states = eps ? (int64_t)n_utt * max_states : 0;
+  WsLayout w = ws_layout(n_utt, total_frames, Nw, Cw, bpf, total_arcs, eps_states);
   if (c->ws_bytes < w.total) {
     if (c->d_ws) { MFA_HIP_CHECK(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->d_ws); c->d_ws = nullptr; c->ws_bytes = 0; }
     MFA_HIP_CHECK(c, hipMalloc(&c->d_ws, w.total));
     c->ws_bytes = w.total;
   }
   unsigned char *base = (unsigned char *)c->d_ws;
-  hipLaunchKernelGGL(arcnext_kernel, dim3(n_utt), dim3(256), 0, c->stream, *g, (uint4 *)(base + w.arcnext));
+  hipLaunchKernelGGL(arcnext_kernel, dim3(n_utt), dim3(256), 0, c->stream, *g, (uint4 *)(base + w.arcnext),
+                     eps ? (u32 *)(base + w.eps) : (u32 *)nullptr, max_states);
   // Launch plan.  The decoder is latency-bound (one wavefront walks one utterance frame by frame), so throughput is the
   // number of wavefronts a CU can keep resident, and that is set by the LDS tables, which scale with the token capacity.
   // With the normal beam a frame rarely holds more than a few dozen tokens, so every utterance is first decoded with
@@ -1447,13 +1791,13 @@ int align_impl(mfa_ctx *c, const mfa_graph_batch *g, const float *d_loglikes, co
     // atomically updated tables do not fit, shrink the token capacity (an overflow is then reported per utterance)
     // (the list passes — table growth, retry beam — hold a handful of utterances: occupancy does not matter there, the
     //  per-frame latency of HBM-resident lists does)
-    bool lists_in_lds = lds_bytes(max_states, L.N, L.C, true) <= kLdsLimit / 2 ||
-                        ((ps == 0 || L.code != 0) && lds_bytes(max_states, L.N, L.C, true) <= kLdsLimit);
-    while (lds_bytes(max_states, L.N, L.C, lists_in_lds) > kLdsLimit && L.N > 64) {
+    bool lists_in_lds = lds_bytes(max_states, L.N, L.C, true, eps) <= kLdsLimit / 2 ||
+                        ((ps == 0 || L.code != 0) && lds_bytes(max_states, L.N, L.C, true, eps) <= kLdsLimit);
+    while (lds_bytes(max_states, L.N, L.C, lists_in_lds, eps) > kLdsLimit && L.N > 64) {
       L.N = (L.N / 2 + 63) & ~63;
       if (L.C > 8 * L.N) L.C = 8 * L.N;
     }
-    size_t lds = lds_bytes(max_states, L.N, L.C, lists_in_lds);
+    size_t lds = lds_bytes(max_states, L.N, L.C, lists_in_lds, eps);
     if (lds > kLdsLimit) return c->fail("Viterbi tables need %zu bytes of LDS (> 160 KiB): %d states, %d tokens", lds, max_states, L.N);
     VitParams p;
     memset(&p, 0, sizeof(p));
@@ -1461,12 +1805,13 @@ int align_impl(mfa_ctx *c, const mfa_graph_batch *g, const float *d_loglikes, co
     p.beam = ps == 0 ? o->beam : o->retry_beam; p.scale = o->acoustic_scale;
     p.nmax = L.N; p.cmax = L.C; p.bpf = bpf; p.pass = ps; p.grow = L.grow; p.hbits = hash_bits(max_states, L.N);
     // workspace strides follow this launch's capacities (lists and stash are per-launch scratch)
-    WsLayout wp = ws_layout(n_utt, total_frames, L.N, L.C, bpf, total_arcs);
+    WsLayout wp = ws_layout(n_utt, total_frames, L.N, L.C, bpf, total_arcs, eps_states);
     p.w_state = (u32 *)(base + wp.state); p.w_cost = (double *)(base + wp.cost);
     p.w_stash_a = (u32 *)(base + wp.sta); p.w_stash_b = (u32 *)(base + wp.stb); p.w_stash_key = (u64 *)(base + wp.stkey);
     p.w_bp = (u64 *)(base + wp.bp); p.w_tokoff = (u32 *)(base + wp.tokoff);
     p.w_hash = (u32 *)(base + w.hash);     // fixed location across launches
     p.w_arcnext = (const uint4 *)(base + w.arcnext);
+    p.w_epsinfo = eps ? (const u32 *)(base + w.eps) : nullptr; p.eps_stride = max_states;
     p.llcap = kLlCap;
     p.stamps = (unsigned long long *)c->vit_stamps;
     int32_t *d_list = (int32_t *)(base + w.list), *d_count = (int32_t *)(base + w.count);
@@ -1484,9 +1829,14 @@ int align_impl(mfa_ctx *c, const mfa_graph_batch *g, const float *d_loglikes, co
     size_t lds2 = 0;
     VitParams p2 = p;
     if (L.N2 > 0) {
-      lds2 = lds_bytes(max_states, L.N2, L.C2, true);
+      lds2 = lds_bytes(max_states, L.N2, L.C2, true, eps);
+      while (lds2 > kLdsLimit && L.N2 > 128) {         // (the epsilon tables can push a 1 024-token large tier over the limit)
+        L.N2 = (L.N2 / 2 + 63) & ~63;
+        if (L.C2 > 4 * L.N2) L.C2 = 4 * L.N2;
+        lds2 = lds_bytes(max_states, L.N2, L.C2, true, eps);
+      }
       if (lds2 > kLdsLimit) return c->fail("Viterbi large tier needs %zu bytes of LDS", lds2);
-      WsLayout w2 = ws_layout(n_utt, total_frames, L.N2, L.C2, bpf, total_arcs);
+      WsLayout w2 = ws_layout(n_utt, total_frames, L.N2, L.C2, bpf, total_arcs, eps_states);
       p2.nmax = L.N2; p2.cmax = L.C2; p2.hbits = hash_bits(max_states, L.N2);
       // park arrays (state / cost) and the back-pointer trail are SHARED between the tiers: the layout of the large one
       p2.w_state = (u32 *)(base + w2.state); p2.w_cost = (double *)(base + w2.cost);
@@ -1498,17 +1848,21 @@ int align_impl(mfa_ctx *c, const mfa_graph_batch *g, const float *d_loglikes, co
       p.w_stash_a = p2.w_stash_a; p.w_stash_b = p2.w_stash_b; p.w_stash_key = p2.w_stash_key;
       MFA_HIP_CHECK(c, hipMemsetAsync(base + w.redo, 0, (size_t)n_utt * 4, c->stream));
     }
-    if (lists_in_lds) MFA_HIP_CHECK(c, hipFuncSetAttribute((const void *)viterbi_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(lds, lds2)));
-    else MFA_HIP_CHECK(c, hipFuncSetAttribute((const void *)viterbi_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // four instantiations: token lists in LDS or HBM × epsilon-free or not
+    void (*k_lds)(VitParams) = eps ? viterbi_kernel<true, true> : viterbi_kernel<true, false>;
+    void (*k_hbm)(VitParams) = eps ? viterbi_kernel<false, true> : viterbi_kernel<false, false>;
+    if (lists_in_lds) MFA_HIP_CHECK(c, hipFuncSetAttribute((const void *)k_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(lds, lds2)));
+    else MFA_HIP_CHECK(c, hipFuncSetAttribute((const void *)k_hbm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (lds2 > 0) MFA_HIP_CHECK(c, hipFuncSetAttribute((const void *)k_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(lds, lds2)));
     auto launch_decoder = [&]() {
       KernelTimer kt(c, MFA_K_VITERBI);
-      if (lists_in_lds) hipLaunchKernelGGL(viterbi_kernel<true>, dim3(n_utt), dim3(64), lds, c->stream, p);
-      else hipLaunchKernelGGL(viterbi_kernel<false>, dim3(n_utt), dim3(64), lds, c->stream, p);
+      if (lists_in_lds) hipLaunchKernelGGL(k_lds, dim3(n_utt), dim3(64), lds, c->stream, p);
+      else hipLaunchKernelGGL(k_hbm, dim3(n_utt), dim3(64), lds, c->stream, p);
     };
     // first tier of the windowed pass: the dedicated 64-token kernel (MFA_VIT_LEAN=0: the general kernel as first tier)
     constexpr int kSmallRounds = 3;
     const size_t lds_small = (size_t)kSmallN * (8 + 16 + 6 * 4 + 8 + 8) + 256 * 4 + (size_t)64 * kSmallRounds * 4 + 16 + (size_t)kBmWords * 4;
-    bool lean = lazy && L.N2 > 0 && lists_in_lds && L.code == 0 && L.N == kSmallN;
+    bool lean = lazy && L.N2 > 0 && lists_in_lds && L.code == 0 && L.N == kSmallN && !eps;
     { const char *e = getenv("MFA_VIT_LEAN"); if (e && e[0] == '0') lean = false; }
     if (!lazy) {
       launch_decoder();
@@ -1557,7 +1911,7 @@ int align_impl(mfa_ctx *c, const mfa_graph_batch *g, const float *d_loglikes, co
           }
           {
             KernelTimer kt2(c, MFA_K_VITERBI);
-            hipLaunchKernelGGL(viterbi_kernel<true>, dim3(n_utt), dim3(64), lds2, c->stream, p2);
+            hipLaunchKernelGGL(k_lds, dim3(n_utt), dim3(64), lds2, c->stream, p2);
           }
         } else {
           launch_decoder();

@@ -137,10 +137,11 @@ class PackedGraphs:
 
     def struct(self) -> GraphBatch:
         t = self.tensors
+        nemit = t.get("state_nemit")
         return GraphBatch(self.n_utt, t["state_off"].data_ptr(), t["arc_base"].data_ptr(), t["start"].data_ptr(),
                           t["arc_off"].data_ptr(), t["final"].data_ptr(), t["arc_next"].data_ptr(),
                           t["arc_weight"].data_ptr(), t["arc_col"].data_ptr(), t["arc_ilabel"].data_ptr(),
-                          t["arc_olabel"].data_ptr())
+                          t["arc_olabel"].data_ptr(), nemit.data_ptr() if nemit is not None else None)
 
 
 class AlignmentEngine:
@@ -444,8 +445,18 @@ class AlignmentEngine:
 
     @staticmethod
     def needs_general_decoder(fst: Fst) -> bool:
-        """True for graphs the wavefront-parallel decoder does not take: epsilon input arcs, a state with > 64 arcs."""
-        return bool(fst.num_arcs and (np.any(fst.arcs["ilabel"] == 0) or int(np.diff(fst.arc_offsets).max()) > 64))
+        """True for graphs the wavefront-parallel decoder does not take: a state with more than 64 emitting (or more than 64
+        epsilon) arcs.  Epsilon input arcs as such are fine since round 3 (``pack_graphs`` stores every state's arcs [emitting | epsilon] and the decoder runs
+        ProcessNonemitting after every frame)."""
+        if not fst.num_arcs:
+            return False
+        eps = fst.arcs["ilabel"] == 0
+        deg = np.diff(fst.arc_offsets)
+        if not eps.any():
+            return bool(int(deg.max()) > 64)
+        src = np.repeat(np.arange(fst.num_states), deg)
+        n_eps = np.bincount(src[eps], minlength=fst.num_states)
+        return bool(int(n_eps.max()) > 64 or int((deg - n_eps).max()) > 64)
 
     def pack_graphs(self, fsts: Sequence[Fst], tm: TransitionModel, cluster_gap: Optional[int] = 32,
                     groups: Optional[int] = None, pool: Optional[StagingPool] = None) -> PackedGraphs:
@@ -484,19 +495,36 @@ class AlignmentEngine:
             arcs = np.concatenate([f.arcs for f in fsts])
         if self.slot_class is None:
             raise _lib.MfaHipError("pack_graphs needs the acoustic model's slot classes: call load_gmm first")
+        nemit = None          # emitting arcs per state, for graphs with epsilon input arcs
         if columns:
             # (the compiler produced next-state and pdf columns; an input label outside the model was refused there)
             nxt, pdf_of_arc = fsts.arc_next, fsts.arc_pdf
             if arcs.shape[0] and int(pdf_of_arc.min()) < 0:
-                raise _lib.MfaHipError("graphs with epsilon input arcs are not supported by the device decoder")
+                raise _lib.MfaHipError("a natively compiled batch cannot hold epsilon input arcs")
         else:
-            if np.any(arcs["ilabel"] <= 0):
-                raise _lib.MfaHipError("graphs with epsilon input arcs are not supported by the device decoder")
-            pdf_of_arc = np.ascontiguousarray(tm.id2pdf[arcs["ilabel"]], dtype=np.int32)
+            il = arcs["ilabel"]
+            if np.any(il < 0) or np.any(il > tm.num_transition_ids):
+                raise _lib.MfaHipError("a graph arc carries an input label outside the model's transition-ids")
+            is_eps = il == 0
+            if is_eps.any():
+                # epsilon input arcs (kalpy / Kaldi-compiled graphs): every state's arcs stored [emitting | epsilon], each
+                # kind in its original order — FasterDecoder's two loops never see the interleaving (include/mfa_hip.h)
+                deg = np.concatenate([np.diff(f.arc_offsets) for f in fsts]).astype(np.int64)
+                src = np.repeat(np.arange(deg.shape[0], dtype=np.int64), deg)
+                perm = np.argsort(src * 2 + is_eps, kind="stable")
+                arcs = arcs[perm]
+                is_eps = is_eps[perm]
+                n_eps = np.bincount(src[perm][is_eps], minlength=deg.shape[0])
+                nemit = (deg - n_eps).astype(np.int32)
+                if int(n_eps.max()) > 64 or int(nemit.max()) > 64:
+                    raise _lib.MfaHipError("a graph state has more than 64 arcs of a kind; the device decoder supports at most 64 "
+                                           "emitting and 64 epsilon arcs per state (needs_general_decoder)")
+            pdf_of_arc = np.ascontiguousarray(np.where(il[perm] > 0, tm.id2pdf[np.maximum(il[perm], 0)], -1) if nemit is not None
+                                              else tm.id2pdf[il], dtype=np.int32)
             nxt = np.ascontiguousarray(arcs["nextstate"], dtype=np.int32)
         # (the concatenated offsets restart at every utterance: those steps are <= 0 and do not disturb the maximum)
         max_deg = int(np.diff(arc_off).max()) if arc_off.shape[0] > 1 else 0
-        if max_deg > 64:
+        if max_deg > 64 and nemit is None:
             raise _lib.MfaHipError(f"a graph state has {max_deg} arcs; the device decoder supports at most 64")
         span = 0 if cluster_gap is None else int(cluster_gap)
         pdf_class = np.ascontiguousarray(self.slot_class, dtype=np.int32)
@@ -560,6 +588,8 @@ class AlignmentEngine:
                 arc_col=up(cols), arc_ilabel=self._dev(arcs["ilabel"].astype(np.int32)),
                 arc_olabel=self._dev(arcs["olabel"].astype(np.int32)),
             )
+        if nemit is not None:
+            t["state_nemit"] = self._dev(nemit)
         sd_dev = up(sd_all[:total_s].reshape(-1)).view(-1, 2)
         return PackedGraphs(n, int(S.max()) if n else 0, int(A.max()) if n else 0, int(A.sum()), t, self._dev(pdf_all),
                             self._dev(pdf_off), self._dev(counts), pdf_off, pdf_lists,

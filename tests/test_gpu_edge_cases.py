@@ -66,11 +66,15 @@ def test_unsupported_inputs_are_refused_loudly(engine, fx):
         fo = np.array([0, 5], np.int64)
         ll, ll_off, ll_cols = engine.score(x, fo, g.pdf_list, g.pdf_off_host, g.class_counts)
         engine.align(g, ll, ll_off, ll_cols, fo, beam=10.0, retry_beam=5.0)
-    # graphs the device decoder does not take: epsilon input labels, states with more than 64 arcs
+    # graphs the device decoder does not take: states with more than 64 arcs of a kind, labels outside the model
+    # (epsilon input labels are taken since round 3: tests/test_gpu_general.py)
     f = fx.mono_graph("this")
     arcs = f.arcs.copy()
     arcs["ilabel"][0] = 0
-    with pytest.raises(_lib.MfaHipError, match="epsilon"):
+    g_eps = engine.pack_graphs([K.Fst(f.start, f.arc_offsets, arcs, f.final)], fx.mono_tm)
+    assert "state_nemit" in g_eps.tensors
+    arcs["ilabel"][0] = fx.mono_tm.num_transition_ids + 5
+    with pytest.raises(_lib.MfaHipError, match="transition-ids"):
         engine.pack_graphs([K.Fst(f.start, f.arc_offsets, arcs, f.final)], fx.mono_tm)
     n = 70
     wide = np.zeros(n, dtype=K.ARC_DTYPE)

@@ -165,3 +165,85 @@ def test_kalpy_facade_routes_epsilon_graphs(engine, fx):
     ref = _oracle(tm, am, G.add_transition_probs(eps, al._scaled), x, 100.0, 400.0)
     assert out[1].alignment == ref["ali"].tolist() and out[1].words == ref["words"].tolist()
     assert out[0].alignment == out[2].alignment
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 3: epsilon input arcs on the wavefront-parallel decoder (pack_graphs stores every state's arcs [emitting | epsilon],
+# the kEps instantiation of viterbi_kernel runs ProcessNonemitting after every frame) — the lazy-scored, windowed product path.
+def _check_fast(engine, tm, am, fsts, feats, beam, retry, dense=False, **caps):
+    keep = [u for u, f in enumerate(fsts) if not engine.needs_general_decoder(f)]
+    assert keep
+    fsts, feats = [fsts[u] for u in keep], [feats[u] for u in keep]
+    engine.load_gmm(am)
+    fo = np.concatenate([[0], np.cumsum([x.shape[0] for x in feats])]).astype(np.int64)
+    g = engine.pack_graphs(fsts, tm)
+    assert "state_nemit" in g.tensors
+    d_feats = _dev(engine, np.concatenate(feats))
+    kw = dict(beam=beam, retry_beam=retry, want_frame_likes=True, max_tokens=caps.get("max_tokens", g.max_states),
+              bp_tokens_per_frame=caps.get("bp", max(g.max_states, 64)))
+    if dense:
+        ll, ll_off, ll_cols = engine.score(d_feats, fo, g.pdf_list, g.pdf_off_host, g.class_counts)
+        res = engine.align(g, ll, ll_off, ll_cols, fo, **kw)
+    else:
+        res = engine.align_features(g, d_feats, fo, **kw)
+    torch.cuda.synchronize()
+    res = {k: v.cpu().numpy() for k, v in res.items() if isinstance(v, torch.Tensor) and k != "loglikes"}
+    seen = set()
+    for u, f in enumerate(fsts):
+        ref = _oracle(tm, am, f, feats[u], beam, retry)
+        assert int(res["status"][u]) == ref["status"], (u, int(res["status"][u]), ref["status"])
+        seen.add(ref["status"])
+        if ref["status"] in (0, 1):
+            a, b = int(fo[u]), int(fo[u + 1])
+            assert np.array_equal(res["ali"][a:b], ref["ali"]), u
+            nw = int(res["n_words"][u])
+            assert np.array_equal(res["words"][a: a + nw], ref["words"]), u
+            assert res["like"][u] == np.float32(ref["like"]), (u, res["like"][u], ref["like"])
+            assert np.array_equal(res["frame_like"][a:b], ref["per_frame"]), u
+    return seen, len(keep)
+
+
+def test_epsilon_training_graphs_on_the_wavefront_decoder(engine, fx):
+    """The same rewritten training graphs as above, through the product path: bit-identical to the oracle with the default
+    capacities (tiers, windows, retry beam) and with scores given densely."""
+    tm, am = fx.mono_tm, fx.mono_am
+    rng = np.random.default_rng(2)
+    sr = 16000
+    cuts = [(0.0, 4.2), (4.0, 6.5), (23.5, 26.72)]
+    texts = ["this is the acoustic corpus i'm talking pretty fast here", "there's nothing going else going on",
+             "um and that should be all thanks"]
+    feats = [fx.mono_feats(fx.pcm[int(a * sr): int(b * sr)]) for a, b in cuts]
+    fsts = [_with_eps(rng, fx.mono_graph(t)) for t in texts]
+    for beam, retry in ((100.0, 400.0), (10.0, 40.0), (1.0e4, 0.0)):
+        _seen, n = _check_fast(engine, tm, am, fsts, feats, beam, retry, max_tokens=1024, bp=512)
+        assert n == 3
+        _check_fast(engine, tm, am, fsts, feats, beam, retry, dense=True, max_tokens=1024, bp=512)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4])
+def test_wavefront_decoder_fuzz_with_epsilon_arcs(engine, fx, seed):
+    """Random graphs with a fifth of their arcs turned into epsilon arcs — chains, zero-weight cycles, exact cost ties,
+    several epsilon arcs of one state into the same destination, more states than hash buckets — against the oracle:
+    closure costs, LIFO insertion order, hash-list order of the states the closure creates, back-pointers on ties."""
+    tm, am = fx.mono_tm, fx.mono_am
+    rng = np.random.default_rng(5000 + seed)
+    fsts, feats = [], []
+    while len(fsts) < 24:
+        S = int(rng.choice([3, 8, 40, 150, 400, 1100, 1500]))
+        f = _random_graph(rng, tm, S)
+        arcs = f.arcs.copy()
+        eps = rng.random(len(arcs)) < 0.2
+        arcs["ilabel"][eps] = 0
+        if seed == 4:                                    # negative epsilon weights too (no negative cycles: forward arcs only)
+            src = np.repeat(np.arange(f.num_states), np.diff(f.arc_offsets))
+            fwd = eps & (arcs["nextstate"] > src)
+            arcs["weight"][fwd] -= 0.5
+        f = K.Fst(f.start, f.arc_offsets, arcs, f.final)
+        if engine.needs_general_decoder(f) or not eps.any():
+            continue
+        fsts.append(f)
+        feats.append(rng.normal(0, 3.0, size=(int(rng.integers(2, 140)), 39)).astype(np.float32))
+    beam, retry = [(1.0, 4.0), (8.0, 32.0), (50.0, 0.0), (3.0, 12.0), (20.0, 80.0)][seed]
+    seen, n = _check_fast(engine, tm, am, fsts, feats, beam, retry)
+    assert n == 24 and seen & {0, 1}
+    _check_fast(engine, tm, am, fsts, feats, beam, retry, dense=True)

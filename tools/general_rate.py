@@ -48,10 +48,13 @@ def main():
     feats, fo = feats_of(pcm[:n_utt], spk[:n_utt])
     g_fast = engine.pack_graphs((plain * rep)[:n_utt], model.tm)
     g_gen = engine.pack_graphs_general((eps * rep)[:n_utt], model.tm)
+    g_eps = engine.pack_graphs((eps * rep)[:n_utt], model.tm)            # round 3: ε graphs on the wavefront-parallel decoder
     kw = dict(beam=10.0, retry_beam=40.0)
     out = {}
     for name, fn in (("fast path, ε-free graphs", lambda: engine.align_features(g_fast, feats, fo, max_tokens=1024,
                                                                                  bp_tokens_per_frame=256, **kw)),
+                     ("wavefront decoder, ε graphs", lambda: engine.align_features(g_eps, feats, fo, max_tokens=1024,
+                                                                                   bp_tokens_per_frame=256, **kw)),
                      ("general decoder, ε graphs", lambda: engine.align_general(g_gen, feats, fo, **kw))):
         r = fn()
         torch.cuda.synchronize()
@@ -65,8 +68,10 @@ def main():
         out[name] = r
         print(f"{name}: {n_utt} utterances in {dt * 1e3:.1f} ms = {n_utt / dt:.0f} utterances/s; "
               f"aligned {(st <= 1).mean():.3f}", flush=True)
-    a, b = out["fast path, ε-free graphs"], out["general decoder, ε graphs"]
+    a, b, c = out["fast path, ε-free graphs"], out["general decoder, ε graphs"], out["wavefront decoder, ε graphs"]
     print("same likelihoods (|Δ| per frame):", float((a["like"] - b["like"]).abs().max()))
+    print("wavefront ε decoder == general decoder:", bool(torch.equal(b["ali"], c["ali"]) and torch.equal(b["like"], c["like"])
+                                                          and torch.equal(b["status"], c["status"])))
 
 
 if __name__ == "__main__":
