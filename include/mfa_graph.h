@@ -118,7 +118,8 @@ MFA_GC_API int mfa_gc_fetch(mfa_gc *gc, int64_t *state_off, int64_t *arc_base, i
  * arc_pdf is not written).  Any output pointer may be NULL.  The batch stays fetchable until the next mfa_gc_prepare. */
 MFA_GC_API int mfa_gc_fetch_columns(mfa_gc *gc, const int32_t *id2pdf, int32_t n_threads, int64_t *state_off, int64_t *arc_base,
                                     int64_t *arc_off, int32_t *arc_off32, void *arcs, float *final_w, int32_t *arc_next,
-                                    int32_t *arc_pdf);
+                                    int32_t *arc_pdf, int32_t *stats /* [3] or NULL: largest out-degree of a state, smallest input
+                                    label, fewest arcs of an utterance — what decides whether the batch can go to the device as it is */);
 
 #ifdef __cplusplus
 }

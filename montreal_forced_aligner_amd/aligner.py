@@ -289,9 +289,8 @@ class CorpusAligner:
         eng = self.engine
         idx_all, fsts_all, pool = comp["idx_all"], comp["fsts_all"], comp["pool"]
         prep = dict(idx_all=idx_all, idx=[], fsts=[], gidx=[], gfsts=[], graphs=None)
-        pdf = getattr(fsts_all, "arc_pdf", None)
-        if pdf is not None and len(fsts_all) and pdf.shape[0] and int(pdf.min()) >= 0 \
-                and int(np.diff(fsts_all.arc_off32).max()) <= 64 and int(np.diff(fsts_all.arc_base).min()) > 0:
+        if getattr(fsts_all, "arc_pdf", None) is not None and len(fsts_all) and getattr(fsts_all, "max_degree", None) is not None \
+                and fsts_all.min_ilabel > 0 and fsts_all.max_degree <= 64 and fsts_all.min_arcs > 0:
             # a batch straight from the native compiler with nothing for the general decoder in it: taken as it is
             prep["idx"], prep["fsts"] = list(idx_all), fsts_all
         else:

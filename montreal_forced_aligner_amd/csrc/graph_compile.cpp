@@ -986,7 +986,8 @@ int mfa_gc_fetch(mfa_gc *gc, int64_t *state_off, int64_t *arc_base, int64_t *arc
  * arc_off32 (int32 copy of the per-utterance arc offsets), arc_next (next state) and arc_pdf (id2pdf[ilabel]; id2pdf may be
  * NULL, then arc_pdf is not written).  Any output pointer may be NULL. */
 int mfa_gc_fetch_columns(mfa_gc *gc, const int32_t *id2pdf, int32_t n_threads, int64_t *state_off, int64_t *arc_base,
-                         int64_t *arc_off, int32_t *arc_off32, void *arcs, float *final_w, int32_t *arc_next, int32_t *arc_pdf) {
+                         int64_t *arc_off, int32_t *arc_off32, void *arcs, float *final_w, int32_t *arc_next, int32_t *arc_pdf,
+                         int32_t *stats) {
   if (!gc) return -1;
   const int n = (int)gc->res.size();
   std::vector<int64_t> so((size_t)n + 1, 0), ab((size_t)n + 1, 0);
@@ -998,9 +999,19 @@ int mfa_gc_fetch_columns(mfa_gc *gc, const int32_t *id2pdf, int32_t n_threads, i
   if (arc_base) memcpy(arc_base, ab.data(), sizeof(int64_t) * (n + 1));
   OutArc *out = (OutArc *)arcs;
   std::atomic<int> bad(0);
+  std::atomic<int> max_deg(0), min_il(INT32_MAX), min_arcs(INT32_MAX);
   parallel_for(n, n_threads, [&](int u) {
     const UttResult &r = gc->res[u];
     const int64_t S = so[u], A = ab[u], O = so[u] + u;
+    if (stats) {      // what the caller would otherwise find with passes of its own: largest out-degree, smallest input label, fewest arcs
+      int md = 0, mi = INT32_MAX;
+      for (size_t i = 0; i + 1 < r.offs.size(); i++) md = std::max(md, (int)(r.offs[i + 1] - r.offs[i]));
+      for (const OutArc &a : r.arcs) mi = std::min(mi, (int)a.il);
+      int cur = max_deg.load(); while (md > cur && !max_deg.compare_exchange_weak(cur, md)) {}
+      cur = min_il.load(); while (mi < cur && !min_il.compare_exchange_weak(cur, mi)) {}
+      const int na = (int)r.arcs.size();
+      cur = min_arcs.load(); while (na < cur && !min_arcs.compare_exchange_weak(cur, na)) {}
+    }
     if (arc_off) memcpy(arc_off + O, r.offs.data(), r.offs.size() * sizeof(int64_t));
     if (arc_off32) for (size_t i = 0; i < r.offs.size(); i++) arc_off32[O + i] = (int32_t)r.offs[i];
     if (out && !r.arcs.empty()) memcpy(out + A, r.arcs.data(), r.arcs.size() * sizeof(OutArc));
@@ -1012,6 +1023,7 @@ int mfa_gc_fetch_columns(mfa_gc *gc, const int32_t *id2pdf, int32_t n_threads, i
         if (il < 0 || il > gc->n_tids) { bad.store(1); arc_pdf[A + i] = -1; } else arc_pdf[A + i] = id2pdf[il];
       }
   });
+  if (stats) { stats[0] = max_deg.load(); stats[1] = min_il.load(); stats[2] = min_arcs.load(); }
   if (bad.load()) return gc->fail("an arc carries an input label outside the model's transition-ids");
   return 0;
 }

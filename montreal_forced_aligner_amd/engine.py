@@ -269,7 +269,15 @@ class AlignmentEngine:
 
     # ------------------------------------------------------------------ stages
     def _dev(self, a: np.ndarray) -> torch.Tensor:
-        return torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+        """Host array → device, without making the host wait for the device: the array is copied into pinned memory from
+        torch's caching host allocator (which keeps the block until the copy has run) and sent asynchronously.  A pageable
+        ``.to(device)`` would block until everything queued on the stream before it has finished — i.e. until the previous
+        batch has been decoded."""
+        t = torch.from_numpy(np.ascontiguousarray(a))
+        if t.numel() == 0:
+            return t.to(self.device)
+        with torch.cuda.device(self.device):
+            return t.pin_memory().to(self.device, non_blocking=True)
 
     def frame_offsets(self, sample_off: np.ndarray) -> np.ndarray:
         frames = self.num_frames_array(np.diff(sample_off))
@@ -499,7 +507,7 @@ class AlignmentEngine:
         if columns:
             # (the compiler produced next-state and pdf columns; an input label outside the model was refused there)
             nxt, pdf_of_arc = fsts.arc_next, fsts.arc_pdf
-            if arcs.shape[0] and int(pdf_of_arc.min()) < 0:
+            if arcs.shape[0] and (fsts.min_ilabel <= 0 if getattr(fsts, "min_ilabel", None) is not None else int(pdf_of_arc.min()) < 0):
                 raise _lib.MfaHipError("a natively compiled batch cannot hold epsilon input arcs")
         else:
             il = arcs["ilabel"]
@@ -523,7 +531,10 @@ class AlignmentEngine:
                                               else tm.id2pdf[il], dtype=np.int32)
             nxt = np.ascontiguousarray(arcs["nextstate"], dtype=np.int32)
         # (the concatenated offsets restart at every utterance: those steps are <= 0 and do not disturb the maximum)
-        max_deg = int(np.diff(arc_off).max()) if arc_off.shape[0] > 1 else 0
+        if columns and getattr(fsts, "max_degree", None) is not None:
+            max_deg = int(fsts.max_degree)
+        else:
+            max_deg = int(np.diff(arc_off).max()) if arc_off.shape[0] > 1 else 0
         if max_deg > 64 and nemit is None:
             raise _lib.MfaHipError(f"a graph state has {max_deg} arcs; the device decoder supports at most 64")
         span = 0 if cluster_gap is None else int(cluster_gap)

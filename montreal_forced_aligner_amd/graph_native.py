@@ -73,7 +73,7 @@ SIGNATURES = {
     "mfa_gc_resolve_windows": (_i64, [_vp]),
     "mfa_gc_finish": (C.c_int, [_vp, _vp, _i32, C.POINTER(_i64), C.POINTER(_i64)]),
     "mfa_gc_fetch": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
-    "mfa_gc_fetch_columns": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mfa_gc_fetch_columns": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 _lib = None
 
@@ -113,6 +113,7 @@ class FstBatch(list):
     arc_next: Optional[np.ndarray] = None     # int32 [total arcs]
     arc_pdf: Optional[np.ndarray] = None      # int32 [total arcs] pdf of the arc's transition-id
     staging = None                            # the object whose ``get`` allocated these arrays (engine.StagingPool), if any
+    max_degree = min_ilabel = min_arcs = None  # (fetch_columns) largest out-degree, smallest input label, fewest arcs of an utterance
 
 
 class NativeGraphCompiler:
@@ -343,8 +344,9 @@ class NativeGraphCompiler:
         if columns:
             arc_off32, arc_next, arc_pdf = alloc("arc_off32", S + n, np.int32), alloc("arc_next", A, np.int32), alloc("arc_pdf", A, np.int32)
             id2pdf = np.ascontiguousarray(self.compiler.tm.id2pdf, dtype=np.int32)
+        stats = np.zeros(3, dtype=np.int32)
         self._check(self.lib.mfa_gc_fetch_columns(self._h, _ptr(id2pdf), self.n_threads, _ptr(state_off), _ptr(arc_base), _ptr(arc_off),
-                                                  _ptr(arc_off32), _ptr(arcs), _ptr(final), _ptr(arc_next), _ptr(arc_pdf)),
+                                                  _ptr(arc_off32), _ptr(arcs), _ptr(final), _ptr(arc_next), _ptr(arc_pdf), _ptr(stats)),
                     "mfa_gc_fetch_columns")
         for j, k in enumerate(native):
             s0, s1, a0, a1 = int(state_off[j]), int(state_off[j + 1]), int(arc_base[j]), int(arc_base[j + 1])
@@ -355,4 +357,5 @@ class NativeGraphCompiler:
         batch.state_off, batch.arc_base, batch.arc_off, batch.arcs, batch.final = state_off, arc_base, arc_off, arcs, final
         batch.arc_off32, batch.arc_next, batch.arc_pdf = arc_off32, arc_next, arc_pdf
         batch.staging = staging
+        batch.max_degree, batch.min_ilabel, batch.min_arcs = int(stats[0]), int(stats[1]), int(stats[2])
         return batch

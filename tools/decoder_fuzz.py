@@ -1,5 +1,7 @@
-"""Extended decoder fuzz beyond the test suite's seeds (GPU; run from the repo root: python tools/decoder_fuzz.py).
-Random graphs, random or tie-heavy scores, random beams; every utterance must match the oracle bit for bit."""
+"""Extended decoder fuzz beyond the test suite's seeds (GPU; run from the repo root: python tools/decoder_fuzz.py [--eps]).
+Random graphs, random or tie-heavy scores, random beams; every utterance must match the oracle bit for bit.
+--eps: a fifth of every graph's arcs become epsilon input arcs (chains, zero-weight cycles, a quarter of the forward ones with
+negative weights) — ProcessNonemitting inside the wavefront-parallel decoder, tie-heavy scores included."""
 import sys
 sys.path.insert(0, '.')
 import numpy as np, torch
@@ -9,13 +11,26 @@ from montreal_forced_aligner_amd.engine import AlignmentEngine
 fx = helpers.Fixtures()
 eng = AlignmentEngine(0)
 tm = fx.mono_tm
+from montreal_forced_aligner_amd import kaldi_io as K
+EPS = "--eps" in sys.argv
 bad = 0
 for seed in range(3, 23):
     rng = np.random.default_rng(5000 + seed)
     fsts, lls = [], []
     for u in range(16):
         S = int(rng.choice([2, 5, 17, 64, 129, 300, 700]))
-        fsts.append(_random_graph(rng, tm, S))
+        f = _random_graph(rng, tm, S)
+        if EPS:
+            arcs = f.arcs.copy()
+            eps = rng.random(len(arcs)) < 0.2
+            arcs["ilabel"][eps] = 0
+            src = np.repeat(np.arange(f.num_states), np.diff(f.arc_offsets))
+            neg = eps & (arcs["nextstate"] > src) & (rng.random(len(arcs)) < 0.25)
+            arcs["weight"][neg] -= 0.5
+            f = K.Fst(f.start, f.arc_offsets, arcs, f.final)
+            if eng.needs_general_decoder(f):
+                f = _random_graph(rng, tm, 5)
+        fsts.append(f)
         T = int(rng.integers(1, 140))
         if rng.random() < 0.4:
             ll = (rng.integers(-240, -160, size=(T, tm.num_pdfs)) * 0.25).astype(np.float32)
