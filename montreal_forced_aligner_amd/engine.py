@@ -268,16 +268,37 @@ class AlignmentEngine:
         return out.astype(np.int64)
 
     # ------------------------------------------------------------------ stages
+    _SLAB_BYTES = 512 << 20
+
     def _dev(self, a: np.ndarray) -> torch.Tensor:
-        """Host array → device, without making the host wait for the device: the array is copied into pinned memory from
-        torch's caching host allocator (which keeps the block until the copy has run) and sent asynchronously.  A pageable
-        ``.to(device)`` would block until everything queued on the stream before it has finished — i.e. until the previous
-        batch has been decoded."""
-        t = torch.from_numpy(np.ascontiguousarray(a))
-        if t.numel() == 0:
-            return t.to(self.device)
+        """Host array → device, without making the host wait for the device: the array is copied into a slab of pinned
+        memory (bump allocation, wrap-around after a stream synchronisation — once every several batches) and sent
+        asynchronously.  A pageable ``.to(device)`` would block until everything queued on the stream before it has finished,
+        i.e. until the previous batch has been decoded; ``Tensor.pin_memory()`` per array costs a pinned allocation (3 ms on
+        this runtime)."""
+        a = np.ascontiguousarray(a)
+        nbytes = a.nbytes
+        if nbytes == 0 or nbytes > self._SLAB_BYTES // 4:
+            return torch.from_numpy(a).to(self.device)
+        slab = getattr(self, "_slab", None)
+        if slab is None:
+            try:
+                slab = self._slab = torch.empty(self._SLAB_BYTES, dtype=torch.uint8, pin_memory=True)
+            except RuntimeError:
+                self._slab = False
+                return torch.from_numpy(a).to(self.device)
+            self._slab_off = 0
+        elif slab is False:
+            return torch.from_numpy(a).to(self.device)
+        off = (self._slab_off + 255) & ~255
+        if off + nbytes > self._SLAB_BYTES:
+            torch.cuda.current_stream(self.device).synchronize()      # every copy out of the slab has run
+            off = 0
+        self._slab_off = off + nbytes
+        view = slab.numpy()[off: off + nbytes].view(a.dtype).reshape(a.shape)
+        view[...] = a
         with torch.cuda.device(self.device):
-            return t.pin_memory().to(self.device, non_blocking=True)
+            return torch.from_numpy(view).to(self.device, non_blocking=True)
 
     def frame_offsets(self, sample_off: np.ndarray) -> np.ndarray:
         frames = self.num_frames_array(np.diff(sample_off))
