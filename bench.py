@@ -498,6 +498,16 @@ def main():
             ca.align(utts_e2e, make_ctm=False, previous_transforms=prev_tf)
         e2e = {}
         holder = {}
+        if os.environ.get("MFA_BENCH_PROFILE_E2E"):     # where the host loop's time goes (stderr)
+            import cProfile
+            import pstats
+            pr_ = cProfile.Profile()
+            pr_.enable()
+            ca.align(utts_e2e, make_ctm=False, previous_transforms=prev_tf)
+            pr_.disable()
+            st_ = pstats.Stats(pr_, stream=sys.stderr).sort_stats("cumulative")
+            st_.print_stats(40)
+            st_.print_callers("wait|synchronize")
         dt_a = timed_loop(lambda: holder.__setitem__("res", ca.align(utts_e2e, make_ctm=False, previous_transforms=prev_tf)), 1)
         ok_a = sum(r is not None for r in holder["res"])
         e2e["alignments"] = {"value": round(B * world / dt_a, 2), "seconds": round(dt_a, 3), "aligned_fraction": ok_a / B}

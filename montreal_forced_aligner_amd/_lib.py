@@ -11,7 +11,7 @@ import subprocess
 from pathlib import Path
 
 _PKG = Path(__file__).resolve().parent
-_SO = _PKG / "libmfa_hip.so"
+_SO = Path(os.environ["MFA_HIP_SO"]).resolve() if os.environ.get("MFA_HIP_SO") else _PKG / "libmfa_hip.so"   # (override: A/B builds)
 _SOURCES = ["api.hip", "mfcc.hip", "feats.hip", "gmm.hip", "viterbi.hip", "viterbi_general.hip", "fmllr.hip"]
 _LIB = None
 

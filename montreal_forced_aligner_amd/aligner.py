@@ -249,11 +249,14 @@ class CorpusAligner:
         # per-batch statistics come from the device kernel (float64, fixed order); batches are added up on the host, in
         # batch order — a few hundred bytes per speaker, and no framework arithmetic on the path
         total = np.zeros((len(spk_ids), 2, self.engine.num_ceps + 1), dtype=np.float64)
+        pending = []
         for idx in self._batches(utts):
             mfcc, fo = self._mfcc(utts, idx)
             rows = np.array([spk_ids[utts[i].speaker] for i in idx], dtype=np.int32)
             local, inv = np.unique(rows, return_inverse=True)
-            st = self.engine.cmvn_stats(mfcc, fo, inv.astype(np.int32), len(local))
+            pending.append((local, self.engine.cmvn_stats(mfcc, fo, inv.astype(np.int32), len(local))))
+        # read back after the last batch is queued: the next batch's PCM is gathered while this one's copy is on the bus
+        for local, st in pending:
             total[local] += st.cpu().numpy()
         return spk_ids, torch.from_numpy(total).to(self.engine.device)
 

@@ -684,11 +684,25 @@ void minimize_encoded(std::vector<DArc> &arcs, std::vector<int> &off, std::vecto
   arcs.swap(out); off.swap(out_off); fin.swap(of); has.swap(oh);
 }
 
+#ifdef MFA_GC_TIMERS
+#include <chrono>
+static std::atomic<long long> g_ns[6];
+struct PhaseClock {
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  void lap(int k) { auto n = std::chrono::steady_clock::now(); g_ns[k] += std::chrono::duration_cast<std::chrono::nanoseconds>(n - t).count(); t = n; }
+};
+#define GC_LAP(k) clk_.lap(k)
+#define GC_CLOCK() PhaseClock clk_
+#else
+#define GC_LAP(k) ((void)0)
+#define GC_CLOCK() ((void)0)
+#endif
 // graph.py TrainingGraphCompiler._expand_hmm (+ add_transition_probs)
 bool expand_hmm(const mfa_gc &gc, const CtxGraph &cg, const float *neg_scaled, UttResult &r, std::string &err) {
   // "G0" (forward transitions only) as one arc pool with a per-node chain in insertion order — nodes are created on the fly
   // and a vector per node was most of this function's time
   struct GArc { int dst, tid, ol, next; double w; };
+  GC_CLOCK();
   const int J = cg.num_nodes;
   std::vector<GArc> pool;
   std::vector<int> head(J, -1), tail(J, -1);
@@ -731,12 +745,15 @@ bool expand_hmm(const mfa_gc &gc, const CtxGraph &cg, const float *neg_scaled, U
   std::vector<char> g_has(head.size(), 0);
   for (int u = 0; u < J; u++) if (cg.has_fin[u]) { g_fin[u] = cg.fin[u]; g_has[u] = 1; }
   int g_start = cg.start;
+  GC_LAP(0);
   if (gc.determinize) {
     std::vector<DArc> d_arcs;
     std::vector<int> d_off;
     std::vector<double> d_fin; std::vector<char> d_has;
     if (determinize_star_log(pool, head, g_fin, g_has, cg.start, d_arcs, d_off, d_fin, d_has)) {
+      GC_LAP(1);
       minimize_encoded(d_arcs, d_off, d_fin, d_has);
+      GC_LAP(2);
       const size_t dn = d_off.size() - 1;
       pool.clear(); head.assign(dn, -1); tail.assign(dn, -1);
       for (size_t u = 0; u < dn; u++) for (int k = d_off[u]; k < d_off[u + 1]; k++) add_arc((int)u, d_arcs[k].dst, d_arcs[k].tid, d_arcs[k].ol, d_arcs[k].w);
@@ -744,6 +761,7 @@ bool expand_hmm(const mfa_gc &gc, const CtxGraph &cg, const float *neg_scaled, U
       g_start = 0;
     }
   }
+  GC_LAP(3);
   // (node, incoming transition-state) → output state: open addressing, keys in first-seen order in `order`
   size_t cap = 64;
   while (cap < pool.size() * 4 + 16) cap <<= 1;
@@ -783,6 +801,7 @@ bool expand_hmm(const mfa_gc &gc, const CtxGraph &cg, const float *neg_scaled, U
   }
   if (neg_scaled)
     for (OutArc &a : r.arcs) if (a.il > 0) a.w = a.w + neg_scaled[a.il];
+  GC_LAP(4);
   return true;
 }
 
@@ -962,6 +981,11 @@ int mfa_gc_finish(mfa_gc *gc, const float *neg_scaled_log_probs, int32_t n_threa
   for (const UttResult &r : gc->res) { S += (int64_t)r.fin.size(); A += (int64_t)r.arcs.size(); }
   *n_states = S; *n_arcs = A;
   gc->ctx.clear();
+#ifdef MFA_GC_TIMERS
+  fprintf(stderr, "[gc timers] G0 %.1f ms, determinize %.1f, minimize %.1f, rebuild %.1f, self-loops %.1f\n", g_ns[0] / 1e6, g_ns[1] / 1e6,
+          g_ns[2] / 1e6, g_ns[3] / 1e6, g_ns[4] / 1e6);
+  for (auto &x : g_ns) x = 0;
+#endif
   return 0;
 }
 

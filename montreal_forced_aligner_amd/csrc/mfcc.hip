@@ -28,7 +28,10 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 
 constexpr int kNfft = 512;
 constexpr int kHalf = 256;
-constexpr int kWavesPerBlock = 8;
+#ifndef MFA_MFCC_WAVES
+#define MFA_MFCC_WAVES 8
+#endif
+constexpr int kWavesPerBlock = MFA_MFCC_WAVES;
 constexpr int kFramesPerWave = 16;      // four passes of four frames
 constexpr int kFramesPerBlock = kWavesPerBlock * kFramesPerWave;
 constexpr int kMaxBins = 32;

@@ -32,11 +32,9 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
-def _host_threads() -> int:
-    try:
-        return max(1, min(32, len(os.sched_getaffinity(0))))
-    except AttributeError:
-        return max(1, min(32, os.cpu_count() or 1))
+def _host_threads(share: float = 1.0, cap: int = 32) -> int:
+    from . import hostcpu
+    return hostcpu.threads(share, cap)
 
 
 class RaggedView:
@@ -194,7 +192,7 @@ class AlignmentEngine:
                 a = np.ascontiguousarray(a, dtype=np.int16)
                 keep.append(a)
             ptrs[k] = a.__array_interface__["data"][0]
-        if self.lib.mfa_gather_pcm(n, ptrs, so.ctypes.data, stage.ctypes.data, _host_threads()) != 0:
+        if self.lib.mfa_gather_pcm(n, ptrs, so.ctypes.data, stage.ctypes.data, _host_threads(0.5, 8)) != 0:
             raise _lib.MfaHipError("mfa_gather_pcm: bad arguments")
         return pool.to_device(stage, self.stream), so
 

@@ -123,11 +123,8 @@ class NativeGraphCompiler:
     def __init__(self, compiler: _graph.TrainingGraphCompiler, n_threads: Optional[int] = None):
         self.compiler = compiler
         self.lib = load()
-        try:
-            avail = len(os.sched_getaffinity(0))
-        except AttributeError:
-            avail = os.cpu_count() or 1
-        self.n_threads = max(1, min(32, avail)) if n_threads is None else max(1, int(n_threads))
+        from . import hostcpu
+        self.n_threads = hostcpu.threads() if n_threads is None else max(1, int(n_threads))
         lex = compiler.lexicon
         if lex.phone_table is None:
             lex.build_phone_table()

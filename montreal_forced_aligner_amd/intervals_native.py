@@ -93,10 +93,8 @@ def _strings(names: Sequence[str]):
 
 
 def _threads() -> int:
-    try:
-        return max(1, min(32, len(os.sched_getaffinity(0))))
-    except AttributeError:
-        return max(1, min(32, os.cpu_count() or 1))
+    from . import hostcpu
+    return hostcpu.threads()
 
 
 class IntervalBatch:
