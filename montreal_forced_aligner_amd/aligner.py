@@ -373,23 +373,37 @@ class CorpusAligner:
         status, ali, words = h["status"].copy(), h["ali"].copy(), h["words"].copy()
         n_words, like = h["n_words"].copy(), h["like"].copy()
         # Capacity overflows (status 3 tokens / 4 back-pointers) are not alignment failures: those utterances are decoded
-        # again on their own with the hard upper bounds (one token per graph state), which cannot overflow.
+        # again on their own with the hard upper bounds (one token per graph state), which cannot overflow — and what still
+        # reports a capacity status then (the epsilon closure's pop budget on a pathological epsilon sub-graph) goes to the
+        # general decoder, which runs Kaldi's loops as they are.
         over = np.flatnonzero((status == 3) | (status == 4)).tolist()
         if over:
+            def take(ks):
+                fo_s = np.concatenate([[0], np.cumsum([fo[k + 1] - fo[k] for k in ks])]).astype(np.int64)
+                sel = np.concatenate([np.arange(fo[k], fo[k + 1]) for k in ks])
+                return fo_s, eng.gather_rows(feats, sel)
+
+            def merge(ks, fo_s, r):
+                st_, ali_, w_ = r["status"].cpu().numpy(), r["ali"].cpu().numpy(), r["words"].cpu().numpy()
+                nw_, like_ = r["n_words"].cpu().numpy(), r["like"].cpu().numpy()
+                for j, k in enumerate(ks):
+                    status[k] = st_[j]
+                    a, b = int(fo[k]), int(fo[k + 1])
+                    ali[a:b] = ali_[fo_s[j]: fo_s[j + 1]]
+                    n_words[k] = nw_[j]
+                    words[a: a + int(nw_[j])] = w_[fo_s[j]: fo_s[j] + int(nw_[j])]
+                    like[k] = like_[j]
+
             sub = eng.pack_graphs([fsts[k] for k in over], self.tm)
-            fo2 = np.concatenate([[0], np.cumsum([fo[k + 1] - fo[k] for k in over])]).astype(np.int64)
-            sel = np.concatenate([np.arange(fo[k], fo[k + 1]) for k in over])
-            f2 = eng.gather_rows(feats, sel)
-            r2 = self._decode(sub, f2, fo2, sub.max_states, sub.max_states)
-            st2, ali2, w2 = r2["status"].cpu().numpy(), r2["ali"].cpu().numpy(), r2["words"].cpu().numpy()
-            nw2, like2 = r2["n_words"].cpu().numpy(), r2["like"].cpu().numpy()
-            for j, k in enumerate(over):
-                status[k] = st2[j]
-                a, b = int(fo[k]), int(fo[k + 1])
-                ali[a:b] = ali2[fo2[j]: fo2[j + 1]]
-                n_words[k] = nw2[j]
-                words[a: a + int(nw2[j])] = w2[fo2[j]: fo2[j] + int(nw2[j])]
-                like[k] = like2[j]
+            fo2, f2 = take(over)
+            mt, bp = sub.hard_bounds()
+            merge(over, fo2, self._decode(sub, f2, fo2, mt, bp))
+            still = [k for k in over if status[k] in (3, 4)]
+            if still:
+                gg = eng.pack_graphs_general([fsts[k] for k in still], self.tm)
+                fo3, f3 = take(still)
+                merge(still, fo3, eng.align_general(gg, f3, fo3, beam=o.beam, retry_beam=o.retry_beam,
+                                                    acoustic_scale=o.acoustic_scale, bp_tokens_per_frame=2 * gg.max_states + 64))
             if want_feats:
                 res["ali"] = torch.from_numpy(ali).to(eng.device)
         out = _BatchOut(idx, fo, ali, words, n_words, like, status)

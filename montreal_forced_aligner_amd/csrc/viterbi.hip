@@ -69,6 +69,7 @@ struct VitParams {
   // out-degree above counts the emitting ones): per state {first epsilon arc << 7 | number of epsilon arcs}, built once per call
   const u32 *w_epsinfo;                // [n_utt * max_states] at (utt * max_states + state), or NULL
   int eps_stride;                      // max_states
+  int eps_pops;                        // pops of one frame's epsilon closure before the utterance is handed back with a capacity status (64 per token slot; Kaldi has no budget: the caller's last resort is the general decoder)
   unsigned long long *stamps;          // -DVIT_STAMPS builds: per-utterance phase cycles (mfa_debug_viterbi_stamps) or NULL
   int llcap;                           // score-row cache capacity in LDS (floats); rows longer than this are read from HBM
   // windowed (resumable) decoding — mfa_align_features_batch: one launch decodes frames [t_begin, t_end) of every utterance,
@@ -499,7 +500,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         int guard = 0;
         bool over = false;
         while (sp > 0u && !over) {
-          if (++guard > 64 * N) { over = true; break; }
+          if (++guard > p.eps_pops) { over = true; break; }
           const u32 e = e_stk[sp - 1u];
           sp--;
           const double ce = __longlong_as_double((long long)s_cost[e]);
@@ -1037,7 +1038,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         int guard = 0;
         bool eps_over = false;
         while (sp > 0u) {
-          if (++guard > 64 * N) { eps_over = true; break; }
+          if (++guard > p.eps_pops) { eps_over = true; break; }
           const u32 e = e_stk[sp - 1u];
           sp--;
           const double ce = dunkey(s_cost[e]);
@@ -1812,6 +1813,9 @@ int align_impl(mfa_ctx *c, const mfa_graph_batch *g, const float *d_loglikes, co
     p.w_hash = (u32 *)(base + w.hash);     // fixed location across launches
     p.w_arcnext = (const uint4 *)(base + w.arcnext);
     p.w_epsinfo = eps ? (const u32 *)(base + w.eps) : nullptr; p.eps_stride = max_states;
+    int eps_pops_env = 0;                  // MFA_VIT_EPS_POPS (tests: forces the hand-over to the general decoder)
+    { const char *e = getenv("MFA_VIT_EPS_POPS"); if (e && atoi(e) > 0) eps_pops_env = atoi(e); }
+    p.eps_pops = eps_pops_env ? eps_pops_env : 64 * L.N;
     p.llcap = kLlCap;
     p.stamps = (unsigned long long *)c->vit_stamps;
     int32_t *d_list = (int32_t *)(base + w.list), *d_count = (int32_t *)(base + w.count);
@@ -1838,6 +1842,7 @@ int align_impl(mfa_ctx *c, const mfa_graph_batch *g, const float *d_loglikes, co
       if (lds2 > kLdsLimit) return c->fail("Viterbi large tier needs %zu bytes of LDS", lds2);
       WsLayout w2 = ws_layout(n_utt, total_frames, L.N2, L.C2, bpf, total_arcs, eps_states);
       p2.nmax = L.N2; p2.cmax = L.C2; p2.hbits = hash_bits(max_states, L.N2);
+      p2.eps_pops = eps_pops_env ? eps_pops_env : 64 * L.N2;
       // park arrays (state / cost) and the back-pointer trail are SHARED between the tiers: the layout of the large one
       p2.w_state = (u32 *)(base + w2.state); p2.w_cost = (double *)(base + w2.cost);
       p2.w_stash_a = (u32 *)(base + w2.sta); p2.w_stash_b = (u32 *)(base + w2.stb); p2.w_stash_key = (u64 *)(base + w2.stkey);

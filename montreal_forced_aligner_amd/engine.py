@@ -11,7 +11,7 @@ from __future__ import annotations
 import os
 import ctypes as C
 from dataclasses import dataclass
-from typing import Dict, List, Optional, Sequence
+from typing import Tuple, Dict, List, Optional, Sequence
 
 import numpy as np
 import torch
@@ -132,6 +132,18 @@ class PackedGraphs:
                          self.pdf_first_frame.data_ptr(), self.pdf_last_depth.data_ptr(), self.state_depth.data_ptr(),
                          int(np.diff(self.pdf_off_host).max()) if self.n_utt else 0, int(self.groups),
                          self.group_counts.data_ptr() if self.group_counts is not None else None)
+
+    @property
+    def has_eps(self) -> bool:
+        """Some graph of the batch has epsilon input arcs (the decoder then runs ProcessNonemitting after every frame)."""
+        return self.tensors.get("state_nemit") is not None
+
+    def hard_bounds(self) -> Tuple[int, int]:
+        """(max_tokens, bp_tokens_per_frame) that the decoder's capacity statuses cannot occur with: one token per graph state
+        — and, for graphs with epsilon arcs, room behind the back-pointer trail for the path the traceback writes there
+        (T + E arc indices, E ≤ T·S in the worst case: half a record per frame and state)."""
+        s = max(1, int(self.max_states))
+        return s, s + (s // 2 + 2 if self.has_eps else 0)
 
     def struct(self) -> GraphBatch:
         t = self.tensors

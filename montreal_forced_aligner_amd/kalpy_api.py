@@ -482,18 +482,34 @@ class GmmAligner:
         # overflow, exactly as CorpusAligner._pass does.
         over = [u for u in range(len(fsts)) if int(res["status"][u]) in (3, 4)]
         if over:
+            def take(us):
+                fo_s = np.concatenate([[0], np.cumsum([frame_off[u + 1] - frame_off[u] for u in us])]).astype(np.int64)
+                return fo_s, eng.gather_rows(d_feats, np.concatenate([np.arange(frame_off[u], frame_off[u + 1]) for u in us]))
+
+            def merge(us, fo_s, r):
+                r = {k: r[k].cpu().numpy() for k in self._RESULT_KEYS}
+                for j, u in enumerate(us):
+                    a, b, a2, b2 = int(frame_off[u]), int(frame_off[u + 1]), int(fo_s[j]), int(fo_s[j + 1])
+                    for k in ("ali", "words", "frame_like"):
+                        res[k][a:b] = r[k][a2:b2]
+                    for k in ("n_words", "like", "status"):
+                        res[k][u] = r[k][j]
+
             sub = eng.pack_graphs([scaled_fsts[u] for u in over], self.transition_model)
-            fo2 = np.concatenate([[0], np.cumsum([frame_off[u + 1] - frame_off[u] for u in over])]).astype(np.int64)
-            f2 = eng.gather_rows(d_feats, np.concatenate([np.arange(frame_off[u], frame_off[u + 1]) for u in over]))
-            r2 = eng.align_features(sub, f2, fo2, beam=self.beam, retry_beam=self.retry_beam, acoustic_scale=self.acoustic_scale,
-                                    max_tokens=sub.max_states, bp_tokens_per_frame=sub.max_states, want_frame_likes=True)
-            r2 = {k: r2[k].cpu().numpy() for k in self._RESULT_KEYS}
-            for j, u in enumerate(over):
-                a, b, a2, b2 = int(frame_off[u]), int(frame_off[u + 1]), int(fo2[j]), int(fo2[j + 1])
-                for k in ("ali", "words", "frame_like"):
-                    res[k][a:b] = r2[k][a2:b2]
-                for k in ("n_words", "like", "status"):
-                    res[k][u] = r2[k][j]
+            fo2, f2 = take(over)
+            mt, bp = sub.hard_bounds()
+            merge(over, fo2, eng.align_features(sub, f2, fo2, beam=self.beam, retry_beam=self.retry_beam,
+                                                acoustic_scale=self.acoustic_scale, max_tokens=mt, bp_tokens_per_frame=bp,
+                                                want_frame_likes=True))
+            # what still reports a capacity status (the epsilon closure's pop budget on a pathological epsilon sub-graph)
+            # goes to the general decoder: Kaldi's loops as they are, no budget
+            still = [u for u in over if int(res["status"][u]) in (3, 4)]
+            if still:
+                gg = eng.pack_graphs_general([scaled_fsts[u] for u in still], self.transition_model)
+                fo3, f3 = take(still)
+                merge(still, fo3, eng.align_general(gg, f3, fo3, beam=self.beam, retry_beam=self.retry_beam,
+                                                    acoustic_scale=self.acoustic_scale, bp_tokens_per_frame=2 * gg.max_states + 64,
+                                                    want_frame_likes=True))
         return self._collect(res, frame_off, len(fsts), utterance_ids)
 
     _RESULT_KEYS = ("ali", "words", "n_words", "like", "status", "frame_like")

@@ -167,6 +167,47 @@ def test_kalpy_facade_routes_epsilon_graphs(engine, fx):
     assert out[0].alignment == out[2].alignment
 
 
+def test_epsilon_closure_budget_hands_over_to_the_general_decoder(engine, fx, monkeypatch):
+    """Kaldi's ProcessNonemitting has no budget; the wavefront kernel's closure has one (64 pops per token slot and frame:
+    tools/decoder_fuzz.py --eps seed 325 — 700 states, a fifth of the arcs epsilon, a quarter of those with negative weights,
+    beam 30 — exceeds it and comes back with a capacity status).  The product path must not report that as a failed
+    alignment: after the hard-bounds redo the utterance goes to the general decoder.  Forced here with a budget of one pop."""
+    from montreal_forced_aligner_amd import kalpy_api as KA
+
+    tm, am = fx.mono_tm, fx.mono_am
+    rng = np.random.default_rng(11)
+    x = fx.mono_feats(fx.pcm[: 16000 * 4])
+    plain = fx.mono_gc.compile_fst("this is the acoustic corpus")
+    eps = _with_eps(rng, plain)
+    al = KA.GmmAligner.__new__(KA.GmmAligner)
+    al.acoustic_model_path = "mono"; al.transition_model, al.acoustic_model = tm, am
+    al.beam, al.retry_beam = 100.0, 400.0
+    al.transition_scale, al.acoustic_scale, al.self_loop_scale = 1.0, 0.1, 0.1
+    al.disambiguation_symbols = []
+    al._scaled = tm.scaled_log_probs(1.0, 0.1)
+    al._loaded = False
+    KA._ENGINE = engine
+    scaled = G.add_transition_probs(eps, al._scaled)
+    ref = _oracle(tm, am, scaled, x, 100.0, 400.0)
+    assert ref["status"] in (0, 1)
+    monkeypatch.setenv("MFA_VIT_EPS_POPS", "1")
+    # the engine itself reports the capacity status, also with the hard bounds ...
+    engine.load_gmm(am)
+    g = engine.pack_graphs([scaled], tm)
+    assert g.has_eps and g.hard_bounds() == (g.max_states, g.max_states + g.max_states // 2 + 2)
+    fo = np.array([0, x.shape[0]], dtype=np.int64)
+    mt, bp = g.hard_bounds()
+    r = engine.align_features(g, _dev(engine, x), fo, beam=100.0, retry_beam=400.0, max_tokens=mt, bp_tokens_per_frame=bp)
+    assert int(r["status"].cpu().numpy()[0]) == 3
+    # ... and the kalpy-shaped aligner hands the utterance over: same alignment as with the default budget and as the oracle's
+    out = al.align_utterances([plain, eps], [x, x], ["a", "b"])
+    assert out[0] is not None and out[1] is not None
+    assert out[1].alignment == ref["ali"].tolist() and out[1].words == ref["words"].tolist()
+    monkeypatch.delenv("MFA_VIT_EPS_POPS")
+    again = al.align_utterances([eps], [x], ["b"])
+    assert again[0].alignment == out[1].alignment and again[0].likelihood == out[1].likelihood
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # Round 3: epsilon input arcs on the wavefront-parallel decoder (pack_graphs stores every state's arcs [emitting | epsilon],
 # the kEps instantiation of viterbi_kernel runs ProcessNonemitting after every frame) — the lazy-scored, windowed product path.

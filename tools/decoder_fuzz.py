@@ -13,8 +13,10 @@ eng = AlignmentEngine(0)
 tm = fx.mono_tm
 from montreal_forced_aligner_amd import kaldi_io as K
 EPS = "--eps" in sys.argv
+_nums = [int(a) for a in sys.argv[1:] if a.lstrip("-").isdigit()]      # optional: first seed, number of seeds
+seed0, n_seeds = (_nums + [3, 20])[:2] if len(_nums) >= 2 else (3, (_nums + [20])[0])
 bad = 0
-for seed in range(3, 23):
+for seed in range(seed0, seed0 + n_seeds):
     rng = np.random.default_rng(5000 + seed)
     fsts, lls = [], []
     for u in range(16):
@@ -43,6 +45,33 @@ for seed in range(3, 23):
         res = _align_case(eng, tm, fx.mono_am, fsts, lls, beam, retry, max_tokens=1024, bp_tokens=700)
         print(seed, beam, retry, np.unique(res["status"], return_counts=True), flush=True)
     except AssertionError as e:
+        arg = e.args[0] if e.args else None
+        if EPS and isinstance(arg, tuple) and len(arg) == 3 and int(arg[1]) == 3 and int(arg[2]) in (0, 1):
+            # the epsilon closure's pop budget (Kaldi has none): the product path hands such an utterance to the general
+            # decoder (aligner._collect, kalpy_api.align_utterances) — do the same and hold THAT to the oracle
+            u = int(arg[0])
+            gg = eng.pack_graphs_general([fsts[u]], tm)
+            cols = lls[u][:, gg.pdf_lists_host[0]]
+            import ctypes as C
+            from montreal_forced_aligner_amd.engine import AlignOpts, _ptr, check
+            T = cols.shape[0]
+            d_ll = torch.from_numpy(np.ascontiguousarray(cols.reshape(-1))).to(eng.device)
+            ali = torch.zeros(T, dtype=torch.int32, device=eng.device); words = torch.zeros(T, dtype=torch.int32, device=eng.device)
+            n_words = torch.zeros(1, dtype=torch.int32, device=eng.device); like = torch.zeros(1, dtype=torch.float32, device=eng.device)
+            status = torch.full((1,), -1, dtype=torch.int32, device=eng.device)
+            ll_off = np.array([0, cols.size], dtype=np.int64); fo = np.array([0, T], dtype=np.int64)
+            ll_cols = torch.tensor([cols.shape[1]], dtype=torch.int32, device=eng.device)
+            opts = AlignOpts(beam, retry, 0.1, 0, 2 * gg.max_states + 64)
+            gs = gg.struct()
+            check(eng.ctx, eng.lib.mfa_align_general_batch(eng.ctx, C.byref(gs), _ptr(d_ll), _ptr(eng._dev(ll_off)), _ptr(ll_cols),
+                                                           _ptr(eng._dev(fo)), fo.ctypes.data, gg.max_states, gg.max_arcs, C.byref(opts),
+                                                           _ptr(ali), _ptr(words), _ptr(n_words), _ptr(like), None, _ptr(status)),
+                  "mfa_align_general_batch")
+            ref = helpers.oracle_align(tm, fsts[u], cols, gg.pdf_lists_host[0], acoustic_scale=0.1, beam=beam, retry_beam=retry)
+            same = int(status.cpu()[0]) == ref["status"] and np.array_equal(ali.cpu().numpy(), ref["ali"])
+            print(seed, beam, retry, f"utterance {u}: closure budget exceeded -> general decoder", "identical to the oracle" if same else "DIFFERS", flush=True)
+            bad += 0 if same else 1
+            continue
         bad += 1
         print("MISMATCH", seed, beam, retry, str(e)[:300], flush=True)
 print("mismatches:", bad)
