@@ -70,6 +70,8 @@ def parse_args(argv=None):
                     help="1: windowed scoring of the cells live decoder tokens can ask for (mfa_align_features_batch); "
                          "0: score the whole (reachability-bounded) matrix, then decode")
     ap.add_argument("--window", type=int, default=64, help="frames per scoring/decoding window of the lazy path")
+    ap.add_argument("--stream-priorities", default="", help="experiment: comma-separated HIP stream priorities, cycled over the "
+                                                            "batches in flight (e.g. \"-1,0\"); empty = all default")
     ap.add_argument("--inflight", type=int, default=6,
                     help="batches in flight per GPU: steps alternate between this many pipelines (own HIP stream, engine "
                          "context and buffers each), so that the short latency-bound tails of a step — retry-beam and "
@@ -293,7 +295,9 @@ def main():
     n_inflight = max(1, args.inflight)
     engines, pipes, streams = [], [], []
     for k in range(n_inflight):
-        st = torch.cuda.current_stream(dev) if k == 0 else torch.cuda.Stream(dev)
+        prio = [int(x) for x in args.stream_priorities.split(",")] if args.stream_priorities else None
+        st = torch.cuda.current_stream(dev) if (k == 0 and prio is None) else \
+            torch.cuda.Stream(dev, priority=prio[k % len(prio)] if prio else 0)
         with torch.cuda.stream(st):
             e_k = eng
             if k > 0:
