@@ -282,7 +282,7 @@ class AlignmentEngine:
 
     def _dev(self, a: np.ndarray) -> torch.Tensor:
         """Host array → device, without making the host wait for the device: the array is copied into a slab of pinned
-        memory (bump allocation, wrap-around after a stream synchronisation — once every several batches) and sent
+        memory (bump allocation, wrap-around after a device synchronisation — once every several batches) and sent
         asynchronously.  A pageable ``.to(device)`` would block until everything queued on the stream before it has finished,
         i.e. until the previous batch has been decoded; ``Tensor.pin_memory()`` per array costs a pinned allocation (3 ms on
         this runtime)."""
@@ -302,7 +302,7 @@ class AlignmentEngine:
             return torch.from_numpy(a).to(self.device)
         off = (self._slab_off + 255) & ~255
         if off + nbytes > self._SLAB_BYTES:
-            torch.cuda.current_stream(self.device).synchronize()      # every copy out of the slab has run
+            torch.cuda.synchronize(self.device)      # every copy out of the slab has run, whichever stream it was queued on
             off = 0
         self._slab_off = off + nbytes
         view = slab.numpy()[off: off + nbytes].view(a.dtype).reshape(a.shape)

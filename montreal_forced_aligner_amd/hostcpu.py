@@ -13,10 +13,10 @@ import os
 from functools import lru_cache
 
 
-def _cgroup_quota() -> float:
+def _cgroup_quota(root: str = "/sys/fs/cgroup") -> float:
     """CPUs the cgroup quota allows (inf when unlimited or unreadable)."""
     try:                                                    # cgroup v2
-        with open("/sys/fs/cgroup/cpu.max") as fh:
+        with open(root + "/cpu.max") as fh:
             quota, period = fh.read().split()[:2]
         if quota != "max" and float(period) > 0:
             return float(quota) / float(period)
@@ -24,9 +24,9 @@ def _cgroup_quota() -> float:
     except (OSError, ValueError):
         pass
     try:                                                    # cgroup v1
-        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fh:
+        with open(root + "/cpu/cpu.cfs_quota_us") as fh:
             quota = float(fh.read())
-        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh:
+        with open(root + "/cpu/cpu.cfs_period_us") as fh:
             period = float(fh.read())
         if quota > 0 and period > 0:
             return quota / period

@@ -363,3 +363,28 @@ def test_determinize_star_log_and_minimize_encoded(fx):
     assert ra["status"] == 0 and rb["status"] == 0
     assert np.array_equal(ra["ali"], rb["ali"]) and np.array_equal(ra["words"], rb["words"])
     assert abs(ra["like"] - rb["like"]) < 10 * len(ra["ali"]) / 2048
+
+
+def test_host_thread_budget_follows_the_cgroup_quota(tmp_path, monkeypatch):
+    """hostcpu: the affinity mask alone over-counts inside a container (the GPU box: 256 cores in the mask, a 16-CPU quota)."""
+    import math
+
+    from montreal_forced_aligner_amd import hostcpu
+
+    (tmp_path / "cpu.max").write_text("1600000 100000\n")
+    assert hostcpu._cgroup_quota(str(tmp_path)) == 16.0
+    (tmp_path / "cpu.max").write_text("max 100000\n")
+    assert hostcpu._cgroup_quota(str(tmp_path)) == math.inf
+    (tmp_path / "cpu.max").unlink()
+    (tmp_path / "cpu").mkdir()
+    (tmp_path / "cpu" / "cpu.cfs_quota_us").write_text("400000\n")
+    (tmp_path / "cpu" / "cpu.cfs_period_us").write_text("100000\n")
+    assert hostcpu._cgroup_quota(str(tmp_path)) == 4.0
+    assert hostcpu._cgroup_quota(str(tmp_path / "nowhere")) == math.inf
+    hostcpu.cpu_budget.cache_clear()
+    monkeypatch.setenv("MFA_HOST_THREADS", "5")
+    assert hostcpu.cpu_budget() == 5 and hostcpu.threads() == 5 and hostcpu.threads(0.5) == 2 and hostcpu.threads(1.0, cap=3) == 3
+    hostcpu.cpu_budget.cache_clear()
+    monkeypatch.delenv("MFA_HOST_THREADS")
+    assert 1 <= hostcpu.cpu_budget() <= (len(__import__("os").sched_getaffinity(0)))
+    hostcpu.cpu_budget.cache_clear()
