@@ -199,7 +199,10 @@ typedef struct {
  *   d_ali [total_frames] transition-ids (at frame_off), d_words [total_frames] word ids packed at frame_off[u] with
  *   d_n_words[u] valid entries, d_like[u] = -(graph+acoustic cost)/acoustic_scale, d_frame_like [total_frames] or NULL,
  *   d_status[u]: 0 ok, 1 ok after retry, 2 no final token (failed), 3 token-capacity overflow, 4 back-pointer overflow,
- *                5 unsupported graph (a state with more than 64 arcs), 6 internal consistency check failed.
+ *                5 unsupported graph (a state with more than 64 arcs), 6 internal consistency check failed,
+ *                7 the best path carries more word labels than the utterance has frames — possible only when epsilon input arcs
+ *                  carry output labels; d_words holds one entry per frame, so the word sequence cannot be returned (the utterance's
+ *                  other outputs are undefined).  Graphs compiled from a lexicon never do this: every word consumes a frame.
  * total_frames = frame_off[n_utt], total_arcs = arc_base[n_utt] (host copies, so the call never synchronises); max_states / max_arcs = largest S_u / A_u
  * in the batch (they bound the token and candidate tables). */
 MFA_API int mfa_align_batch(mfa_ctx *ctx, const mfa_graph_batch *graphs, const float *d_loglikes, const int64_t *d_ll_off,

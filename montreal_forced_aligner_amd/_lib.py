@@ -20,6 +20,21 @@ class MfaHipError(RuntimeError):
     pass
 
 
+# d_status codes beyond 0 / 1 (include/mfa_hip.h), as the failure reasons the host layers report
+STATUS_REASONS = {
+    2: "no alignment within the retry beam",
+    3: "token capacity exceeded (device decoder status 3)",
+    4: "back-pointer capacity exceeded (device decoder status 4)",
+    5: "unsupported graph: a state with more than 64 arcs of a kind (device decoder status 5)",
+    6: "internal consistency check failed (device decoder status 6)",
+    7: "the best path carries more word labels than the utterance has frames: output labels on epsilon arcs (device decoder status 7)",
+}
+
+
+def status_reason(code: int) -> str:
+    return STATUS_REASONS.get(int(code), f"device decoder status {int(code)} (include/mfa_hip.h)")
+
+
 class MfccOpts(C.Structure):
     _fields_ = [
         ("sample_frequency", C.c_float), ("frame_length_ms", C.c_float), ("frame_shift_ms", C.c_float),

@@ -20,6 +20,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import numpy as np
 
 from . import ctm as _ctm
+from . import _lib
 from . import fmllr as _fmllr
 from . import graph as _graph
 from . import sharding
@@ -351,8 +352,7 @@ class CorpusAligner:
             if out.status[k] in (0, 1):
                 results[i] = (out, k)
             else:
-                self.failure_reasons[utts[i].utt_id] = ("no alignment within the retry beam" if out.status[k] == 2 else
-                                                       f"general decoder status {int(out.status[k])} (include/mfa_hip.h)")
+                self.failure_reasons[utts[i].utt_id] = _lib.status_reason(out.status[k])
         if want_feats:
             import torch
             ali_dev = rg["ali"].clone()
@@ -412,9 +412,9 @@ class CorpusAligner:
             results[idx[k]] = (out, k)
         for k in np.flatnonzero(~ok).tolist():
             if status[k] == 2:
-                self.failure_reasons.setdefault(utts[idx[k]].utt_id, "no alignment within the retry beam")
+                self.failure_reasons.setdefault(utts[idx[k]].utt_id, _lib.status_reason(2))
             else:
-                self.failure_reasons[utts[idx[k]].utt_id] = f"device decoder status {int(status[k])} (include/mfa_hip.h)"
+                self.failure_reasons[utts[idx[k]].utt_id] = _lib.status_reason(status[k])
         if want_feats:
             bad = np.flatnonzero(~ok).tolist()
             if bad:   # frames of utterances that failed must not vote in the fMLLR statistics

@@ -42,7 +42,7 @@ constexpr float kHashRatio = 2.0f;
 constexpr int kArcBits = 6;               // at most 64 arcs per state
 constexpr int kMaxArcsPerState = 1 << kArcBits;
 
-enum { ST_OK = 0, ST_RETRIED = 1, ST_FAILED = 2, ST_TOKEN_OVERFLOW = 3, ST_BP_OVERFLOW = 4, ST_UNSUPPORTED = 5, ST_INTERNAL = 6, ST_PENDING = -1, ST_GROW = -2 };
+enum { ST_OK = 0, ST_RETRIED = 1, ST_FAILED = 2, ST_TOKEN_OVERFLOW = 3, ST_BP_OVERFLOW = 4, ST_UNSUPPORTED = 5, ST_INTERNAL = 6, ST_WORDS = 7, ST_PENDING = -1, ST_GROW = -2 };
 
 // decoder state of one utterance between two windows (the token list itself is parked in w_state / w_cost)
 struct VitState { int32_t n, cur, done, pad0; u32 H, pad1; u64 bp_used; };
@@ -319,7 +319,10 @@ __device__ __forceinline__ void finalize_utterance(const VitParams &p, int utt, 
       if (i < L && il != 0 && tt < (u32)T) { ali[tt] = il; if (flike) flike[tt] = my_fl; }
       frames_done += (u32)__popcll(em);
     }
-    if (nw_out > (u32)T) nw_out = (u32)T;
+    if (nw_out > (u32)T) {   // more word labels than frames (output labels on epsilon arcs): the output layout cannot hold them
+      if (lane == 0) { p.status[utt] = ST_WORDS; p.n_words[utt] = 0; p.like[utt] = 0.0f; }
+      return;
+    }
   } else {
   // ---------------- traceback, arc index per frame parked in ali[].  The chain is pos → record → pos; the per-frame offsets
   // do not depend on it, so 64 of them are fetched at once and handed out by v_readlane: one dependent load per frame

@@ -22,7 +22,7 @@
 
 namespace {
 
-enum { G_OK = 0, G_RETRIED = 1, G_FAILED = 2, G_TOKEN_OVERFLOW = 3, G_BP_OVERFLOW = 4, G_INTERNAL = 6 };
+enum { G_OK = 0, G_RETRIED = 1, G_FAILED = 2, G_TOKEN_OVERFLOW = 3, G_BP_OVERFLOW = 4, G_INTERNAL = 6, G_WORDS = 7 };
 constexpr int kMinActive = 20;
 constexpr float kBeamDelta = 0.5f;
 constexpr float kHashRatio = 2.0f;
@@ -334,7 +334,8 @@ __global__ __launch_bounds__(64) void viterbi_general_kernel(GenParams p) {
     }
     if (d.a_ol[a] != 0) { if (n_w < d.T) words[n_w] = d.a_ol[a]; n_w++; }
   }
-  if (n_ali != d.T || n_w > d.T) { fail(G_INTERNAL); return; }
+  if (n_ali != d.T) { fail(G_INTERNAL); return; }
+  if (n_w > d.T) { fail(G_WORDS); return; }   // more word labels than frames: d_words holds one per frame (mfa_hip.h, status 7)
   w1 += d.final_w[d.a_next[d.tok_arc[best_tok]]];
   p.like[utt] = -(w1 + w2) / p.scale;
   p.n_words[utt] = n_w;

@@ -23,6 +23,7 @@ from typing import Dict, Iterable, Iterator, List, Optional, Sequence, Tuple, Un
 
 import numpy as np
 
+from . import _lib
 from . import ctm as _ctm
 from . import graph as _graph
 from . import kaldi_io
@@ -523,8 +524,7 @@ class GmmAligner:
                 # the reference returns None and lets the caller count the failure (statuses beyond "no final token"
                 # concern this utterance only, never the rest of the batch; they are logged with their code)
                 if st != 2:
-                    logger.warning("utterance %s: device decoder status %d (include/mfa_hip.h)",
-                                   utterance_ids[u] if utterance_ids else u, st)
+                    logger.warning("utterance %s: %s", utterance_ids[u] if utterance_ids else u, _lib.status_reason(st))
                 out.append(None)
                 continue
             a, b = int(frame_off[u]), int(frame_off[u + 1])

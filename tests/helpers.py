@@ -77,3 +77,11 @@ def random_gmm(rng, dim, gauss_per_pdf):
         gconsts.append(gc.astype(np.float32)); mi.append((mean * inv).astype(np.float32)); iv.append(inv.astype(np.float32))
         offs.append(offs[-1] + g)
     return M.DiagGmmModel(dim, np.concatenate(gconsts), np.concatenate(mi), np.concatenate(iv), np.asarray(offs, np.int32))
+
+
+def device_status(ref, n_frames):
+    """The status the device decoders report for an utterance the oracle aligned: the oracle's, except that a best path with
+    more word labels than frames (output labels on epsilon arcs) cannot be returned in d_words — status 7 (include/mfa_hip.h)."""
+    if ref["status"] in (0, 1) and len(ref["words"]) > n_frames:
+        return 7
+    return ref["status"]
