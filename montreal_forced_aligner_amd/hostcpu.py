@@ -48,7 +48,12 @@ def cpu_budget() -> int:
     quota = _cgroup_quota()
     if quota != math.inf:
         avail = min(avail, max(1, int(2 * quota)))
-    return max(1, avail)
+    # one process per GPU (torchrun / bench.py's self-launch export LOCAL_WORLD_SIZE): the ranks of a node share its cores
+    try:
+        ranks = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
+    except ValueError:
+        ranks = 1
+    return max(1, avail // ranks)
 
 
 def threads(share: float = 1.0, cap: int = 32) -> int:

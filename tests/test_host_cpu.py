@@ -386,5 +386,10 @@ def test_host_thread_budget_follows_the_cgroup_quota(tmp_path, monkeypatch):
     assert hostcpu.cpu_budget() == 5 and hostcpu.threads() == 5 and hostcpu.threads(0.5) == 2 and hostcpu.threads(1.0, cap=3) == 3
     hostcpu.cpu_budget.cache_clear()
     monkeypatch.delenv("MFA_HOST_THREADS")
-    assert 1 <= hostcpu.cpu_budget() <= (len(__import__("os").sched_getaffinity(0)))
+    monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
+    whole = hostcpu.cpu_budget()
+    assert 1 <= whole <= (len(__import__("os").sched_getaffinity(0)))
+    hostcpu.cpu_budget.cache_clear()
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "4")                # four ranks on the node share its cores
+    assert hostcpu.cpu_budget() == max(1, whole // 4)
     hostcpu.cpu_budget.cache_clear()

@@ -1,7 +1,8 @@
 """Extended fuzz of the lazy (windowed, speculative) path beyond the test suite's seeds: random graphs (cycles, dead ends,
 wide states), random mixture models with every slot class, random beams, window sizes and look-aheads; every output and
 every written score cell must equal the dense path's bit for bit (the dense path is fuzzed against the oracle by
-tools/decoder_fuzz.py).  GPU; from the repo root:  python tools/lazy_fuzz.py [n_seeds]"""
+tools/decoder_fuzz.py).  GPU; from the repo root:  python tools/lazy_fuzz.py [n_seeds] [first_seed] [--eps]
+--eps: a fifth of every graph's arcs become epsilon input arcs (the closure inside the windowed, lazily scored decoder)."""
 import os
 import sys
 
@@ -17,9 +18,12 @@ from tests.test_gpu_parity import _random_graph                        # noqa: E
 fx = helpers.Fixtures()
 eng = AlignmentEngine(0)
 tm = fx.mono_tm
-n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+_nums = [int(a) for a in sys.argv[1:] if a.isdigit()]
+n_seeds = _nums[0] if _nums else 24
+seed0 = _nums[1] if len(_nums) > 1 else 0
+EPS = "--eps" in sys.argv
 bad = 0
-for seed in range(n_seeds):
+for seed in range(seed0, seed0 + n_seeds):
     rng = np.random.default_rng(9100 + seed)
     dim = int(rng.choice([39, 40, 45]))
     # single-block classes only (1..32 Gaussians): lazy and dense cells are bit-identical there (multi-block pdfs agree to 1e-4)
@@ -27,7 +31,17 @@ for seed in range(n_seeds):
     eng.load_gmm(helpers.random_gmm(rng, dim, sizes))
     fsts, feats = [], []
     for u in range(10):
-        fsts.append(_random_graph(rng, tm, int(rng.choice([3, 8, 40, 150, 400, 900]))))
+        f = _random_graph(rng, tm, int(rng.choice([3, 8, 40, 150, 400, 900])))
+        if EPS:
+            from montreal_forced_aligner_amd import kaldi_io as K
+            arcs = f.arcs.copy()
+            eps = rng.random(len(arcs)) < 0.2
+            arcs["ilabel"][eps] = 0
+            arcs["olabel"][eps & (rng.random(len(arcs)) < 0.7)] = 0      # (few word labels on epsilon arcs: keeps words <= frames mostly)
+            g = K.Fst(f.start, f.arc_offsets, arcs, f.final)
+            if not eng.needs_general_decoder(g):
+                f = g
+        fsts.append(f)
         feats.append(rng.normal(0, 3.0, size=(int(rng.integers(2, 400)), dim)).astype(np.float32))
     fo = np.concatenate([[0], np.cumsum([f.shape[0] for f in feats])]).astype(np.int64)
     graphs = eng.pack_graphs(fsts, tm, groups=int(rng.choice([1, 2, 8])))
