@@ -85,3 +85,26 @@ def device_status(ref, n_frames):
     if ref["status"] in (0, 1) and len(ref["words"]) > n_frames:
         return 7
     return ref["status"]
+
+
+def has_negative_eps_cycle(fst) -> bool:
+    """A cycle of epsilon input arcs with negative total weight: Kaldi's ProcessNonemitting does not terminate on it (and the
+    oracle, a faithful restatement, runs out of memory) — fuzzers must not generate one.  Bellman-Ford over the epsilon arcs."""
+    arcs = fst.arcs
+    eps = arcs["ilabel"] == 0
+    if not eps.any():
+        return False
+    src = np.repeat(np.arange(fst.num_states), np.diff(fst.arc_offsets))[eps]
+    dst = arcs["nextstate"][eps].astype(np.int64)
+    w = arcs["weight"][eps].astype(np.float64)
+    if not (w < 0).any():
+        return False
+    dist = np.zeros(fst.num_states, dtype=np.float64)
+    for _ in range(fst.num_states + 1):
+        cand = dist[src] + w
+        new = dist.copy()
+        np.minimum.at(new, dst, cand)
+        if np.array_equal(new, dist):
+            return False
+        dist = new
+    return True

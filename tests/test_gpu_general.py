@@ -247,6 +247,33 @@ def test_more_word_labels_than_frames_is_reported_not_truncated(engine, fx):
     assert int(r2["status"].cpu()[0]) == 0 and r2["words"].cpu().numpy()[:3].tolist() == ref2["words"].tolist() == [11, 13, 14]
 
 
+def test_negative_epsilon_cycle_ends_as_a_failed_utterance(engine, fx):
+    """An invalid graph — a cycle of epsilon arcs with negative total weight: Kaldi's ProcessNonemitting never terminates on it.
+    Here every decoder is bounded (pop budget, token pool): the utterance comes back failed, the rest of the batch aligned."""
+    from montreal_forced_aligner_amd import kalpy_api as KA
+
+    tm, am = fx.mono_tm, fx.mono_am
+    x = fx.mono_feats(fx.pcm[: 16000 * 2])
+    good = G.add_transition_probs(fx.mono_gc.compile_fst("this is"), tm.scaled_log_probs(1.0, 0.1))
+    tid = int(np.flatnonzero(tm.id2pdf >= 0)[0])
+    arcs = np.array([(0, 0, -0.5, 1), (0, 0, 0.1, 0), (tid, 7, 0.0, 2), (tid, 0, 0.0, 2)], dtype=K.ARC_DTYPE)
+    bad = K.Fst(0, np.array([0, 1, 3, 4], dtype=np.int64), arcs, np.array([np.inf, np.inf, 0.0], dtype=np.float32))
+    assert helpers.has_negative_eps_cycle(bad)
+    al = KA.GmmAligner.__new__(KA.GmmAligner)
+    al.acoustic_model_path = "mono"; al.transition_model, al.acoustic_model = tm, am
+    al.beam, al.retry_beam = 100.0, 400.0
+    al.transition_scale, al.acoustic_scale, al.self_loop_scale = 1.0, 0.1, 0.1
+    al.disambiguation_symbols = []
+    al._scaled = np.zeros_like(tm.scaled_log_probs(1.0, 0.1))      # (graphs given with their weights in place)
+    al._loaded = False
+    KA._ENGINE = engine
+    out = al.align_utterances([good, bad, good], [x, x, x], ["a", "b", "c"])
+    assert out[1] is None and out[0] is not None and out[2] is not None
+    assert out[0].alignment == out[2].alignment
+    ref = _oracle(tm, am, good, x, 100.0, 400.0)
+    assert out[0].alignment == ref["ali"].tolist()
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # Round 3: epsilon input arcs on the wavefront-parallel decoder (pack_graphs stores every state's arcs [emitting | epsilon],
 # the kEps instantiation of viterbi_kernel runs ProcessNonemitting after every frame) — the lazy-scored, windowed product path.
@@ -320,7 +347,7 @@ def test_wavefront_decoder_fuzz_with_epsilon_arcs(engine, fx, seed):
             fwd = eps & (arcs["nextstate"] > src)
             arcs["weight"][fwd] -= 0.5
         f = K.Fst(f.start, f.arc_offsets, arcs, f.final)
-        if engine.needs_general_decoder(f) or not eps.any():
+        if engine.needs_general_decoder(f) or not eps.any() or helpers.has_negative_eps_cycle(f):   # (Kaldi's closure would not end)
             continue
         fsts.append(f)
         feats.append(rng.normal(0, 3.0, size=(int(rng.integers(2, 140)), 39)).astype(np.float32))

@@ -393,3 +393,21 @@ def test_host_thread_budget_follows_the_cgroup_quota(tmp_path, monkeypatch):
     monkeypatch.setenv("LOCAL_WORLD_SIZE", "4")                # four ranks on the node share its cores
     assert hostcpu.cpu_budget() == max(1, whole // 4)
     hostcpu.cpu_budget.cache_clear()
+
+
+def test_negative_epsilon_cycle_detector():
+    from montreal_forced_aligner_amd import kaldi_io as K
+    from tests import helpers
+
+    def fst(arcs_by_state):
+        off = np.concatenate([[0], np.cumsum([len(a) for a in arcs_by_state])]).astype(np.int64)
+        arcs = np.array([x for a in arcs_by_state for x in a], dtype=K.ARC_DTYPE)
+        return K.Fst(0, off, arcs, np.zeros(len(arcs_by_state), dtype=np.float32))
+
+    # 0 -eps/-0.5-> 1 -eps/0.1-> 0: a negative cycle; with +0.6 on the way back it is not
+    assert helpers.has_negative_eps_cycle(fst([[(0, 0, -0.5, 1)], [(0, 0, 0.1, 0)]]))
+    assert not helpers.has_negative_eps_cycle(fst([[(0, 0, -0.5, 1)], [(0, 0, 0.6, 0)]]))
+    # the negative arc is emitting: no epsilon cycle at all
+    assert not helpers.has_negative_eps_cycle(fst([[(3, 0, -0.5, 1)], [(0, 0, 0.1, 0)]]))
+    # zero-weight epsilon cycles are fine (Kaldi replaces a token only when strictly cheaper)
+    assert not helpers.has_negative_eps_cycle(fst([[(0, 0, 0.0, 1)], [(0, 0, 0.0, 0)]]))

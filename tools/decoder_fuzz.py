@@ -30,6 +30,9 @@ for seed in range(seed0, seed0 + n_seeds):
             neg = eps & (arcs["nextstate"] > src) & (rng.random(len(arcs)) < 0.25)
             arcs["weight"][neg] -= 0.5
             f = K.Fst(f.start, f.arc_offsets, arcs, f.final)
+            if helpers.has_negative_eps_cycle(f):              # Kaldi's closure does not terminate on one: take the negative weights back
+                arcs["weight"][neg] += 0.5
+                f = K.Fst(f.start, f.arc_offsets, arcs, f.final)
             if eng.needs_general_decoder(f):
                 f = _random_graph(rng, tm, 5)
         fsts.append(f)
