@@ -67,8 +67,8 @@ typedef struct {
   int32_t num_coefficients; /* 13 */
   int32_t snip_edges;       /* MFA default 0 */
   int32_t remove_dc_offset; /* 1 */
-  int32_t use_energy;       /* 0 */
-  int32_t raw_energy;       /* 1 */
+  int32_t use_energy;       /* 0; 1: C0 := the frame's log energy (floored at log(energy_floor) when that is > 0) */
+  int32_t raw_energy;       /* 1: energy before pre-emphasis and window; 0: after */
 } mfa_mfcc_opts;
 
 MFA_API int mfa_mfcc_configure(mfa_ctx *ctx, const mfa_mfcc_opts *opts);

@@ -53,6 +53,8 @@ static_assert(kMelOff + 4 * kMelStride <= kTileFloats, "tile reuse");
 struct MfccParams {
   int win, shift, nbins, nceps, snip_edges, remove_dc;
   int n_pieces, n_rounds, np_max;
+  int raw_energy;           // use_energy (kEnergy instantiations): C0 is the frame's log energy, before (1) or after (0) pre-emphasis and window
+  float log_energy_floor;   // log(energy_floor) or -inf
   float preemph;
   const float *window;      // [16][16][2]: window[2m], window[2m+1] for m = i + 16 j (0 beyond the window)
   const float *tw256;       // [16][16][2]: W256^(i·k1) at [k1][i]
@@ -138,7 +140,7 @@ __device__ __forceinline__ void dft16(v2f (&a)[16]) {
 }
 
 // kJ = ⌈window / 32⌉ packed sample pairs per lane (13 for MFA's 25 ms at 16 kHz)
-template <int kJ>
+template <int kJ, bool kEnergy = false>
 __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void mfcc_kernel(MfccParams p, const int16_t *__restrict__ pcm,
                                                                         const int64_t *__restrict__ sample_off,
                                                                         const int64_t *__restrict__ frame_off,
@@ -238,6 +240,17 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void mfcc_kernel(MfccParams
     for (int j = 0; j < kJ; j++) a[j] += splat(off);
     if (!ok_e) a[kJ - 1].x = 0.0f;
     if (!ok_o) a[kJ - 1].y = 0.0f;
+    // ---- use_energy: Kaldi's ProcessWindow takes the log energy here when raw_energy (default), after the window otherwise
+    // (VecVec over the frame, floored at FLT_EPSILON; the sum's order is this kernel's, the result agrees to float rounding)
+    float log_energy = 0.0f;
+    auto frame_log_energy = [&]() {
+      float e = 0.0f;
+#pragma unroll
+      for (int j = 0; j < kJ; j++) e = fmaf(a[j].y, a[j].y, fmaf(a[j].x, a[j].x, e));
+      e = row_sum_exact(e);
+      return __builtin_amdgcn_logf(fmaxf(e, 1.1920928955078125e-07f)) * 0.693147180559945309f;
+    };
+    if constexpr (kEnergy) { if (p.raw_energy) log_energy = frame_log_energy(); }
     // ---- pre-emphasis + window.  x[2m−1] is the odd sample of the previous lane (row_shr:1); lane 0 takes it from lane 15
     // of the previous register (row_ror:1 → kept where row_shr has no source); sample 0 uses itself (Kaldi)
     {
@@ -254,6 +267,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void mfcc_kernel(MfccParams
         a[j] = (a[j] - splat(p.preemph) * prev) * wnd[16 * j];
       }
     }
+    if constexpr (kEnergy) { if (!p.raw_energy) log_energy = frame_log_energy(); }
     // ---- 256-point complex FFT of z[m] = x[2m] + i x[2m+1]: 16-point DFTs over j, twiddle, transpose, 16-point DFTs over i
     dft16<kJ>(a);
 #pragma unroll
@@ -313,7 +327,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void mfcc_kernel(MfccParams
       const float *d = s_dct + i * p.nbins;
       float acc = 0.0f;
       for (int b = 0; b < p.nbins; b++) acc = fmaf(d[b], melq[b], acc);
-      if (live) out[(f0 + f) * p.nceps + i] = acc * lift_k;
+      float c_out = acc * lift_k;
+      if constexpr (kEnergy) { if (i == 0) c_out = fmaxf(log_energy, p.log_energy_floor); }   // C0 := log energy (MfccComputer::Compute)
+      if (live) out[(f0 + f) * p.nceps + i] = c_out;
     }
     WAVE_SYNC();
   }
@@ -332,7 +348,6 @@ MFA_API int mfa_mfcc_configure(mfa_ctx *c, const mfa_mfcc_opts *o) {
   int nfft = 1;
   while (nfft < win) nfft <<= 1;
   if (nfft != kNfft) return c->fail("MFCC kernel supports a 512-point FFT (window %d samples → %d)", win, nfft);
-  if (o->use_energy) return c->fail("use_energy=true is not supported by the MFCC kernel (MFA default is false)");
   if (o->num_mel_bins > kMaxBins || o->num_coefficients > kMaxCeps || o->num_coefficients > o->num_mel_bins ||
       o->num_mel_bins * o->num_coefficients > kMaxDct)
     return c->fail("unsupported num_mel_bins/num_coefficients %d/%d", o->num_mel_bins, o->num_coefficients);
@@ -451,15 +466,21 @@ MFA_API int mfa_mfcc_batch(mfa_ctx *c, const int16_t *d_pcm, const int64_t *d_sa
   MfccParams p;
   p.win = c->win; p.shift = c->shift; p.nbins = c->mfcc.num_mel_bins; p.nceps = c->mfcc.num_coefficients;
   p.snip_edges = c->mfcc.snip_edges; p.remove_dc = c->mfcc.remove_dc_offset; p.preemph = c->mfcc.preemphasis;
+  p.raw_energy = c->mfcc.raw_energy;
+  p.log_energy_floor = c->mfcc.energy_floor > 0.0f ? logf(c->mfcc.energy_floor) : -INFINITY;
   p.window = c->d_window; p.tw256 = c->d_twiddle; p.tw512 = c->d_twiddle + 512;
   p.melw = c->d_melw; p.melinfo = c->d_melidx; p.dct = c->d_dct; p.lifter = c->d_lifter;
   p.n_pieces = c->n_melw; p.n_rounds = (c->n_melw + 15) / 16; p.np_max = c->mel_np_max;
   dim3 grid((max_frames + kFramesPerBlock - 1) / kFramesPerBlock, n_utt);
   KernelTimer kt(c, MFA_K_MFCC);
-  if (c->win <= 32 * 13)
-    hipLaunchKernelGGL(mfcc_kernel<13>, grid, dim3(64 * kWavesPerBlock), 0, c->stream, p, d_pcm, d_sample_off, d_frame_off, d_mfcc);
-  else
-    hipLaunchKernelGGL(mfcc_kernel<16>, grid, dim3(64 * kWavesPerBlock), 0, c->stream, p, d_pcm, d_sample_off, d_frame_off, d_mfcc);
+  const bool energy = c->mfcc.use_energy != 0;       // (its own instantiations: the default kernel carries nothing for it)
+  if (c->win <= 32 * 13) {
+    if (energy) hipLaunchKernelGGL((mfcc_kernel<13, true>), grid, dim3(64 * kWavesPerBlock), 0, c->stream, p, d_pcm, d_sample_off, d_frame_off, d_mfcc);
+    else hipLaunchKernelGGL((mfcc_kernel<13, false>), grid, dim3(64 * kWavesPerBlock), 0, c->stream, p, d_pcm, d_sample_off, d_frame_off, d_mfcc);
+  } else {
+    if (energy) hipLaunchKernelGGL((mfcc_kernel<16, true>), grid, dim3(64 * kWavesPerBlock), 0, c->stream, p, d_pcm, d_sample_off, d_frame_off, d_mfcc);
+    else hipLaunchKernelGGL((mfcc_kernel<16, false>), grid, dim3(64 * kWavesPerBlock), 0, c->stream, p, d_pcm, d_sample_off, d_frame_off, d_mfcc);
+  }
   MFA_HIP_CHECK(c, hipGetLastError());
   return 0;
 }

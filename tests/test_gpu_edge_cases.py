@@ -81,9 +81,7 @@ def test_unsupported_inputs_are_refused_loudly(engine, fx):
     wide["ilabel"] = 1; wide["nextstate"] = 1
     with pytest.raises(_lib.MfaHipError, match="64"):
         engine.pack_graphs([K.Fst(0, np.array([0, n, n], np.int64), wide, np.array([np.inf, 0.0], np.float32))], fx.mono_tm)
-    # a feature window that is not 512 points, and energy features, are outside the MFCC kernel
+    # a feature window that is not 512 points is outside the MFCC kernel
     with pytest.raises(_lib.MfaHipError):
         engine.configure_mfcc(frame_length_ms=40.0)
-    with pytest.raises(_lib.MfaHipError):
-        engine.configure_mfcc(use_energy=1)
     engine.configure_mfcc()

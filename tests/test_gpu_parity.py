@@ -42,6 +42,35 @@ def test_mfcc_matches_oracle(engine, fx, snip):
     engine.configure_mfcc()
 
 
+@pytest.mark.parametrize("raw,floor", [(1, 0.0), (0, 0.0), (1, 5.0e7)])
+def test_mfcc_use_energy_matches_oracle(engine, fx, raw, floor):
+    """use_energy (MFA/corpus/features.py:780-820 passes it through; default false): C0 is the frame's log energy — before
+    pre-emphasis and window with raw_energy, after them without, floored at log(energy_floor) — the other coefficients
+    unchanged (Kaldi feat/feature-mfcc.cc, feature-window.cc ProcessWindow)."""
+    segs = _segments(fx) + [np.zeros(2000, np.int16)]
+    so = np.concatenate([[0], np.cumsum([len(s) for s in segs])]).astype(np.int64)
+    pcm = _dev(engine, np.concatenate(segs).astype(np.int16))
+    engine.configure_mfcc()
+    plain, fo = engine.mfcc(pcm, so)
+    plain = plain.cpu().numpy()
+    engine.configure_mfcc(use_energy=1, raw_energy=raw, energy_floor=floor)
+    out, fo2 = engine.mfcc(pcm, so)
+    out = out.cpu().numpy()
+    engine.configure_mfcc()
+    assert np.array_equal(fo, fo2) and np.array_equal(out[:, 1:], plain[:, 1:])      # only C0 changes
+    opts = O.default_mfcc_opts(use_energy=1, raw_energy=raw, energy_floor=floor)
+    floored = 0
+    for u, s in enumerate(segs):
+        ref = O.mfcc(s.astype(np.float32), opts)
+        got = out[fo[u]: fo[u + 1]]
+        assert got.shape == ref.shape
+        assert np.abs(got - ref).max() < 2e-3, (u, float(np.abs(got - ref).max()))
+        if floor > 0:
+            floored += int(np.isclose(ref[:, 0], np.log(floor), rtol=0, atol=1e-5).sum())
+    assert floor == 0.0 or floored > 0                                                  # the floor really was applied somewhere
+    assert np.abs(out[:, 0] - plain[:, 0]).max() > 1.0                                 # and C0 really is something else
+
+
 def test_mfcc_digital_silence_and_full_scale(engine):
     engine.configure_mfcc()
     rng = np.random.default_rng(7)
