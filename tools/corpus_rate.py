@@ -1,6 +1,7 @@
 """End-to-end rate of CorpusAligner on configs[2]-shaped utterances: int16 PCM + transcripts in host memory → alignments
 (and, with --ctm, phone/word intervals) on the host; stage times of the host loop printed beside it.
-GPU box:  python tools/corpus_rate.py [n_utt] [--ctm] [--full] [--textgrid]
+GPU box:  python tools/corpus_rate.py [n_utt] [--ctm] [--full] [--textgrid] [--ragged]
+--ragged: BASELINE configs[4]'s shape — utterance lengths log-uniform between 1 s and 30 s (three words per second) instead of 10 s each.
 --full: the bench's model (4 960 pdfs x 32 Gaussians) and DISTINCT utterances, as bench.py's value_end_to_end loop."""
 import cProfile
 import pstats
@@ -35,7 +36,12 @@ def main():
 
     model = synth.train_triphone(world, feats_of, n_train=60, n_gauss=32, n_classes=5 if full else 2)
     pool = n if full else 128
-    base = [world.utterance(20000 + i, n_words=30) for i in range(pool)]
+    if "--ragged" in sys.argv:
+        rng = np.random.default_rng(4)
+        secs = np.exp(rng.uniform(np.log(1.0), np.log(30.0), size=pool))
+        base = [world.utterance(20000 + i, n_words=max(1, int(round(3 * s_))), samples=int(16000 * s_)) for i, s_ in enumerate(secs)]
+    else:
+        base = [world.utterance(20000 + i, n_words=30) for i in range(pool)]
     utts = [CorpusUtterance(f"{base[i % pool][3]}-{i}", str(base[i % pool][3]), base[i % pool][0], base[i % pool][1]) for i in range(n)]
     al = CorpusAligner(model.tm, model.am, model.tree, world.lexicon, lda=lda, engine=eng,
                        options=AlignOptions(batch_frames=1_025_000))
@@ -50,7 +56,9 @@ def main():
     torch.cuda.synchronize()
     dt = time.time() - t0
     ok = sum(r is not None for r in res)
-    print(f"CorpusAligner.align(make_ctm={want_ctm}): {n} utterances in {dt:.2f} s = {n / dt:.0f} utterances/s; {ok} aligned", flush=True)
+    audio = sum(len(u.pcm) for u in utts) / 16000.0
+    print(f"CorpusAligner.align(make_ctm={want_ctm}): {n} utterances in {dt:.2f} s = {n / dt:.0f} utterances/s; {ok} aligned; "
+          f"{audio / 3600:.2f} h of audio, real-time factor {dt / audio:.2e}", flush=True)
     st = pstats.Stats(pr)
     st.sort_stats("cumulative").print_stats(45)
     if "--textgrid" in sys.argv:
