@@ -163,6 +163,8 @@ struct MfaWindowScore {
   const int32_t *n_list;
   const int32_t *done;          // per-utterance "finished" word: done[utt * done_stride + done_word] != 0 → skip
   int done_stride, done_word;
+  const int32_t *lag;           // per-utterance lag word (or NULL): non-zero → the utterance's window in this call is the PREVIOUS one
+  int lag_stride, lag_word;     // (t_begin − window), scored with the proven band whatever hi_slack says
   int cols_per_wave;            // 0: one wavefront walks a sub-tile's whole band; n: one wavefront per n columns of it
   int hi_slack;                 // speculative look-ahead: the band's upper depth bound is lowered by this many arcs (0: the
                                 // proven bound); the decoder then checks every score it reads against mfa_band_ranges

@@ -80,6 +80,9 @@ struct GmmParams {
   const int32_t *b_band;       // [n_utt][2] {min longest-path depth of a live token, max BFS depth reachable in the window}
   const int32_t *b_utt_list; const int32_t *b_n_list;
   const int32_t *b_done; int b_done_stride, b_done_word;
+  // utterances one window behind the launch (their speculative window failed and is scored again, with the proven band, by the
+  // next launch): lag word of the decoder's per-utterance state, frames per window
+  const int32_t *b_lag; int b_lag_stride, b_lag_word, b_lag_frames;
   const int32_t *last_depth;   // parallel to pdf_list: running max (inside a class) of the longest-path depth of the pdf's sources
   int b_skip0;                 // f32 band kernel: classes 0..4 were scored by gmm_band_kernel (it keeps 5: single Gaussians, f32-exact)
   int b_chunk, b_nchunk;       // gmm_band_kernel: columns per wavefront (0 = the whole band) and chunks per sub-tile
@@ -102,11 +105,18 @@ struct GmmParams {
 // Band of one (utterance, window): pdf j of a class is needed iff first_frame[j] <= hi and last_depth[j] >= lo; both keys
 // are non-decreasing along a class, so the needed pdfs are the index range [count(last_depth < lo), count(first_frame <= hi)).
 struct Band { int lo, hi; };
+__device__ __forceinline__ int band_lag(const GmmParams &p, int utt) {
+  return (p.b_lag && p.b_t_begin > 0) ? (p.b_lag[(size_t)utt * p.b_lag_stride + p.b_lag_word] != 0 ? 1 : 0) : 0;
+}
+// first frame of the utterance's window in this launch
+__device__ __forceinline__ int band_t_begin(const GmmParams &p, int utt) { return p.b_t_begin - band_lag(p, utt) * p.b_lag_frames; }
 __device__ __forceinline__ Band band_of(const GmmParams &p, int utt) {
   Band b;
-  if (p.b_t_begin == 0) { b.lo = 0; b.hi = 64 * p.b_sub - 1; }   // only the start state is live: BFS depth 0
+  const int lag = band_lag(p, utt);
+  if (p.b_t_begin - lag * p.b_lag_frames <= 0) { b.lo = 0; b.hi = 64 * p.b_sub - 1; }   // only the start state is live: BFS depth 0
   else { b.lo = p.b_band[2 * utt]; b.hi = p.b_band[2 * utt + 1]; }
-  if (p.b_hi_slack > 0 && b.hi != INT32_MAX) b.hi -= p.b_hi_slack;   // speculative look-ahead (the decoder checks what it reads)
+  // speculative look-ahead (the decoder checks what it reads) — not for a window that is being redone: the proven band
+  if (p.b_hi_slack > 0 && !lag && b.hi != INT32_MAX) b.hi -= p.b_hi_slack;
   return b;
 }
 // gmm_band_kernel launches over a grouped plan: workgroup → (index of its four sub-tiles, run of class 0).  Consecutive
@@ -1612,7 +1622,7 @@ __global__ __launch_bounds__(256, 2) void gmm_band_kernel(GmmParams p) {
   if (!band_item(p, wave, utt, r, &chunk)) return;
   const int64_t f0 = p.frame_off[utt];
   const int T = (int)(p.frame_off[utt + 1] - f0);
-  const int t_base = p.b_t_begin + 64 * r;
+  const int t_base = band_t_begin(p, utt) + 64 * r;
   if (t_base >= T) return;
   int *redo_flag = p.redo + ((size_t)utt * p.b_sub + r) * p.b_nchunk + chunk;
   if (!kHalf && p.redo_mode == 2 && *redo_flag == 0) return;          // only what the f16 pass declined
@@ -2090,7 +2100,7 @@ __global__ __launch_bounds__(256, 2) void gmm_band_f32_kernel(GmmParams p) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int utt, r;
   if (!band_item(p, wave, utt, r)) return;
-  score_tile<M8, 2>(p, utt, p.b_t_begin + 64 * r, lane, stage_all[wave], 0);
+  score_tile<M8, 2>(p, utt, band_t_begin(p, utt) + 64 * r, lane, stage_all[wave], 0);
 }
 
 // max over the batch of the pdfs' first possible frames → *max_ff (the persistent kernel derives its phase split from it)
@@ -2812,6 +2822,7 @@ int mfa_gmm_score_window(mfa_ctx *c, const MfaLazyScoring *lazy, const MfaWindow
   p.b_mode = 1; p.b_t_begin = ws->t_begin; p.b_sub = ws->window / 64; p.b_band = ws->band;
   p.b_utt_list = ws->utt_list; p.b_n_list = ws->n_list;
   p.b_done = ws->done; p.b_done_stride = ws->done_stride; p.b_done_word = ws->done_word;
+  p.b_lag = ws->lag; p.b_lag_stride = ws->lag_stride; p.b_lag_word = ws->lag_word; p.b_lag_frames = ws->window;
   const int64_t waves = (int64_t)n_utt * p.b_sub;
   const dim3 grid((unsigned)((waves + 3) / 4));
   p.groups = lazy->plan.groups > 1 && lazy->plan.d_group_counts ? lazy->plan.groups : 0;

@@ -69,6 +69,9 @@ struct VitParams {
   // out-degree above counts the emitting ones): per state {first epsilon arc << 7 | number of epsilon arcs}, built once per call
   const u32 *w_epsinfo;                // [n_utt * max_states] at (utt * max_states + state), or NULL
   int eps_stride;                      // max_states
+  int lagmode;                         // windowed first-beam pass with the 64-token first tier: VitState.pad0 is the utterance's lag —
+                                       // 1: its window in this launch is the previous one (a failed speculation being redone with the
+                                       // proven band, by the first tier itself); the utterance stays one window behind from then on
   int eps_pops;                        // pops of one frame's epsilon closure before the utterance is handed back with a capacity status (64 per token slot; Kaldi has no budget: the caller's last resort is the general decoder)
   unsigned long long *stamps;          // -DVIT_STAMPS builds: per-utterance phase cycles (mfa_debug_viterbi_stamps) or NULL
   int llcap;                           // score-row cache capacity in LDS (floats); rows longer than this are read from HBM
@@ -466,7 +469,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   int status = ST_OK;
   const int start = p.g.d_start[utt];
   if (S <= 0 || start < 0 || start >= S || T <= 0) status = ST_FAILED;
-  const bool resume = p.windowed && p.t_begin > 0;
+  // (lagmode: an utterance one window behind — VitState.pad0 — works on [t_begin − K, t_begin))
+  const int lag = (p.lagmode && p.windowed && p.t_begin > 0) ? (p.w_vstate[utt].pad0 != 0 ? 1 : 0) : 0;
+  const int t_begin_u = p.t_begin - lag * (p.t_end - p.t_begin);
+  const bool resume = p.windowed && t_begin_u > 0;
   int cur = 0, n = 1;
   u32 H = p.pass == 0 ? 1000u : p.w_hash[utt];
   u64 bp_used = 0;
@@ -580,7 +586,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   } else {
     const VitState vs = p.w_vstate[utt];
     if (vs.done) return;                           // finished (or failed) in an earlier window: outputs are final
-    n = vs.n; H = vs.H; bp_used = vs.bp_used; t = p.t_begin;
+    n = vs.n; H = vs.H; bp_used = vs.bp_used; t = t_begin_u;
     if (p.redo_mode == 1 && n > N) {               // more live tokens than this tier holds: the large tier takes the window
       if (lane == 0) p.w_redo[utt] = 1u;
       return;
@@ -593,7 +599,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
       cur = vs.cur & 1;
     }
   }
-  const int t_stop = p.windowed ? min(T, p.t_end) : T;
+  const int t_stop = p.windowed ? min(T, t_begin_u + (p.t_end - p.t_begin)) : T;
   // score rows are staged through LDS one frame ahead (registers hold row t+1 while frame t is processed)
   constexpr int kPre = 8;
   const bool row_cached = P <= p.llcap && P <= 64 * kPre;
@@ -1199,7 +1205,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     dmin_inv = wave_max_u32(dmin_inv);
     if (lane == 0) {
       VitState vs;
-      vs.n = n; vs.cur = kListsInLds ? 0 : cur; vs.done = 0; vs.pad0 = 0; vs.H = H; vs.pad1 = 0; vs.bp_used = bp_used;
+      vs.n = n; vs.cur = kListsInLds ? 0 : cur; vs.done = 0; vs.pad0 = lag; vs.H = H; vs.pad1 = 0; vs.bp_used = bp_used;
       p.w_vstate[utt] = vs;
       if (p.band) {
         const long long hi = (long long)dmax + (long long)p.next_window - 1;
@@ -1211,7 +1217,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   }
   if (p.windowed && lane == 0) {   // finished one way or the other: later windows of this pass skip the utterance
     VitState vs;
-    vs.n = 0; vs.cur = 0; vs.done = 1; vs.pad0 = 0; vs.H = H; vs.pad1 = 0; vs.bp_used = bp_used;
+    vs.n = 0; vs.cur = 0; vs.done = 1; vs.pad0 = lag; vs.H = H; vs.pad1 = 0; vs.bp_used = bp_used;
     p.w_vstate[utt] = vs;
   }
   if (p.pass == 0 && lane == 0) p.w_hash[utt] = H;
@@ -1241,8 +1247,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
   const int lane = threadIdx.x;
   const int utt = blockIdx.x;
   const VitState vs0 = p.w_vstate[utt];
-  const bool resume = p.t_begin > 0;
-  if (resume && vs0.done) return;                  // finished (or failed, or waiting for the finish kernel)
+  // lagmode: an utterance whose speculative window failed is one window behind from then on (VitState.pad0): this launch redoes
+  // that window for it — scored again with the proven band by the scoring launch before this one — without the check
+  const int K_ = p.t_end - p.t_begin;
+  const int lag = (p.lagmode && p.t_begin > 0 && vs0.pad0 != 0) ? 1 : 0;
+  const int t_begin_u = p.t_begin - lag * K_;
+  const bool resume = t_begin_u > 0;
+  if (p.t_begin > 0 && vs0.done) return;           // finished (or failed, or waiting for the finish kernel)
   const int64_t so = p.g.d_state_off[utt];
   const int S = (int)(p.g.d_state_off[utt + 1] - so);
   const int64_t ab_ = p.g.d_arc_base[utt];
@@ -1256,7 +1267,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
   u32 *park_state = p.w_state + (size_t)utt * 2 * NP;
   u32 *park_an = p.w_state + (size_t)p.g.n_utt * 2 * NP + (size_t)utt * 2 * NP;
   double *park_cost = p.w_cost + (size_t)utt * 2 * NP;
-  auto hand_over = [&]() { if (lane == 0) p.w_redo[utt] = 1u; };   // nothing parked has been touched: the large tier redoes the window
+  // Outside this kernel's envelope (more than 64 tokens, more than 64·kRounds candidates, a malformed graph).  Without lagmode:
+  // nothing parked has been touched, the large tier — launched right after — redoes the window.  With lagmode there is no such
+  // launch: the utterance leaves the fast track for good and is decoded from its first frame by the table-growth list pass that
+  // follows the windowed pass (general kernel, the caller's full capacity) — rare: none of the 4 096 utterances of the bench
+  // workload ever holds more than 64 tokens at beam 10.
+  auto hand_over = [&]() {
+    if (lane != 0) return;
+    if (p.lagmode) {
+      VitState vs; vs.n = 0; vs.cur = 0; vs.done = 1; vs.pad0 = 0; vs.H = 1000u; vs.pad1 = 0; vs.bp_used = 0;
+      p.w_vstate[utt] = vs;
+      p.status[utt] = ST_GROW; p.n_words[utt] = 0; p.like[utt] = 0.0f;
+    } else {
+      p.w_redo[utt] = 1u;
+    }
+  };
 
   int n = 1, t = 0;
   u32 H = 1000u;
@@ -1264,7 +1289,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
   const int start = p.g.d_start[utt];
   if (S <= 0 || start < 0 || start >= S || T <= 0) { hand_over(); return; }   // (the general kernel reports the failure)
   if (resume) {
-    n = vs0.n; H = vs0.H; bp_used = vs0.bp_used; t = p.t_begin;
+    n = vs0.n; H = vs0.H; bp_used = vs0.bp_used; t = t_begin_u;
     if (n > N || n <= 0) { hand_over(); return; }
   }
 
@@ -1299,9 +1324,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
   } else if (lane < n) {
     l_state0[lane] = park_state[lane]; l_an0[lane] = park_an[lane]; l_cost0[lane] = park_cost[lane];
   }
-  const int t_stop = min(T, p.t_end);
+  const int t_stop = min(T, t_begin_u + K_);
   WSYNC();
-  const bool spec = p.spec != 0;
+  const bool spec = p.spec != 0 && lag == 0;
   if (spec) build_scored_bitmap(p, utt, lane, bm);
 
   bool overflow = false, spec_fail = false;
@@ -1534,14 +1559,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
   if (overflow) { hand_over(); return; }
   // the narrow band did not hold: nothing parked has been touched, so the window is scored again with the proven band and
   // redone from its parked state by the large tier — the same hand-over as a capacity overflow
-  if (spec_fail) { hand_over(); return; }
+  if (spec_fail) {
+    if (p.lagmode) {
+      // the parked state is as it was at the window's start: mark the utterance as one window behind — the next scoring launch
+      // scores this window again with the proven band, the next launch of this kernel redoes it (no separate launch for a
+      // handful of wavefronts, which with several batches in flight left the chip empty a tenth of the time)
+      if (lane == 0) {
+        VitState vs = vs0;
+        if (!resume) { vs.n = 1; vs.cur = 0; vs.H = 1000u; vs.pad1 = 0; vs.bp_used = 0; }   // (window 0: nothing was parked yet)
+        vs.done = 0; vs.pad0 = 1;
+        p.w_vstate[utt] = vs;
+      }
+      return;
+    }
+    hand_over(); return;
+  }
   __threadfence_block();
   u32 *c_state = l_state0 + cur * N;
   double *c_costp = l_cost0 + cur * N;
   const u32 *c_anp = l_an0 + cur * N;
   if (n == 0) {   // no surviving token: pending for the retry pass, as the general kernel's finalisation reports it
     if (lane == 0) {
-      VitState vs; vs.n = 0; vs.cur = 0; vs.done = 1; vs.pad0 = 0; vs.H = H; vs.pad1 = 0; vs.bp_used = bp_used;
+      VitState vs; vs.n = 0; vs.cur = 0; vs.done = 1; vs.pad0 = lag; vs.H = H; vs.pad1 = 0; vs.bp_used = bp_used;
       p.w_vstate[utt] = vs;
       p.w_hash[utt] = H;
       p.status[utt] = ST_PENDING; p.n_words[utt] = 0; p.like[utt] = 0.0f;
@@ -1562,7 +1601,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
   dmin_inv = wave_max_u32(dmin_inv);
   if (lane == 0) {
     VitState vs;
-    vs.n = n; vs.cur = 0; vs.done = t < T ? 0 : 2; vs.pad0 = 0; vs.H = H; vs.pad1 = 0; vs.bp_used = bp_used;
+    vs.n = n; vs.cur = 0; vs.done = t < T ? 0 : 2; vs.pad0 = lag; vs.H = H; vs.pad1 = 0; vs.bp_used = bp_used;
     p.w_vstate[utt] = vs;
     if (t >= T) p.w_hash[utt] = H;
     if (p.band && t < T) {
@@ -1769,14 +1808,19 @@ int align_impl(mfa_ctx *c, const mfa_graph_batch *g, const float *d_loglikes, co
     spec_slack = std::max(0, lazy->window - 1 - look);
     if (lazy->plan.max_cols > 32 * kBmWords) spec_slack = 0;   // (the decoder's bitmap of scored columns holds 2 048)
   }
+  bool will_lag = false;
   if (lazy && N[0] > kSmallTokens) {
     // windowed first-beam pass: the small tier decodes every window; the few utterances it cannot hold in a window are
     // decoded again — that window only, from the state parked at its start — by the large tier (LDS-resident lists,
     // so at most 1 024 tokens; beyond that a from-scratch pass with HBM-resident lists follows, as in the dense path)
     const int nb = std::min(N[0], 1024);
     const int cb = std::min(C[0], 4 * nb);
-    const bool second = nb < N[0];   // a from-scratch list pass: table growth beyond the large tier (a failed speculation is
-                                     // redone window by window, below)
+    // lag mode (see the window loop): the 64-token first tier redoes its own failed speculations one window later and sends
+    // capacity overflows to the from-scratch list pass instead of a large-tier launch per window
+    will_lag = kSmallTokens == 64 && !eps;
+    { const char *e = getenv("MFA_VIT_LEAN"); if (e && e[0] == '0') will_lag = false; }
+    { const char *e = getenv("MFA_VIT_LAG"); if (e && e[0] == '0') will_lag = false; }
+    const bool second = nb < N[0] || will_lag;   // a from-scratch list pass: table growth beyond the large tier / the first tier
     Launch a{0, kSmallTokens, std::min(C[0], 4 * kSmallTokens), 0, second ? 1 : 0};
     a.N2 = nb; a.C2 = cb;
     plan.push_back(a);
@@ -1881,8 +1925,17 @@ int align_impl(mfa_ctx *c, const mfa_graph_batch *g, const float *d_loglikes, co
       const int K = L.code == 0 ? lazy->window : std::max(lazy->window, 256);
       p.windowed = 1; p.next_window = K;
       p.state_depth = lazy->plan.d_state_depth; p.band = (int32_t *)(base + w.band);
-      for (int t0 = 0; t0 < lazy->max_frames; t0 += K) {
+      // lagmode (the 64-token first tier only; MFA_VIT_LAG=0 turns it off): an utterance whose speculative window failed is not
+      // handed to the large tier — a launch that a handful of wavefronts can use — but falls one window behind: the next scoring
+      // launch scores the failed window again for it, with the proven band, the next first-tier launch redoes it, and so on to
+      // the end, where one extra round of launches finishes the stragglers.  The large tier keeps the capacity overflows.
+      const bool lagmode = lean && will_lag;
+      p.lagmode = lagmode ? 1 : 0; p2.lagmode = p.lagmode;
+      const int t_loop_end = lazy->max_frames + (lagmode ? K : 0);
+      for (int t0 = 0; t0 < t_loop_end; t0 += K) {
         MfaWindowScore ws;
+        memset(&ws, 0, sizeof(ws));
+        if (lagmode) { ws.lag = (const int32_t *)(base + w.vstate); ws.lag_stride = (int)(sizeof(VitState) / 4); ws.lag_word = 3; }
         ws.t_begin = t0; ws.window = K; ws.band = p.band; ws.utt_list = p.utt_list; ws.n_list = p.n_list;
         ws.cols_per_wave = L.code == 0 ? 0 : 32;   // list passes: few utterances, wide bands — spread the columns over wavefronts
         const bool spec = L.code == 0 && L.N2 > 0 && lists_in_lds && spec_slack > 0;   // (only the tiered first-beam pass speculates)
@@ -1901,6 +1954,10 @@ int align_impl(mfa_ctx *c, const mfa_graph_batch *g, const float *d_loglikes, co
             hipLaunchKernelGGL(viterbi_small_kernel<kSmallRounds>, dim3(n_utt), dim3(64), lds_small, c->stream, p);
           } else {
             launch_decoder();
+          }
+          if (lagmode) {      // nothing else per window: failed speculations lag, capacity overflows wait for the list pass below
+            MFA_DEBUG_POINT(c, "decoded window t0=%d K=%d (first tier, lag mode)", t0, K);
+            continue;
           }
           p2.windowed = 1; p2.next_window = K; p2.state_depth = p.state_depth; p2.band = p.band;
           p2.t_begin = t0; p2.t_end = t0 + K; p2.redo_mode = 2; p2.npark = p.npark; p2.grow = L.grow;

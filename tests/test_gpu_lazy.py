@@ -276,9 +276,19 @@ def test_plan_grouping_and_decoder_tier_do_not_change_results(engine, tri, monke
     monkeypatch.setenv("MFA_VIT_LEAN", "0")
     general = engine.align_features(g8, feats, fo, **kw)
     monkeypatch.delenv("MFA_VIT_LEAN")
+    # ... and how a failed speculation is redone: by the first tier itself one window later (lag mode, default) or by a
+    # large-tier launch right away (MFA_VIT_LAG=0) — with a short look-ahead so that windows really are redone
+    monkeypatch.setenv("MFA_LAZY_LOOKAHEAD", "8")
+    short = engine.align_features(g8, feats, fo, **kw)
+    monkeypatch.setenv("MFA_VIT_LAG", "0")
+    short_nolag = engine.align_features(g8, feats, fo, **kw)
+    monkeypatch.delenv("MFA_LAZY_LOOKAHEAD")
+    nolag = engine.align_features(g8, feats, fo, **kw)
+    monkeypatch.delenv("MFA_VIT_LAG")
     torch.cuda.synchronize()
     assert set(ref["status"].cpu().tolist()) <= {0, 1}
-    for other, what in ((one, "ungrouped plan"), (general, "general kernel as first tier")):
+    for other, what in ((one, "ungrouped plan"), (general, "general kernel as first tier"), (short, "8-arc look-ahead, lag mode"),
+                        (short_nolag, "8-arc look-ahead, large-tier redo"), (nolag, "large-tier redo")):
         for k in ("status", "ali", "words", "n_words", "like", "frame_like"):
             assert torch.equal(ref[k], other[k]), f"{k} differs with the {what}"
     # same cells, same values: column c of the grouped layout is the ungrouped layout's column of the same arcs
