@@ -10,4 +10,4 @@ for v in "MFA_VIT_LEAN=0" "MFA_VIT_LAG=0" "MFA_PLAN_GROUPS=1" "MFA_GMM_PRESPLIT=
 done
 # Expected to fail under a switch, because they assert the DEFAULT configuration itself: test_gpu_config2_fullsize (groups == 8)
 # under MFA_PLAN_GROUPS=1; test_speculative_lookahead_failures_fall_back_to_the_proven_band[6|24] (speculation fills fewer cells
-# than the proven band) under MFA_LAZY_LOOKAHEAD=63.  Round 3: everything else green under all eight switches.
+# than the proven band) under MFA_LAZY_LOOKAHEAD=16 and =63.  Round 3: everything else green under all eight switches.
