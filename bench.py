@@ -49,7 +49,9 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=4096, help="utterances per step per GPU")
+    ap.add_argument("--batch", type=int, default=8192,
+                    help="utterances per step per GPU (8 192 x 6 in flight hold about 160 GB of the 288 GB of HBM; measured 243 k "
+                         "utterances/s against 230 k with 4 096 x 6 and 232 k with 4 096 x 8)")
     ap.add_argument("--pool", type=int, default=0,
                     help="distinct synthetic utterances generated per rank (0 = one per batch slot: all distinct)")
     ap.add_argument("--workload", choices=["triphone", "mono"], default="triphone")
@@ -496,7 +498,7 @@ def main():
         prev_tf = None if mono else fm_np[np.array([int(s_[1:]) for s_ in spk_order]) % n_spk_total]
         ca = CorpusAligner(model.tm, model.am, model.tree, world_.lexicon, lda=lda_np, engine=eng,
                            options=AlignOptions(beam=args.beam, retry_beam=args.retry_beam, max_tokens=args.max_tokens,
-                                                bp_tokens_per_frame=args.bp_tokens, batch_frames=max(1024, B // 4) * 1001),
+                                                bp_tokens_per_frame=args.bp_tokens, batch_frames=1024 * 1001),
                            silence_phones=[pt.find("sil"), pt.find("spn")])
         for _ in range(3):    # warm-up at full size: the pinned staging buffers come in rotating sets of two and three
             ca.align(utts_e2e, make_ctm=False, previous_transforms=prev_tf)
