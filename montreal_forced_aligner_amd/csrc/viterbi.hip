@@ -588,7 +588,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     if (vs.done) return;                           // finished (or failed) in an earlier window: outputs are final
     n = vs.n; H = vs.H; bp_used = vs.bp_used; t = t_begin_u;
     if (p.redo_mode == 1 && n > N) {               // more live tokens than this tier holds: the large tier takes the window
-      if (lane == 0) p.w_redo[utt] = 1u;
+      if (lane == 0) p.w_redo[utt] = 1u;           // (cannot happen in lag mode: an utterance that outgrows the tier has left it)
       return;
     }
     if (n < 0 || n > N) { n = 0; status = ST_INTERNAL; }
@@ -607,9 +607,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 #pragma unroll
   for (int r = 0; r < kPre; r++) pre[r] = (row_cached && t < T && lane + 64 * r < P) ? ll[(size_t)t * P + lane + 64 * r] : 0.0f;
   WSYNC();
-  const bool spec = p.spec != 0 && p.windowed;
+  const bool spec = p.spec != 0 && p.windowed && lag == 0;
   if (spec) build_scored_bitmap(p, utt, lane, bm);
   bool viol = false;   // a score outside the scored columns was read this window
+  bool spec_failed = false;
 
 #ifdef VIT_STAMPS
   unsigned long long stamp_acc[12] = {0}, stamp_last;
@@ -943,7 +944,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     WSYNC();
     const u32 nslots = ctr[0], nstash = ctr[1];
     if (__any(bad_degree)) { status = ST_UNSUPPORTED; break; }
-    if (spec && __any(viol)) { status = ST_TOKEN_OVERFLOW; break; }   // reported as ST_GROW (p.grow): the list pass decodes it again
+    if (spec && __any(viol)) { status = ST_TOKEN_OVERFLOW; spec_failed = true; break; }   // first tier: the window is redone (large tier, or lag mode)
     if (nslots > (u32)N || nstash > (u32)C || cand_base > (u32)C) { status = ST_TOKEN_OVERFLOW; break; }
     if (nslots == 0) { n = 0; t++; break; }  // everything pruned: no surviving token
 
@@ -1179,6 +1180,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   if (p.redo_mode == 1 && status == ST_TOKEN_OVERFLOW) {
     // small tier out of slots: nothing parked has been touched (lists and decoder state are written at a window's END
     // only; the back-pointer records of this window are simply written again) — the large tier redoes the window
+    if (p.lagmode) {
+      // lag mode (see viterbi_small_kernel): a failed speculation puts the utterance one window behind — this kernel redoes the
+      // window in its next launch, on the proven band; a capacity overflow sends it to the from-scratch list pass
+      if (lane == 0) {
+        VitState vs;
+        if (spec_failed) {
+          if (resume) vs = p.w_vstate[utt];
+          else { vs.n = 1; vs.cur = 0; vs.H = 1000u; vs.pad1 = 0; vs.bp_used = 0; }     // (window 0: nothing was parked yet)
+          vs.done = 0; vs.pad0 = 1;
+        } else {
+          vs.n = 0; vs.cur = 0; vs.done = 1; vs.pad0 = 0; vs.H = 1000u; vs.pad1 = 0; vs.bp_used = 0;
+          p.status[utt] = ST_GROW; p.n_words[utt] = 0; p.like[utt] = 0.0f;
+        }
+        p.w_vstate[utt] = vs;
+      }
+      return;
+    }
     if (lane == 0) p.w_redo[utt] = 1u;
     return;
   }
@@ -1817,8 +1835,7 @@ int align_impl(mfa_ctx *c, const mfa_graph_batch *g, const float *d_loglikes, co
     const int cb = std::min(C[0], 4 * nb);
     // lag mode (see the window loop): the 64-token first tier redoes its own failed speculations one window later and sends
     // capacity overflows to the from-scratch list pass instead of a large-tier launch per window
-    will_lag = kSmallTokens == 64 && !eps;
-    { const char *e = getenv("MFA_VIT_LEAN"); if (e && e[0] == '0') will_lag = false; }
+    will_lag = true;                             // (either first tier: the 64-token kernel or the general one — epsilon batches)
     { const char *e = getenv("MFA_VIT_LAG"); if (e && e[0] == '0') will_lag = false; }
     const bool second = nb < N[0] || will_lag;   // a from-scratch list pass: table growth beyond the large tier / the first tier
     Launch a{0, kSmallTokens, std::min(C[0], 4 * kSmallTokens), 0, second ? 1 : 0};
@@ -1925,11 +1942,13 @@ int align_impl(mfa_ctx *c, const mfa_graph_batch *g, const float *d_loglikes, co
       const int K = L.code == 0 ? lazy->window : std::max(lazy->window, 256);
       p.windowed = 1; p.next_window = K;
       p.state_depth = lazy->plan.d_state_depth; p.band = (int32_t *)(base + w.band);
-      // lagmode (the 64-token first tier only; MFA_VIT_LAG=0 turns it off): an utterance whose speculative window failed is not
-      // handed to the large tier — a launch that a handful of wavefronts can use — but falls one window behind: the next scoring
-      // launch scores the failed window again for it, with the proven band, the next first-tier launch redoes it, and so on to
-      // the end, where one extra round of launches finishes the stragglers.  The large tier keeps the capacity overflows.
-      const bool lagmode = lean && will_lag;
+      // lagmode (the tiered first-beam pass, whichever kernel is its first tier; MFA_VIT_LAG=0 turns it off): an utterance whose
+      // speculative window failed is not handed to the large tier — a launch that a handful of wavefronts can use, one workgroup
+      // with up to 100 KB of LDS per utterance of the batch to find them — but falls one window behind: the next scoring launch
+      // scores the failed window again for it, with the proven band, the next first-tier launch redoes it, and so on to the end,
+      // where one extra round of launches finishes the stragglers.  Capacity overflows wait for the from-scratch list pass.
+      const bool tiered_pass = L.N2 > 0 && lists_in_lds && L.code == 0;
+      const bool lagmode = tiered_pass && will_lag;
       p.lagmode = lagmode ? 1 : 0; p2.lagmode = p.lagmode;
       const int t_loop_end = lazy->max_frames + (lagmode ? K : 0);
       for (int t0 = 0; t0 < t_loop_end; t0 += K) {
