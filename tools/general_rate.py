@@ -1,6 +1,7 @@
 """Rate of the general-graph decoder (mfa_align_general_batch: ε input arcs, one thread per utterance) on configs[2]-shaped
 utterances whose training graphs were rewritten with ε arcs on a third of their arcs — next to the fast path on the
-equivalent ε-free graphs.  GPU box only:  python tools/general_rate.py [n_utt]
+equivalent ε-free graphs.  GPU box only:  python tools/general_rate.py [n_utt] [eps_fraction]
+(eps_fraction: share of the arcs split by an ε arc, default 0.3 — far more than a compiled training graph carries.)
 """
 import sys
 import time
@@ -17,6 +18,7 @@ from tests.test_gpu_general import _with_eps                            # noqa: 
 
 def main():
     n_utt = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+    frac = float(sys.argv[2]) if len(sys.argv) > 2 else 0.3
     engine = AlignmentEngine(0)
     world = synth.SynthWorld.build()
     engine.configure_mfcc()
@@ -41,7 +43,8 @@ def main():
     scaled = model.tm.scaled_log_probs(1.0, 0.1)
     plain = [G.add_transition_probs(gc.compile_fst(u[1]), scaled) for u in utts]
     rng = np.random.default_rng(5)
-    eps = [_with_eps(rng, f) for f in plain]
+    eps = [_with_eps(rng, f, frac) for f in plain]
+    print(f"epsilon arcs: {sum(int((f.arcs['ilabel'] == 0).sum()) for f in eps)} of {sum(f.num_arcs for f in eps)} arcs", flush=True)
     rep = (n_utt + pool - 1) // pool
     pcm = [u[0] for u in utts] * rep
     spk = [u[3] for u in utts] * rep
