@@ -7,6 +7,7 @@
 // (tests/test_graph_native_cpu.py compares the two on random transcripts).  No GPU code, no torch; built with g++.
 #include "../../include/mfa_graph.h"
 
+#include <chrono>
 #include <algorithm>
 #include <array>
 #include <atomic>
@@ -684,8 +685,7 @@ void minimize_encoded(std::vector<DArc> &arcs, std::vector<int> &off, std::vecto
   arcs.swap(out); off.swap(out_off); fin.swap(of); has.swap(oh);
 }
 
-#ifdef MFA_GC_TIMERS
-#include <chrono>
+#ifdef MFA_GC_TIMERS   // (phase timers of expand_hmm, printed by mfa_gc_finish: g++ -DMFA_GC_TIMERS)
 static std::atomic<long long> g_ns[6];
 struct PhaseClock {
   std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
