@@ -1256,7 +1256,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 //   GetCutoff's min_active rule: the (min_active + 1 − k)-th smallest cost outside the beam by ballot quickselect (a
 //   handful of compare+ballot steps) instead of ranking every token against every other.
 constexpr int kSmallN = 64;
-template <int kRounds>
+template <int kRounds, bool kEps = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void viterbi_small_kernel(VitParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int N = kSmallN, C = 64 * kRounds;
@@ -1326,6 +1326,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
   u32 *cntord = l_an0 + 2 * N;               // [C]: owner map of the candidate ordinals, then bucket sizes → exclusive sums
   u32 *ctr = cntord + C;                     // [2]
   u32 *bm = ctr + 4;                         // [kBmWords] columns scored for this window (speculative look-ahead only)
+  // epsilon closure (kEps; as the general kernel's): per slot its list position, the inverse, the winning epsilon arc, a scratch
+  // word for the winner vote, the state's epsilon-arc info; and the stack of ProcessNonemitting
+  u32 *e_pos = bm + kBmWords;                // [N]
+  u32 *e_inv = e_pos + N;                    // [N]
+  u32 *e_arc = e_inv + N;                    // [N]
+  u32 *e_tmp = e_arc + N;                    // [N]
+  u32 *e_info = e_tmp + N;                   // [N]
+  u32 *e_stk = e_info + N;                   // [2N]
   // (no staged score row: a candidate reads its score straight from L2 — measured faster than the general kernel's LDS
   //  row cache here, and 2 KB less LDS per wavefront leaves room for a scoring workgroup next to sixteen of these)
 
@@ -1336,9 +1344,91 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
   for (u32 i = lane; i < HM; i += 64) hmap[i] = kEmpty;
   for (int i = lane; i < C; i += 64) cntord[i] = 0;
   if (lane == 0) ctr[0] = 0;
+  if constexpr (kEps) e_tmp[lane] = 0xFFFFFFFFu;
   int cur = 0;
   if (!resume) {
-    if (lane == 0) { l_state0[0] = (u32)start; l_cost0[0] = 0.0; l_an0[0] = ((u32)arc_off[start] << 7) | (u32)(arc_off[start + 1] - arc_off[start]); }
+    if constexpr (kEps) {
+      // InitDecoding's ProcessNonemitting(cutoff = FLT_MAX), as in viterbi_kernel<·, true>: the wavefront walks Kaldi's
+      // sequential algorithm (a stack; the popped token's epsilon arcs one after the other; destinations looked up by a ballot
+      // over the tokens created so far), then the hash-list order gives the initial list and its back-pointer records —
+      // bp[0 .. n): the start token's carries arc 0xFFFFFFFF, the others an epsilon arc and a position in this list.
+      u32 nc_ = 1u;
+      if (lane == 0) {
+        s_state[0] = (u32)start; s_cost[0] = (u64)__double_as_longlong(0.0); e_arc[0] = 0xFFFFFFFFu; e_inv[0] = 0u;
+        s_an[0] = ((u32)arc_off[start] << 7) | min((u32)p.g.d_state_nemit[so + start], 127u);
+        e_stk[0] = 0u;
+      }
+      WSYNC();
+      {
+        u32 sp = 1u;
+        int guard = 0;
+        bool over = false;
+        while (sp > 0u && !over) {
+          if (++guard > p.eps_pops) { over = true; break; }
+          const u32 e = e_stk[sp - 1u];
+          sp--;
+          const double ce = __longlong_as_double((long long)s_cost[e]);
+          const u32 ei = p.w_epsinfo[(size_t)utt * p.eps_stride + s_state[e]];
+          const u32 n_eps = ei & 127u, first = ei >> 7;
+          for (u32 k = 0; k < n_eps && !over; k++) {
+            const uint4 rec = a_rec[first + k];
+            const u32 d = rec.x;
+            const double ncst = ce + (double)__uint_as_float(rec.w);
+            if (ncst > (double)3.4028234663852886e38f) continue;      // cutoff = numeric_limits<float>::max()
+            const u64 hit = __ballot((u32)lane < nc_ && s_state[lane] == d);
+            const u32 found = hit ? (u32)__ffsll((long long)hit) - 1u : kEmpty;
+            bool pushed = false; u32 who = 0u;
+            if (found == kEmpty) {
+              if (nc_ >= (u32)N) { over = true; break; }
+              if (lane == 0) {
+                s_state[nc_] = d; s_cost[nc_] = (u64)__double_as_longlong(ncst); e_arc[nc_] = first + k; e_inv[nc_] = e; s_an[nc_] = rec.y;
+              }
+              who = nc_; nc_++; pushed = true;
+            } else if (__longlong_as_double((long long)s_cost[found]) > ncst) {
+              if (lane == 0) { s_cost[found] = (u64)__double_as_longlong(ncst); e_arc[found] = first + k; e_inv[found] = e; }
+              who = found; pushed = true;
+            }
+            if (pushed) {
+              if (sp >= 2u * (u32)N) { over = true; break; }
+              if (lane == 0) e_stk[sp] = who;
+              sp++;
+            }
+            WSYNC();
+          }
+        }
+        if (over) { hand_over(); return; }
+      }
+      // hash-list order: position of token c = number of tokens whose (bucket's first creator, own index) is smaller
+      if ((u32)lane < nc_) {
+        const u32 c_ = (u32)lane;
+        const u32 bc = s_state[c_] % H;
+        u32 lead_c = c_;
+        for (u32 x = 0; x < c_; x++) if (s_state[x] % H == bc) { lead_c = x; break; }
+        u32 pos_ = 0;
+        for (u32 x = 0; x < nc_; x++) {
+          if (x == c_) continue;
+          const u32 bx = s_state[x] % H;
+          u32 lead_x = x;
+          for (u32 y = 0; y < x; y++) if (s_state[y] % H == bx) { lead_x = y; break; }
+          if (lead_x < lead_c || (lead_x == lead_c && x < c_)) pos_++;
+        }
+        e_pos[c_] = pos_;
+      }
+      WSYNC();
+      if ((u32)lane < nc_) {
+        const u32 c_ = (u32)lane, pos_ = e_pos[c_];
+        l_state0[pos_] = s_state[c_];
+        l_cost0[pos_] = __longlong_as_double((long long)s_cost[c_]);
+        l_an0[pos_] = s_an[c_];
+        bp[pos_] = ((u64)e_arc[c_] << 32) | (u64)(c_ == 0u ? 0u : e_pos[e_inv[c_]]);
+      }
+      n = (int)nc_;
+      bp_used = nc_;
+      __threadfence_block();
+      WSYNC();
+    } else {
+      if (lane == 0) { l_state0[0] = (u32)start; l_cost0[0] = 0.0; l_an0[0] = ((u32)arc_off[start] << 7) | (u32)(arc_off[start + 1] - arc_off[start]); }
+    }
   } else if (lane < n) {
     l_state0[lane] = park_state[lane]; l_an0[lane] = park_an[lane]; l_cost0[lane] = park_cost[lane];
   }
@@ -1360,7 +1450,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     const u32 an = lane < n ? c_an[lane] : 0u;
     // The cheapest token's cost is the cheapest candidate of the previous frame (the global minimum is always created and
     // wins its slot, and a slot's cost is its candidate's, bit for bit): carried over instead of a wavefront reduction.
-    const double best = have_best ? best_carry : wave_min_f64(cst);
+    const double best = (have_best && !kEps) ? best_carry : wave_min_f64(cst);   // (a closure token can undercut every candidate)
     const u32 best_i = (u32)__ffsll((long long)__ballot(lane < n && cst == best)) - 1u;
     double wcut = INFINITY; float abeam = INFINITY;
     if (n > kMinActive) {
@@ -1507,69 +1597,211 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     const u32 nslots = ctr[0];
     if (nslots > (u32)N || bp_used + nslots > bp_cap) { overflow = true; break; }
     if (nslots == 0) { n = 0; t++; break; }            // everything pruned: no surviving token
-    // ---------------- Kaldi list order of the new tokens (one slot per lane)
+    // ---------------- Kaldi list order of the new tokens (one slot per lane): ordinal of the hash bucket's first creator and
+    // rank inside the bucket; bucket sizes at the leaders' ordinals, then exclusive sums = where every bucket starts.
+    // (kEps: slots created by the epsilon closure carry ordinals past the candidates': s_F = 0x80000000 | k.)
     u32 aux = 0;
-    if ((u32)lane < nslots) {
-      const u32 d = s_state[lane], Fj = s_F[lane];
-      u32 Fb = Fj, nb = 1, rank = 0;
-      if ((u32)S > H) {
-        nb = 0;
-        for (u32 m = d % H; m < (u32)S; m += H) {
-          u32 h = (m * 2654435761u) >> hshift, sm = kEmpty;
-          for (;;) {
-            const u32 v = hmap[h];
-            if (v == kEmpty) break;
-            if (v < (u32)N && s_state[v] == m) { sm = v; break; }
-            h = (h + 1u) & hmask;
-          }
-          if (sm < (u32)N) {
-            const u32 Fm = s_F[sm];
-            nb++;
-            if (Fm < Fj) rank++;
-            if (Fm < Fb) Fb = Fm;
+    auto order_lanes = [&](u32 ns, u32 n_ord) {
+      aux = 0;
+      if ((u32)lane < ns) {
+        const u32 d = s_state[lane], Fj = s_F[lane];
+        u32 Fb = Fj, nb = 1, rank = 0;
+        if ((u32)S > H) {
+          nb = 0;
+          for (u32 m = d % H; m < (u32)S; m += H) {
+            u32 h = (m * 2654435761u) >> hshift, sm = kEmpty;
+            for (;;) {
+              const u32 v = hmap[h];
+              if (v == kEmpty) break;
+              if (v < (u32)N && s_state[v] == m) { sm = v; break; }
+              h = (h + 1u) & hmask;
+            }
+            if (sm < (u32)N) {
+              const u32 Fm = s_F[sm];
+              nb++;
+              if (Fm < Fj) rank++;
+              if (Fm < Fb) Fb = Fm;
+            }
           }
         }
+        u32 ord_b = t_cbase[(Fb >> kArcBits) & (u32)(N - 1)] + (Fb & (kMaxArcsPerState - 1));
+        if constexpr (kEps) { if (Fb >> 31) ord_b = ctot + (Fb & 0x7FFFFFFFu); }
+        aux = (rank << 24) | ord_b;
+        if (Fb == Fj) cntord[ord_b] = nb;
       }
-      const u32 ord_b = t_cbase[Fb >> kArcBits] + (Fb & (kMaxArcsPerState - 1));
-      aux = (rank << 24) | ord_b;
-      if (Fb == Fj) cntord[ord_b] = nb;
-    }
-    WSYNC();
-    {
-      u32 carry = 0;
+      WSYNC();
+      {
+        u32 carry = 0;
+        const int rounds_ord = (int)((n_ord + 63u) >> 6);
 #pragma unroll
-      for (int r = 0; r < kRounds; r++) {
-        if (r < rounds) {
-          const u32 o = (u32)lane + 64u * r;
-          const u32 v = cntord[o];
-          const u32 inc = incl_scan_sum(v);
-          if (v != 0) cntord[o] = carry + inc - v;
-          carry += (u32)__builtin_amdgcn_readlane((int)inc, 63);
+        for (int r = 0; r < kRounds; r++) {
+          if (r < rounds_ord) {
+            const u32 o = (u32)lane + 64u * r;
+            const u32 v = cntord[o];
+            const u32 inc = incl_scan_sum(v);
+            if (v != 0) cntord[o] = carry + inc - v;
+            carry += (u32)__builtin_amdgcn_readlane((int)inc, 63);
+          }
+        }
+      }
+      WSYNC();
+    };
+    order_lanes(nslots, ctot);
+    u32 nslots_f = nslots;
+    if constexpr (kEps) {
+      // ---------------- FasterDecoder::ProcessNonemitting(next_weight_cutoff), as in viterbi_kernel<·, true>: the pops one after
+      // the other in Kaldi's order (stack of the list, last token on top), the popped state's epsilon arcs relaxed by the lanes.
+      const double eps_cut = run + (double)abeam;
+      u32 my_info = 0;
+      if ((u32)lane < nslots) { my_info = p.w_epsinfo[(size_t)utt * p.eps_stride + s_state[lane]]; e_info[lane] = my_info; }
+      if (__any((my_info & 127u) != 0u)) {
+        bool eps_broken = false;
+        if ((u32)lane < nslots) {
+          const u32 pos = cntord[aux & 0xFFFFFFu] + (aux >> 24);
+          if (pos < nslots) e_inv[pos] = (u32)lane; else eps_broken = true;
+        }
+        if (__any(eps_broken)) { overflow = true; break; }
+        WSYNC();
+        u32 sp = 0;
+        {
+          const u32 j = (u32)lane < nslots ? e_inv[lane] : 0u;
+          const bool has = (u32)lane < nslots && (e_info[j] & 127u) != 0u;
+          const u64 m = __ballot(has);
+          if (has) e_stk[(u32)__popcll(m & ((1ull << lane) - 1ull))] = j;
+          sp = (u32)__popcll(m);
+        }
+        WSYNC();
+        u32 eord = 0;
+        int guard = 0;
+        bool eps_over = false;
+        while (sp > 0u) {
+          if (++guard > p.eps_pops) { eps_over = true; break; }
+          const u32 e = e_stk[sp - 1u];
+          sp--;
+          const double ce = dunkey(s_cost[e]);
+          if (ce > eps_cut) continue;
+          const u32 ei = e_info[e];
+          const u32 n_eps = ei & 127u, first = ei >> 7;
+          if (n_eps == 0u) continue;
+          if (n_eps > 64u) { eps_over = true; break; }
+          const bool valid = (u32)lane < n_eps;
+          u32 nxe = 0u, nane = 0u; float w = 0.0f;
+          if (valid) { const uint4 rec = a_rec[first + (u32)lane]; nxe = rec.x; nane = rec.y; w = __uint_as_float(rec.w); }
+          const double nc = ce + (double)w;           // Kaldi: new_tok->cost_ = tok->cost_ + arc.weight (no acoustic term)
+          const bool ok0 = valid && !(nc > eps_cut);
+          u32 sle = kEmpty;
+          {
+            bool pend = ok0; u32 h = (nxe * 2654435761u) >> hshift;
+            while (__any(pend)) {
+              if (pend) {
+                const u32 v = hmap[h];
+                if (v == kEmpty) {
+                  if (atomicCAS(&hmap[h], kEmpty, kClaim) == kEmpty) {
+                    const u32 my = atomicAdd(&ctr[0], 1u);
+                    if (my < (u32)N) {
+                      s_state[my] = nxe; s_an[my] = nane; s_cost[my] = kKeyInf; s_F[my] = kEmpty; s_W[my] = kEmpty; s_bucket[my] = h;
+                      hmap[h] = my;
+                      sle = my;
+                    } else {
+                      hmap[h] = kOver;
+                    }
+                    pend = false;
+                  }
+                } else if (v == kOver) {
+                  pend = false;
+                } else if (v != kClaim) {
+                  if (s_state[v] == nxe) { sle = v; pend = false; }
+                  else h = (h + 1u) & hmask;
+                }
+              }
+              WSYNC();
+              if (ctr[0] > (u32)N) break;
+            }
+          }
+          if (ctr[0] > (u32)N) { eps_over = true; break; }
+          const bool ok = ok0 && sle != kEmpty;
+          const u64 okm = __ballot(ok);
+          const u64 pre = ok ? s_cost[sle] : kKeyInf;  // before this pop: infinite = the state was not in the list
+          const bool is_new = ok && pre == kKeyInf;
+          if (is_new) e_info[sle] = p.w_epsinfo[(size_t)utt * p.eps_stride + nxe];
+          // earlier arcs of this pop into the same state (rare): what Kaldi's sequential loop would have left there
+          double pm = INFINITY; bool first_dup = true;
+          for (u32 j = 0; j < n_eps; j++) {
+            const u32 nxj = (u32)__builtin_amdgcn_readlane((int)nxe, (int)j);
+            const double ncj = readlane_f64(nc, (int)j);
+            if (((okm >> j) & 1ull) && (u32)lane > j && nxj == nxe) { pm = min_f64(pm, ncj); first_dup = false; }
+          }
+          const bool push = ok && (is_new ? (first_dup || nc < pm) : (nc < min_f64(dunkey(pre), pm)));
+          WSYNC();                                    // every lane has read `pre`
+          if (push) atomicMin(&s_cost[sle], dkey(nc));
+          if (is_new) atomicMin(&s_F[sle], 0x80000000u | (eord + (u32)__popcll(okm & ((1ull << lane) - 1ull))));
+          WSYNC();
+          const bool win = push && dkey(nc) == s_cost[sle];
+          if (win) atomicMin(&e_tmp[sle], (u32)lane);
+          WSYNC();
+          if (win && e_tmp[sle] == (u32)lane) { s_W[sle] = 0x80000000u | e; e_arc[sle] = first + (u32)lane; }
+          WSYNC();
+          if (win) e_tmp[sle] = 0xFFFFFFFFu;
+          const bool pp = push && (e_info[sle] & 127u) != 0u;
+          const u64 pmk = __ballot(pp);
+          const u32 at = sp + (u32)__popcll(pmk & ((1ull << lane) - 1ull));
+          if (pp && at < 2u * (u32)N) e_stk[at] = sle;
+          sp += (u32)__popcll(pmk);
+          if (sp > 2u * (u32)N) { eps_over = true; break; }
+          eord += (u32)__popcll(okm);
+          if (ctot + eord > (u32)C) { eps_over = true; break; }
+          WSYNC();
+        }
+        if (eps_over) { overflow = true; break; }
+        nslots_f = ctr[0];
+        if (nslots_f > (u32)N || bp_used + nslots_f > bp_cap) { overflow = true; break; }
+        if (nslots_f > nslots) {
+          // new states: the list order is worked out again over all slots (a new state goes to the end of its bucket's chain)
+          if ((u32)lane < nslots) cntord[aux & 0xFFFFFFu] = 0u;
+          WSYNC();
+          order_lanes(nslots_f, ctot + eord);
         }
       }
     }
-    WSYNC();
     // ---------------- write the new list + back-pointers, reset the tables
     bool broken = false;
-    if ((u32)lane < nslots) {
+    if constexpr (kEps) {
+      if ((u32)lane < nslots_f) e_pos[lane] = cntord[aux & 0xFFFFFFu] + (aux >> 24);
+      WSYNC();
+    }
+    if ((u32)lane < nslots_f) {
       const u32 pos = cntord[aux & 0xFFFFFFu] + (aux >> 24);
       const u32 d = s_state[lane], W = s_W[lane];
-      const u32 ppos = W >> kArcBits, k = W & (kMaxArcsPerState - 1);
-      if (pos >= nslots || ppos >= (u32)n || d >= (u32)S) broken = true;
-      else {
-        const u32 arc = (c_an[ppos] >> 7) + k;
-        n_state[pos] = d;
-        n_an[pos] = s_an[lane];
-        n_cost[pos] = dunkey(s_cost[lane]);
-        bp[bp_used + pos] = ((u64)arc << 32) | (u64)ppos;
+      bool eps_w = false;
+      if constexpr (kEps) eps_w = (W >> 31) != 0u;
+      if (eps_w) {
+        // the token came over an epsilon arc: its predecessor is a token of THIS frame's list (no frame consumed)
+        const u32 src = W & 0x7FFFFFFFu;
+        if (pos >= nslots_f || src >= nslots_f || d >= (u32)S) broken = true;
+        else {
+          n_state[pos] = d;
+          n_an[pos] = s_an[lane];
+          n_cost[pos] = dunkey(s_cost[lane]);
+          bp[bp_used + pos] = ((u64)e_arc[lane] << 32) | (u64)e_pos[src];
+        }
+      } else {
+        const u32 ppos = W >> kArcBits, k = W & (kMaxArcsPerState - 1);
+        if (pos >= nslots_f || ppos >= (u32)n || d >= (u32)S) broken = true;
+        else {
+          const u32 arc = (c_an[ppos] >> 7) + k;
+          n_state[pos] = d;
+          n_an[pos] = s_an[lane];
+          n_cost[pos] = dunkey(s_cost[lane]);
+          bp[bp_used + pos] = ((u64)arc << 32) | (u64)ppos;
+        }
       }
     }
     if (__any(broken)) { overflow = true; break; }     // (cannot happen; the large tier would report ST_INTERNAL)
     WSYNC();
-    if ((u32)lane < nslots) { hmap[s_bucket[lane]] = kEmpty; cntord[aux & 0xFFFFFFu] = 0; }
+    if ((u32)lane < nslots_f) { hmap[s_bucket[lane]] = kEmpty; cntord[aux & 0xFFFFFFu] = 0; }
     if (lane == 0) { tokoff[t] = (u32)bp_used; ctr[0] = 0; }
-    bp_used += nslots;
-    n = (int)nslots;
+    bp_used += nslots_f;
+    n = (int)nslots_f;
     cur ^= 1;
     best_carry = run; have_best = true;
     WSYNC();
@@ -1646,7 +1878,7 @@ __global__ __launch_bounds__(64) void viterbi_finish_kernel(VitParams p) {
   if (lane == 0) { VitState d = vs; d.done = 1; p.w_vstate[utt] = d; }
   finalize_utterance(p, utt, lane, ST_OK, T, T, vs.n, c_state, c_cost, p.g.d_final + so, p.w_bp + (size_t)f0 * p.bpf,
                      p.w_tokoff + f0 + utt, f0, ab_, p.g.d_arc_weight + ab_, p.g.d_arc_col + ab_, p.ll + p.ll_off[utt],
-                     p.ll_cols[utt]);
+                     p.ll_cols[utt], p.w_epsinfo != nullptr, vs.bp_used, (u64)T * (u64)p.bpf);
 }
 
 // Build the retry list: utterances left pending by the first pass.
@@ -1930,8 +2162,9 @@ int align_impl(mfa_ctx *c, const mfa_graph_batch *g, const float *d_loglikes, co
     };
     // first tier of the windowed pass: the dedicated 64-token kernel (MFA_VIT_LEAN=0: the general kernel as first tier)
     constexpr int kSmallRounds = 3;
-    const size_t lds_small = (size_t)kSmallN * (8 + 16 + 6 * 4 + 8 + 8) + 256 * 4 + (size_t)64 * kSmallRounds * 4 + 16 + (size_t)kBmWords * 4;
-    bool lean = lazy && L.N2 > 0 && lists_in_lds && L.code == 0 && L.N == kSmallN && !eps;
+    const size_t lds_small = (size_t)kSmallN * (8 + 16 + 6 * 4 + 8 + 8) + 256 * 4 + (size_t)64 * kSmallRounds * 4 + 16 + (size_t)kBmWords * 4 +
+                             (eps ? (size_t)kSmallN * 7 * 4 : 0);      // (epsilon closure: position / inverse / arc / vote / info + stack)
+    bool lean = lazy && L.N2 > 0 && lists_in_lds && L.code == 0 && L.N == kSmallN;
     { const char *e = getenv("MFA_VIT_LEAN"); if (e && e[0] == '0') lean = false; }
     if (!lazy) {
       launch_decoder();
@@ -1970,7 +2203,8 @@ int align_impl(mfa_ctx *c, const mfa_graph_batch *g, const float *d_loglikes, co
           p.redo_mode = 1;
           if (lean) {
             KernelTimer kt1(c, MFA_K_VITERBI);
-            hipLaunchKernelGGL(viterbi_small_kernel<kSmallRounds>, dim3(n_utt), dim3(64), lds_small, c->stream, p);
+            if (eps) hipLaunchKernelGGL((viterbi_small_kernel<kSmallRounds, true>), dim3(n_utt), dim3(64), lds_small, c->stream, p);
+            else hipLaunchKernelGGL((viterbi_small_kernel<kSmallRounds, false>), dim3(n_utt), dim3(64), lds_small, c->stream, p);
           } else {
             launch_decoder();
           }

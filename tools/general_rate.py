@@ -18,7 +18,7 @@ from tests.test_gpu_general import _with_eps                            # noqa: 
 
 def main():
     n_utt = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-    frac = float(sys.argv[2]) if len(sys.argv) > 2 else 0.3
+    frac = float(sys.argv[2]) if len(sys.argv) > 2 and not sys.argv[2].startswith('-') else 0.3
     engine = AlignmentEngine(0)
     world = synth.SynthWorld.build()
     engine.configure_mfcc()
@@ -44,6 +44,13 @@ def main():
     plain = [G.add_transition_probs(gc.compile_fst(u[1]), scaled) for u in utts]
     rng = np.random.default_rng(5)
     eps = [_with_eps(rng, f, frac) for f in plain]
+    if "--no-start-eps" in sys.argv:      # (measurement aid: graphs whose start state has no epsilon arc)
+        def start_has_eps(f):
+            a0, a1 = int(f.arc_offsets[f.start]), int(f.arc_offsets[f.start + 1])
+            return bool((f.arcs["ilabel"][a0:a1] == 0).any())
+        for k in range(len(eps)):
+            while start_has_eps(eps[k]):
+                eps[k] = _with_eps(rng, plain[k], frac)
     print(f"epsilon arcs: {sum(int((f.arcs['ilabel'] == 0).sum()) for f in eps)} of {sum(f.num_arcs for f in eps)} arcs", flush=True)
     rep = (n_utt + pool - 1) // pool
     pcm = [u[0] for u in utts] * rep

@@ -38,7 +38,14 @@ for seed in range(seed0, seed0 + n_seeds):
             eps = rng.random(len(arcs)) < 0.2
             arcs["ilabel"][eps] = 0
             arcs["olabel"][eps & (rng.random(len(arcs)) < 0.7)] = 0      # (few word labels on epsilon arcs: keeps words <= frames mostly)
+            arcs["weight"][eps & (rng.random(len(arcs)) < 0.3)] = 0.0    # zero-weight epsilon arcs (cycles of them included): ties
+            src = np.repeat(np.arange(f.num_states), np.diff(f.arc_offsets))
+            neg = eps & (arcs["nextstate"] > src) & (rng.random(len(arcs)) < 0.2)
+            arcs["weight"][neg] -= 0.5
             g = K.Fst(f.start, f.arc_offsets, arcs, f.final)
+            if helpers.has_negative_eps_cycle(g):                        # Kaldi's closure does not terminate on one
+                arcs["weight"][neg] += 0.5
+                g = K.Fst(f.start, f.arc_offsets, arcs, f.final)
             if not eng.needs_general_decoder(g):
                 f = g
         fsts.append(f)
